@@ -1,0 +1,137 @@
+/*
+ * pips_hip.h -- C ABI of libpips_hip.so: the PIPs particle-tracker inference hot path
+ * (reference: aharley/pips  nets/pips.py:428-611, Pips.forward) as hand-written HIP for
+ * gfx950 (MI355X / CDNA4).
+ *
+ * The reference has no FFI of its own: the operator API of the path is the Python class
+ * nets.pips.Pips (nets/pips.py:400-611).  The replacement keeps that class
+ * (pips_amd.Pips) and puts ALL arithmetic behind the entry points below; each one names
+ * the reference code it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative PIPS_E_* code; the text of the
+ *     last error of the calling thread is available from pips_last_error();
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - the caller owns every buffer (inputs, outputs, weight arena, workspace); the
+ *     library never allocates, frees or synchronises, and keeps no mutable global state:
+ *     calls are re-entrant, stream-ordered on `stream` (a hipStream_t passed as void*)
+ *     and safe to capture in a hipGraph;
+ *   - all tensors are dense fp32 unless stated; "frames" F = B*S; mixer rows are ordered
+ *     m = (b*N + n)*S + s ("particle-major"), map levels are channel-last
+ *     [F][H_l][W_l][128].
+ */
+#ifndef PIPS_HIP_H
+#define PIPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIPS_OK            0
+#define PIPS_E_ARG        -1   /* bad shape / null pointer / unsupported size        */
+#define PIPS_E_WORKSPACE  -2   /* workspace too small                                */
+#define PIPS_E_LAUNCH     -3   /* hipLaunch error (see pips_last_error)              */
+
+#define PIPS_S        8        /* frames per window, fixed by the mixer weights      */
+#define PIPS_C        128      /* latent channels            nets/pips.py:408        */
+#define PIPS_LEVELS   4        /* correlation pyramid levels nets/pips.py:409        */
+#define PIPS_RADIUS   3        /* correlation radius         nets/pips.py:410        */
+#define PIPS_NCORR    196      /* LEVELS * (2R+1)^2                                  */
+#define PIPS_KIN      519      /* mixer input width          nets/pips.py:289        */
+#define PIPS_KIN_PAD  544      /* same, zero-padded to a multiple of 32              */
+#define PIPS_DMIX     512      /* mixer width                nets/pips.py:298        */
+#define PIPS_DEPTH    12       /* mixer depth                nets/pips.py:300        */
+#define PIPS_NOUT     1040     /* S*(C+2)                    nets/pips.py:299        */
+#define PIPS_NPARAMS  200      /* tensors in the reference state dict                */
+
+const char* pips_last_error(void);
+int         pips_abi_version(void);
+
+/* ---- weights ------------------------------------------------------------------------
+ * Replaces: nn.Module parameter storage + load_state_dict (saverloader.py:58-59).
+ * `params[i]` is the device pointer of the i-th tensor of the reference state dict in
+ * its canonical order (nets/pips.py:400-426; pips_amd/weights.py:param_table), in the
+ * reference's own layout.  The arena receives the kernel-side layouts
+ * (conv [Cout][kh][kw][Cin], stem [ci*kh*kw][64], first Linear zero-padded to 544
+ * columns, updater Linear transposed, the rest verbatim). */
+size_t pips_weight_arena_bytes(void);
+int    pips_repack_weights(const void* const* params_host, int nparams, void* arena, void* stream);
+
+/* ---- whole forward -------------------------------------------------------------------
+ * Replaces: Pips.forward, inference branch (nets/pips.py:428-611 minus the dead fcp
+ * upsample :504-511, the sw visualisation branches and the losses :600-606).
+ *   rgbs        (B,S,3,H,W) fp32 0..255, NCHW exactly as callers pass it (demo.py:40)
+ *   xys         (B,N,2) pixels
+ *   coords_init (B,S,N,2) pixels or NULL   (nets/pips.py:452-455)
+ *   feat_init   (B,N,128) or NULL          (nets/pips.py:461-465)
+ *   times       (S) = torch.linspace(0,S,S) (nets/pips.py:519)
+ *   out_trajs   (iters+1,B,S,N,2) pixels: entry 0 = initial coords*stride
+ *               (coord_predictions2[0]), entries 1.. = coord_predictions
+ *   out_vis     (B,S,N) logits             (nets/pips.py:559)
+ *   out_ffeat0  (B,N,128) initial feature  (nets/pips.py:463, returned when return_feat)
+ * stride is 4 or 8 in the reference's callers; any value >=1 with non-empty level-3 map.
+ * flags: bit0 = skip the encoder and reuse the pyramid already in the workspace
+ *        (same B,S,H,W,stride as the call that produced it). */
+size_t pips_workspace_bytes(int B, int S, int H, int W, int N, int stride);
+int    pips_forward(const void* arena, const float* rgbs, const float* xys,
+                    const float* coords_init, const float* feat_init, const float* times,
+                    int B, int S, int H, int W, int N, int stride, int iters, int flags,
+                    void* workspace, size_t workspace_bytes,
+                    float* out_trajs, float* out_vis, float* out_ffeat0, void* stream);
+
+/* ---- stages (same kernels, exposed for parity tests and for callers that cache maps) --*/
+
+/* BasicEncoder.forward (nets/pips.py:247-281) incl. the 2*(x/255)-1 of :436 and
+ * CorrBlock.__init__ (:346-352).  Writes the 4-level channel-last pyramid:
+ * level l at pyramid + pips_pyramid_offset(l), shape [F][H_l][W_l][128]. */
+size_t pips_encoder_workspace_bytes(int F, int H, int W, int stride);
+size_t pips_pyramid_floats(int F, int H, int W, int stride);
+size_t pips_pyramid_offset(int F, int H, int W, int stride, int level);   /* in floats */
+int    pips_encoder_fwd(const void* arena, const float* rgbs, int F, int H, int W, int stride,
+                        float* pyramid, void* workspace, size_t workspace_bytes, void* stream);
+
+/* utils.samp.bilinear_sample2d (utils/samp.py:5-78): clamped-index point sample of frame
+ * 0 of every clip.  xy (B,N,2) in map pixels -> out (B,N,128). */
+int    pips_point_sample(const float* level0, int B, int S, int H8, int W8,
+                         const float* xy, int N, float* out, void* stream);
+
+/* CorrBlock.corr + CorrBlock.sample + get_3d_embedding + the concat of
+ * DeltaBlock.forward (nets/pips.py:384-398, 355-382, 517-522, 304-308; utils/misc.py:44-69):
+ * builds the mixer input X (B*N*S, 544) = [ffeat 128 | corr 196 | sincos 192 | dx dy t | 0..].
+ * ffeats (B*N*S,128), coords (B*N*S,2) in map pixels, both particle-major. */
+int    pips_mixer_input_build(const float* pyramid, int B, int S, int H8, int W8,
+                              const float* ffeats, const float* coords, const float* times,
+                              int N, float* X, void* stream);
+
+/* MLPMixer (nets/pips.py:111-123): X (M,544) -> delta (M/8, 1040).  M = B*N*8. */
+size_t pips_mixer_workspace_bytes(int M);
+int    pips_mixer_fwd(const void* arena, const float* X, int M, float* delta,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* State update nets/pips.py:525-539 (+ vis head :559 when out_vis != NULL).
+ * delta (B*N,1040); ffeats/coords updated in place; coords0 = locked frame-0 coords;
+ * out_traj (B,S,N,2) receives coords*stride. */
+int    pips_state_update(const void* arena, const float* delta, float* ffeats, float* coords,
+                         const float* coords0, int B, int N, float stride,
+                         float* out_traj, float* out_vis, void* stream);
+
+/* Generic fp32-MFMA building blocks (exposed for unit tests).
+ * C[M,N] = epi(A[M,K] * W[N,K]^T + bias[N]); K % 32 == 0; epi: 0 none, 1 GELU(erf),
+ * 2 add residual R (ldr). */
+int    pips_gemm_f32(const float* A, int lda, const float* W, const float* bias,
+                     float* C, int ldc, int M, int N, int K, int epi,
+                     const float* R, int ldr, void* stream);
+/* NHWC convolution as implicit GEMM, weights [Cout][kh][kw][Cin], Cin % 32 == 0.
+ * stats (optional) receives per-(frame, m-tile, channel) {sum, sumsq} partials of the
+ * output; returns the number of m-tiles per frame through *tiles_m_host. */
+int    pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin,
+                          const float* wgt, const float* bias, int Cout, int ksize, int cstride, int pad,
+                          float* out, float* stats, int* tiles_m_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIPS_HIP_H */

@@ -1,0 +1,504 @@
+// C ABI of libpips_hip.so (include/pips_hip.h): weight arena, stage entry points and the
+// whole-forward driver that replaces Pips.forward (nets/pips.py:428-611).  Everything here
+// is host-side launch logic; no allocation, no synchronisation, no global mutable state.
+#include "common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace pips {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------ arena layout
+// conv geometry in execution (= state-dict) order: nets/pips.py:206-223, 135-136, 169-170
+static ArenaLayout build_layout() {
+    ArenaLayout A;
+    memset(&A, 0, sizeof(A));
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };   // 256-B aligned
+    int ci = 0, idx = 0;
+    auto add_conv = [&](int cout, int cin, int k, int s, int p) {
+        ConvW& c = A.conv[idx++];
+        c.cout = cout; c.cin = cin; c.k = k; c.stride = s; c.pad = p;
+        c.w = take((size_t)cout * cin * k * k);
+        c.b = take(cout);
+    };
+    add_conv(64, 3, 7, 2, 3);
+    ci = 64;
+    const int dims[4] = {64, 96, 128, 128}, strides[4] = {1, 2, 2, 2};
+    for (int l = 0; l < 4; ++l)
+        for (int b = 0; b < 2; ++b) {
+            const int s = b == 0 ? strides[l] : 1;
+            add_conv(dims[l], ci, 3, s, 1);
+            add_conv(dims[l], dims[l], 3, 1, 1);
+            if (s != 1) add_conv(dims[l], ci, 1, s, 0);
+            ci = dims[l];
+        }
+    add_conv(256, 416, 3, 1, 1);
+    add_conv(128, 256, 1, 1, 0);
+    A.w_in = take((size_t)PIPS_DMIX * PIPS_KIN_PAD);
+    A.b_in = take(PIPS_DMIX);
+    for (int d = 0; d < PIPS_DEPTH; ++d) {
+        MixLayerW& L = A.mix[d];
+        L.tw0 = take(32 * 8); L.tb0 = take(32); L.tw3 = take(8 * 32); L.tb3 = take(8);
+        L.ln1g = take(PIPS_DMIX); L.ln1b = take(PIPS_DMIX);
+        L.w1 = take((size_t)4 * PIPS_DMIX * PIPS_DMIX); L.b1 = take(4 * PIPS_DMIX);
+        L.w2 = take((size_t)4 * PIPS_DMIX * PIPS_DMIX); L.b2 = take(PIPS_DMIX);
+        L.ln2g = take(PIPS_DMIX); L.ln2b = take(PIPS_DMIX);
+    }
+    A.lnf_g = take(PIPS_DMIX); A.lnf_b = take(PIPS_DMIX);
+    A.w_head = take((size_t)PIPS_NOUT * PIPS_DMIX); A.b_head = take(PIPS_NOUT);
+    A.norm_g = take(PIPS_C); A.norm_b = take(PIPS_C);
+    A.w_upd_t = take(PIPS_C * PIPS_C); A.b_upd = take(PIPS_C);
+    A.w_vis = take(PIPS_C); A.b_vis = take(1);
+    A.total = off;
+    return A;
+}
+
+const ArenaLayout& arena_layout() {
+    static const ArenaLayout A = build_layout();
+    return A;
+}
+
+// ------------------------------------------------------------------ repack kernels
+// OIHW -> O(HW)I   (implicit-GEMM K order = kh, kw, ci)
+__global__ void repack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int I, int T) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)O * I * T) return;
+    const int ci = (int)(i % I);
+    const int t = (int)((i / I) % T);
+    const int o = (int)(i / ((size_t)I * T));
+    dst[i] = src[((size_t)o * I + ci) * T + t];
+}
+// [R][Cc] -> [Cc][R]
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * Cc) return;
+    const int r = (int)(i % R), c = (int)(i / R);
+    dst[i] = src[(size_t)r * Cc + c];
+}
+// [R][Kin] -> [R][Kpad] zero padded
+__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Kin, int Kpad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * Kpad) return;
+    const int k = (int)(i % Kpad), r = (int)(i / Kpad);
+    dst[i] = k < Kin ? src[(size_t)r * Kin + k] : 0.f;
+}
+
+static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace pips
+
+using namespace pips;
+
+extern "C" {
+
+const char* pips_last_error(void) { return g_err; }
+int pips_abi_version(void) { return 1; }
+
+size_t pips_weight_arena_bytes(void) { return arena_layout().total * sizeof(float); }
+
+int pips_repack_weights(const void* const* params, int nparams, void* arena_v, void* stream) {
+    PIPS_CHECK_ARG(params != nullptr && arena_v != nullptr, "repack: null pointer");
+    PIPS_CHECK_ARG(nparams == PIPS_NPARAMS, "repack: expected %d tensors, got %d", PIPS_NPARAMS, nparams);
+    for (int i = 0; i < nparams; ++i) PIPS_CHECK_ARG(params[i] != nullptr, "repack: tensor %d is null", i);
+    hipStream_t st = (hipStream_t)stream;
+    const ArenaLayout& A = arena_layout();
+    float* arena = (float*)arena_v;
+    int pi = 0;
+    auto src = [&]() { return (const float*)params[pi++]; };
+    auto copy = [&](size_t dst_off, size_t n) {
+        (void)hipMemcpyAsync(arena + dst_off, src(), n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    };
+    // stem: [64][3*49] -> [147][64]
+    {
+        const ConvW& c = A.conv[0];
+        hipLaunchKernelGGL(transpose_kernel, dim3(nblk(64 * 147)), dim3(256), 0, st, src(), arena + c.w, 64, 147);
+        copy(c.b, 64);
+    }
+    for (int i = 1; i < 22; ++i) {
+        const ConvW& c = A.conv[i];
+        const size_t n = (size_t)c.cout * c.cin * c.k * c.k;
+        hipLaunchKernelGGL(repack_conv_kernel, dim3(nblk(n)), dim3(256), 0, st, src(), arena + c.w, c.cout,
+                           c.cin, c.k * c.k);
+        copy(c.b, c.cout);
+    }
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(nblk((size_t)PIPS_DMIX * PIPS_KIN_PAD)), dim3(256), 0, st, src(),
+                       arena + A.w_in, PIPS_DMIX, PIPS_KIN, PIPS_KIN_PAD);
+    copy(A.b_in, PIPS_DMIX);
+    for (int d = 0; d < PIPS_DEPTH; ++d) {
+        const MixLayerW& L = A.mix[d];
+        copy(L.tw0, 32 * 8); copy(L.tb0, 32); copy(L.tw3, 8 * 32); copy(L.tb3, 8);
+        copy(L.ln1g, PIPS_DMIX); copy(L.ln1b, PIPS_DMIX);
+        copy(L.w1, (size_t)4 * PIPS_DMIX * PIPS_DMIX); copy(L.b1, 4 * PIPS_DMIX);
+        copy(L.w2, (size_t)4 * PIPS_DMIX * PIPS_DMIX); copy(L.b2, PIPS_DMIX);
+        copy(L.ln2g, PIPS_DMIX); copy(L.ln2b, PIPS_DMIX);
+    }
+    copy(A.lnf_g, PIPS_DMIX); copy(A.lnf_b, PIPS_DMIX);
+    copy(A.w_head, (size_t)PIPS_NOUT * PIPS_DMIX); copy(A.b_head, PIPS_NOUT);
+    copy(A.norm_g, PIPS_C); copy(A.norm_b, PIPS_C);
+    hipLaunchKernelGGL(transpose_kernel, dim3(nblk(PIPS_C * PIPS_C)), dim3(256), 0, st, src(), arena + A.w_upd_t,
+                       PIPS_C, PIPS_C);
+    copy(A.b_upd, PIPS_C);
+    copy(A.w_vis, PIPS_C); copy(A.b_vis, 1);
+    PIPS_CHECK_LAUNCH("pips_repack_weights");
+    return pi == PIPS_NPARAMS ? PIPS_OK : PIPS_E_ARG;
+}
+
+// ------------------------------------------------------------------ building blocks
+int pips_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N,
+                  int K, int epi, const float* R, int ldr, void* stream) {
+    PIPS_CHECK_ARG(A && W && C, "gemm: null pointer");
+    PIPS_CHECK_ARG(epi >= 0 && epi <= 2 && (epi != EPI_RESIDUAL || R != nullptr), "gemm: bad epilogue");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.W = W; g.bias = bias; g.C = C; g.R = R;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.epi = epi;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+static int conv_nhwc(const float* in, int F, int H, int W, int Cin, const float* wgt, const float* bias, int Cout,
+                     int k, int s, int p, float* out, float* stats, int* tiles, hipStream_t st) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = in; g.W = wgt; g.bias = bias; g.C = out; g.stats = stats;
+    g.H = H; g.Win = W; g.Cin = Cin; g.KH = g.KW = k; g.cstride = s; g.pad = p;
+    g.Ho = conv_out(H, k, s, p); g.Wo = conv_out(W, k, s, p);
+    g.M = g.Ho * g.Wo; g.N = Cout; g.K = k * k * Cin; g.ldc = Cout; g.epi = EPI_BIAS;
+    PIPS_CHECK_ARG(g.Ho > 0 && g.Wo > 0, "conv: empty output");
+    return launch_conv(g, F, tiles, st);
+}
+
+int pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin, const float* wgt, const float* bias,
+                       int Cout, int ksize, int cstride, int pad, float* out, float* stats, int* tiles_m_host,
+                       void* stream) {
+    PIPS_CHECK_ARG(in && wgt && out, "conv: null pointer");
+    return conv_nhwc(in, F, H, W, Cin, wgt, bias, Cout, ksize, cstride, pad, out, stats, tiles_m_host,
+                     (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ encoder
+namespace {
+
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t floats) { size_t o = off; off += (floats + 63) / 64 * 64; return o; }
+};
+
+struct EncPlan {
+    int F, H, W, stride;
+    int Hs[5], Ws[5];         // stem/layer1, layer2, layer3, layer4 resolutions; [4] = target H8,W8
+    size_t raw, mid, xa, xb, ds, outs[4], cat, partial, partial2, st_a, st_b;
+    size_t total;             // floats
+};
+
+EncPlan plan_encoder(int F, int H, int W, int stride) {
+    EncPlan P;
+    P.F = F; P.H = H; P.W = W; P.stride = stride;
+    P.Hs[0] = conv_out(H, 7, 2, 3); P.Ws[0] = conv_out(W, 7, 2, 3);
+    for (int l = 1; l < 4; ++l) { P.Hs[l] = conv_out(P.Hs[l - 1], 3, 2, 1); P.Ws[l] = conv_out(P.Ws[l - 1], 3, 2, 1); }
+    P.Hs[4] = H / stride; P.Ws[4] = W / stride;
+    const int ch[4] = {64, 96, 128, 128};
+    size_t big = 0;
+    for (int l = 0; l < 4; ++l) big = big > (size_t)F * P.Hs[l] * P.Ws[l] * ch[l] ? big : (size_t)F * P.Hs[l] * P.Ws[l] * ch[l];
+    const size_t tgt = (size_t)F * P.Hs[4] * P.Ws[4];
+    if (big < tgt * 256) big = tgt * 256;
+    Bump b;
+    P.raw = b.take(big); P.mid = b.take(big); P.xa = b.take(big); P.xb = b.take(big); P.ds = b.take(big);
+    for (int l = 0; l < 4; ++l) P.outs[l] = b.take((size_t)F * P.Hs[l] * P.Ws[l] * ch[l]);
+    P.cat = b.take(tgt * 416);
+    // partial statistics: [F][tiles][C][2]; tiles <= rows/64 + 1
+    size_t pmax = 0;
+    for (int l = 0; l < 4; ++l) {
+        size_t t = (size_t)F * (cdiv(P.Hs[l] * P.Ws[l], 64)) * ch[l] * 2;
+        pmax = pmax > t ? pmax : t;
+    }
+    size_t t2 = (size_t)F * cdiv(P.Hs[4] * P.Ws[4], 64) * 256 * 2;
+    pmax = pmax > t2 ? pmax : t2;
+    P.partial = b.take(pmax); P.partial2 = b.take(pmax);
+    P.st_a = b.take((size_t)F * 256 * 2); P.st_b = b.take((size_t)F * 256 * 2);
+    P.total = b.off;
+    return P;
+}
+
+void pyramid_dims(int H, int W, int stride, int* lh, int* lw) {
+    lh[0] = H / stride; lw[0] = W / stride;
+    for (int l = 1; l < PIPS_LEVELS; ++l) { lh[l] = lh[l - 1] / 2; lw[l] = lw[l - 1] / 2; }
+}
+
+int check_geometry(int F, int H, int W, int stride) {
+    PIPS_CHECK_ARG(F > 0 && H > 0 && W > 0 && stride >= 1, "bad geometry F=%d H=%d W=%d stride=%d", F, H, W, stride);
+    int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
+    pyramid_dims(H, W, stride, lh, lw);
+    PIPS_CHECK_ARG(lh[PIPS_LEVELS - 1] >= 1 && lw[PIPS_LEVELS - 1] >= 1,
+                   "input %dx%d too small for a 4-level pyramid at stride %d", H, W, stride);
+    return PIPS_OK;
+}
+
+#define RUN(x) do { int rc__ = (x); if (rc__ != PIPS_OK) return rc__; } while (0)
+
+// conv -> partial stats -> mean/rstd
+int conv_stats(const float* arena, const ConvW& c, const float* in, int F, int H, int W, float* out,
+               float* partial, float* mean_rstd, hipStream_t st) {
+    int tiles = 0;
+    RUN(conv_nhwc(in, F, H, W, c.cin, arena + c.w, arena + c.b, c.cout, c.k, c.stride, c.pad, out, partial, &tiles, st));
+    const int Ho = conv_out(H, c.k, c.stride, c.pad), Wo = conv_out(W, c.k, c.stride, c.pad);
+    return launch_inorm_finalize(partial, F, tiles, c.cout, Ho * Wo, mean_rstd, st);
+}
+
+// ResidualBlock.forward, nets/pips.py:173-181
+int res_block(const float* arena, const ArenaLayout& A, int& ci, bool down, const float* x, int F, int H, int W,
+              float* ws, const EncPlan& P, float* out, hipStream_t st) {
+    const ConvW& c1 = A.conv[ci++];
+    const ConvW& c2 = A.conv[ci++];
+    const int Ho = conv_out(H, 3, c1.stride, 1), Wo = conv_out(W, 3, c1.stride, 1);
+    float* raw = ws + P.raw; float* mid = ws + P.mid;
+    RUN(conv_stats(arena, c1, x, F, H, W, raw, ws + P.partial, ws + P.st_a, st));
+    RUN(launch_inorm_apply(raw, ws + P.st_a, nullptr, nullptr, mid, F, Ho * Wo, c1.cout, st));
+    RUN(conv_stats(arena, c2, mid, F, Ho, Wo, raw, ws + P.partial, ws + P.st_a, st));
+    if (down) {
+        const ConvW& cd = A.conv[ci++];
+        RUN(conv_stats(arena, cd, x, F, H, W, ws + P.ds, ws + P.partial2, ws + P.st_b, st));
+        RUN(launch_inorm_apply(raw, ws + P.st_a, ws + P.ds, ws + P.st_b, out, F, Ho * Wo, c2.cout, st));
+    } else {
+        RUN(launch_inorm_apply(raw, ws + P.st_a, x, nullptr, out, F, Ho * Wo, c2.cout, st));
+    }
+    return PIPS_OK;
+}
+
+}  // namespace
+
+size_t pips_encoder_workspace_bytes(int F, int H, int W, int stride) {
+    if (F <= 0 || H <= 0 || W <= 0 || stride < 1) return 0;
+    return plan_encoder(F, H, W, stride).total * sizeof(float);
+}
+
+size_t pips_pyramid_floats(int F, int H, int W, int stride) {
+    int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
+    pyramid_dims(H, W, stride, lh, lw);
+    size_t n = 0;
+    for (int l = 0; l < PIPS_LEVELS; ++l) n += ((size_t)F * lh[l] * lw[l] * PIPS_C + 63) / 64 * 64;
+    return n;
+}
+
+size_t pips_pyramid_offset(int F, int H, int W, int stride, int level) {
+    int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
+    pyramid_dims(H, W, stride, lh, lw);
+    size_t n = 0;
+    for (int l = 0; l < level && l < PIPS_LEVELS; ++l) n += ((size_t)F * lh[l] * lw[l] * PIPS_C + 63) / 64 * 64;
+    return n;
+}
+
+int pips_encoder_fwd(const void* arena_v, const float* rgbs, int F, int H, int W, int stride, float* pyramid,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    PIPS_CHECK_ARG(arena_v && rgbs && pyramid && workspace, "encoder: null pointer");
+    RUN(check_geometry(F, H, W, stride));
+    const EncPlan P = plan_encoder(F, H, W, stride);
+    if (workspace_bytes < P.total * sizeof(float)) {
+        set_error("encoder: workspace %zu < %zu bytes", workspace_bytes, P.total * sizeof(float));
+        return PIPS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const ArenaLayout& A = arena_layout();
+    const float* arena = (const float*)arena_v;
+    float* ws = (float*)workspace;
+
+    // stem: conv1 + norm1 + relu (nets/pips.py:251-253)
+    int tiles = 0;
+    RUN(launch_stem(rgbs, arena + A.conv[0].w, arena + A.conv[0].b, ws + P.raw, ws + P.partial, F, H, W, P.Hs[0],
+                    P.Ws[0], &tiles, st));
+    RUN(launch_inorm_finalize(ws + P.partial, F, tiles, 64, P.Hs[0] * P.Ws[0], ws + P.st_a, st));
+    RUN(launch_inorm_apply(ws + P.raw, ws + P.st_a, nullptr, nullptr, ws + P.xa, F, P.Hs[0] * P.Ws[0], 64, st));
+
+    // layer1..4 (:265-268)
+    int ci = 1;
+    const float* x = ws + P.xa;
+    int Hc = P.Hs[0], Wc = P.Ws[0];
+    for (int l = 0; l < 4; ++l) {
+        const bool down = l > 0;
+        RUN(res_block(arena, A, ci, down, x, F, Hc, Wc, ws, P, ws + P.xb, st));
+        Hc = P.Hs[l]; Wc = P.Ws[l];
+        RUN(res_block(arena, A, ci, false, ws + P.xb, F, Hc, Wc, ws, P, ws + P.outs[l], st));
+        x = ws + P.outs[l];
+    }
+    // resize a,b,c,d to (H//stride, W//stride) and concatenate (:269-273)
+    const int ch[4] = {64, 96, 128, 128};
+    const int H8 = P.Hs[4], W8 = P.Ws[4];
+    for (int l = 0, coff = 0; l < 4; coff += ch[l], ++l)
+        RUN(launch_resize_into(ws + P.outs[l], F, P.Hs[l], P.Ws[l], ch[l], ws + P.cat, H8, W8, 416, coff, st));
+    // conv2 + norm2 + relu + conv3 (:273-276)
+    const ConvW& c2 = A.conv[ci++];
+    const ConvW& c3 = A.conv[ci++];
+    RUN(conv_stats(arena, c2, ws + P.cat, F, H8, W8, ws + P.raw, ws + P.partial, ws + P.st_a, st));
+    RUN(launch_inorm_apply(ws + P.raw, ws + P.st_a, nullptr, nullptr, ws + P.mid, F, H8 * W8, 256, st));
+    RUN(conv_nhwc(ws + P.mid, F, H8, W8, 256, arena + c3.w, arena + c3.b, 128, 1, 1, 0, pyramid, nullptr, nullptr, st));
+    // CorrBlock.__init__ pyramid (:346-352)
+    int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
+    pyramid_dims(H, W, stride, lh, lw);
+    for (int l = 1; l < PIPS_LEVELS; ++l)
+        RUN(launch_avgpool2(pyramid + pips_pyramid_offset(F, H, W, stride, l - 1), F, lh[l - 1], lw[l - 1], PIPS_C,
+                            pyramid + pips_pyramid_offset(F, H, W, stride, l), st));
+    return PIPS_OK;
+}
+
+// ------------------------------------------------------------------ tracker stages
+int pips_point_sample(const float* level0, int B, int S, int H8, int W8, const float* xy, int N, float* out,
+                      void* stream) {
+    PIPS_CHECK_ARG(level0 && xy && out && B > 0 && N > 0 && S > 0, "point_sample: bad argument");
+    return launch_point_sample(level0, B, S, H8, W8, xy, N, out, (hipStream_t)stream);
+}
+
+static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats, const float* coords,
+                       const float* times, int N, float* X, hipStream_t st) {
+    size_t off[PIPS_LEVELS];
+    int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
+    lh[0] = H8; lw[0] = W8;
+    for (int l = 1; l < PIPS_LEVELS; ++l) { lh[l] = lh[l - 1] / 2; lw[l] = lw[l - 1] / 2; }
+    size_t o = 0;
+    for (int l = 0; l < PIPS_LEVELS; ++l) {
+        off[l] = o;
+        o += ((size_t)B * S * lh[l] * lw[l] * PIPS_C + 63) / 64 * 64;
+    }
+    PIPS_CHECK_ARG(lh[PIPS_LEVELS - 1] >= 1 && lw[PIPS_LEVELS - 1] >= 1, "mixer_input: map too small");
+    return launch_mixer_input(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, st);
+}
+
+int pips_mixer_input_build(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats,
+                           const float* coords, const float* times, int N, float* X, void* stream) {
+    PIPS_CHECK_ARG(pyramid && ffeats && coords && times && X, "mixer_input: null pointer");
+    PIPS_CHECK_ARG(S == PIPS_S && B > 0 && N > 0, "mixer_input: S must be %d", PIPS_S);
+    return mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, X, (hipStream_t)stream);
+}
+
+size_t pips_mixer_workspace_bytes(int M) {
+    if (M <= 0) return 0;
+    Bump b;
+    b.take((size_t)M * PIPS_DMIX); b.take((size_t)M * PIPS_DMIX); b.take((size_t)M * 4 * PIPS_DMIX);
+    b.take((size_t)(M / PIPS_S) * PIPS_DMIX);
+    return b.off * sizeof(float);
+}
+
+int pips_mixer_fwd(const void* arena_v, const float* X, int M, float* delta, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+    PIPS_CHECK_ARG(arena_v && X && delta && workspace, "mixer: null pointer");
+    PIPS_CHECK_ARG(M > 0 && M % PIPS_S == 0, "mixer: M=%d must be a positive multiple of %d", M, PIPS_S);
+    if (workspace_bytes < pips_mixer_workspace_bytes(M)) {
+        set_error("mixer: workspace %zu < %zu bytes", workspace_bytes, pips_mixer_workspace_bytes(M));
+        return PIPS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const ArenaLayout& A = arena_layout();
+    const float* arena = (const float*)arena_v;
+    Bump b;
+    float* ws = (float*)workspace;
+    float* x = ws + b.take((size_t)M * PIPS_DMIX);
+    float* xn = ws + b.take((size_t)M * PIPS_DMIX);
+    float* h = ws + b.take((size_t)M * 4 * PIPS_DMIX);
+    float* pooled = ws + b.take((size_t)(M / PIPS_S) * PIPS_DMIX);
+    const int P = M / PIPS_S;
+
+    RUN(pips_gemm_f32(X, PIPS_KIN_PAD, arena + A.w_in, arena + A.b_in, x, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
+                      EPI_BIAS, nullptr, 0, stream));
+    for (int d = 0; d < PIPS_DEPTH; ++d) {
+        const MixLayerW& L = A.mix[d];
+        RUN(launch_token_mix(arena, L, x, xn, P, st));
+        RUN(pips_gemm_f32(xn, PIPS_DMIX, arena + L.w1, arena + L.b1, h, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX, PIPS_DMIX,
+                          EPI_GELU, nullptr, 0, stream));
+        RUN(pips_gemm_f32(h, 4 * PIPS_DMIX, arena + L.w2, arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
+                          EPI_RESIDUAL, x, PIPS_DMIX, stream));
+    }
+    RUN(launch_ln_mean(x, arena + A.lnf_g, arena + A.lnf_b, pooled, P, st));
+    RUN(pips_gemm_f32(pooled, PIPS_DMIX, arena + A.w_head, arena + A.b_head, delta, PIPS_NOUT, P, PIPS_NOUT, PIPS_DMIX,
+                      EPI_BIAS, nullptr, 0, stream));
+    return PIPS_OK;
+}
+
+int pips_state_update(const void* arena, const float* delta, float* ffeats, float* coords, const float* coords0,
+                      int B, int N, float stride, float* out_traj, float* out_vis, void* stream) {
+    PIPS_CHECK_ARG(arena && delta && ffeats && coords && coords0 && out_traj, "state_update: null pointer");
+    PIPS_CHECK_ARG(B > 0 && N > 0, "state_update: empty");
+    return launch_state_update((const float*)arena, delta, ffeats, coords, coords0, B, N, stride, out_traj, out_vis,
+                               (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ whole forward
+namespace {
+struct FwdPlan {
+    size_t pyramid, enc, coords, coords0, ffeats, ffeat0, X, delta, mixer, total;   // floats
+};
+FwdPlan plan_forward(int B, int S, int H, int W, int N, int stride) {
+    FwdPlan P;
+    Bump b;
+    const int F = B * S, M = B * N * S;
+    P.pyramid = b.take(pips_pyramid_floats(F, H, W, stride));
+    P.enc = b.take(pips_encoder_workspace_bytes(F, H, W, stride) / sizeof(float));
+    P.coords = b.take((size_t)M * 2);
+    P.coords0 = b.take((size_t)M * 2);
+    P.ffeats = b.take((size_t)M * PIPS_C);
+    P.ffeat0 = b.take((size_t)B * N * PIPS_C);
+    P.X = b.take((size_t)M * PIPS_KIN_PAD);
+    P.delta = b.take((size_t)B * N * PIPS_NOUT);
+    P.mixer = b.take(pips_mixer_workspace_bytes(M) / sizeof(float));
+    P.total = b.off;
+    return P;
+}
+}  // namespace
+
+size_t pips_workspace_bytes(int B, int S, int H, int W, int N, int stride) {
+    if (B <= 0 || S != PIPS_S || H <= 0 || W <= 0 || N <= 0 || stride < 1) return 0;
+    return plan_forward(B, S, H, W, N, stride).total * sizeof(float);
+}
+
+int pips_forward(const void* arena, const float* rgbs, const float* xys, const float* coords_init,
+                 const float* feat_init, const float* times, int B, int S, int H, int W, int N, int stride,
+                 int iters, int flags, void* workspace, size_t workspace_bytes, float* out_trajs, float* out_vis,
+                 float* out_ffeat0, void* stream) {
+    PIPS_CHECK_ARG(arena && xys && times && workspace && out_trajs && out_vis, "forward: null pointer");
+    PIPS_CHECK_ARG((flags & 1) || rgbs != nullptr, "forward: rgbs is null");
+    PIPS_CHECK_ARG(S == PIPS_S, "forward: S=%d, the mixer weights fix S=%d (nets/pips.py:295-301)", S, PIPS_S);
+    PIPS_CHECK_ARG(B > 0 && N > 0 && iters >= 1, "forward: need B,N >= 1 and iters >= 1");
+    RUN(check_geometry(B * S, H, W, stride));
+    const FwdPlan P = plan_forward(B, S, H, W, N, stride);
+    if (workspace_bytes < P.total * sizeof(float)) {
+        set_error("forward: workspace %zu < %zu bytes", workspace_bytes, P.total * sizeof(float));
+        return PIPS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const int F = B * S, M = B * N * S;
+    const int H8 = H / stride, W8 = W / stride;
+    float* pyramid = ws + P.pyramid;
+    if (!(flags & 1))
+        RUN(pips_encoder_fwd(arena, rgbs, F, H, W, stride, pyramid, ws + P.enc,
+                             pips_encoder_workspace_bytes(F, H, W, stride), stream));
+    float* coords = ws + P.coords; float* coords0 = ws + P.coords0; float* ffeats = ws + P.ffeats;
+    float* ffeat0 = out_ffeat0 != nullptr ? out_ffeat0 : ws + P.ffeat0;
+    const size_t traj_sz = (size_t)B * S * N * 2;
+    RUN(launch_init_coords(xys, coords_init, B, N, (float)stride, coords, coords0, out_trajs, st));
+    if (feat_init != nullptr) {
+        if (feat_init != ffeat0)
+            (void)hipMemcpyAsync(ffeat0, feat_init, (size_t)B * N * PIPS_C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    } else {
+        RUN(launch_point_sample_strided(pyramid, B, S, H8, W8, coords, S * 2, N, ffeat0, st));   // :463
+    }
+    RUN(launch_init_ffeats(ffeat0, B * N, ffeats, st));                                          // :466
+    for (int it = 0; it < iters; ++it) {                                                         // :499
+        RUN(mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, ws + P.X, st));
+        RUN(pips_mixer_fwd(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes(M), stream));
+        RUN(launch_state_update((const float*)arena, ws + P.delta, ffeats, coords, coords0, B, N, (float)stride,
+                                out_trajs + (size_t)(it + 1) * traj_sz, it + 1 == iters ? out_vis : nullptr, st));
+    }
+    PIPS_CHECK_LAUNCH("pips_forward");
+    return PIPS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// Internal declarations shared by the HIP translation units of libpips_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/pips_hip.h"
+
+namespace pips {
+
+void set_error(const char* fmt, ...);
+
+#define PIPS_CHECK_ARG(cond, ...)                                   \
+    do {                                                            \
+        if (!(cond)) { ::pips::set_error(__VA_ARGS__); return PIPS_E_ARG; } \
+    } while (0)
+
+#define PIPS_CHECK_LAUNCH(what)                                                     \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            ::pips::set_error("%s: %s", what, hipGetErrorString(e__));              \
+            return PIPS_E_LAUNCH;                                                   \
+        }                                                                           \
+    } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- GEMM / conv core
+enum Epilogue { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
+
+struct GemmArgs {
+    const float* A;      // plain: [M][lda]; conv: NHWC input of frame 0
+    const float* W;      // [N][K], K contiguous
+    const float* bias;   // [N] or null
+    float* C;            // [M][ldc] (conv: output of frame 0, ldc = N)
+    const float* R;      // residual [M][ldr] (EPI_RESIDUAL)
+    float* stats;        // optional partial {sum,sumsq}: [frame][tiles_m][N][2]
+    int M, N, K;
+    int lda, ldc, ldr;
+    int epi;
+    // implicit-GEMM geometry (conv only); M = Ho*Wo rows per frame, gridDim.z = frames
+    int H, Win, Cin, Ho, Wo, KH, KW, cstride, pad;
+};
+
+int launch_gemm(const GemmArgs& a, hipStream_t st);          // plain GEMM, picks a tile
+int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
+int conv_tiles_m(int rows_per_frame, int Cout, int frames);  // tile count launch_conv will use
+
+// ---------------------------------------------------------------- weight arena
+// Offsets in floats into the packed arena (see api.hip: build_layout()).
+struct ConvW { size_t w, b; int cout, cin, k, stride, pad; };
+struct MixLayerW { size_t tw0, tb0, tw3, tb3, ln1g, ln1b, ln2g, ln2b, w1, b1, w2, b2; };
+struct ArenaLayout {
+    ConvW conv[22];          // execution order, conv[0] = stem ([147][64] layout)
+    size_t w_in, b_in;       // first Linear, [512][544]
+    MixLayerW mix[PIPS_DEPTH];
+    size_t lnf_g, lnf_b, w_head, b_head;
+    size_t norm_g, norm_b, w_upd_t, b_upd, w_vis, b_vis;
+    size_t total;            // floats
+};
+const ArenaLayout& arena_layout();
+
+// ---------------------------------------------------------------- encoder pieces (encoder.hip)
+struct MapDims { int H, W; };
+inline int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+int launch_stem(const float* rgbs, const float* w, const float* bias, float* out, float* stats,
+                int F, int H, int W, int Ho, int Wo, int* tiles_m, hipStream_t st);
+int stem_tiles_m(int rows_per_frame);
+int launch_inorm_finalize(const float* partial, int F, int tiles, int C, int count, float* mean_rstd,
+                          hipStream_t st);
+// y = relu((x-m)*r)                               (res == null)
+// y = relu(res + relu((x-m)*r))                   (res != null, res_stats == null)
+// y = relu((res-m2)*r2 + relu((x-m)*r))           (res_stats != null)
+int launch_inorm_apply(const float* x, const float* stats, const float* res, const float* res_stats,
+                       float* y, int F, int HW, int C, hipStream_t st);
+int launch_resize_into(const float* src, int F, int Hs, int Ws, int C, float* dst, int Hd, int Wd,
+                       int Cdst, int coff, hipStream_t st);
+int launch_avgpool2(const float* src, int F, int H, int W, int C, float* dst, hipStream_t st);
+
+// ---------------------------------------------------------------- tracker pieces (track.hip)
+int launch_point_sample(const float* level0, int B, int S, int H8, int W8, const float* xy, int N,
+                        float* out, hipStream_t st);
+int launch_point_sample_strided(const float* level0, int B, int S, int H8, int W8, const float* xy,
+                                int xy_stride, int N, float* out, hipStream_t st);
+int launch_init_coords(const float* xys, const float* coords_init, int B, int N, float stride,
+                       float* coords, float* coords0, float* out_traj0, hipStream_t st);
+int launch_init_ffeats(const float* ffeat0, int BN, float* ffeats, hipStream_t st);
+int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW,
+                       int B, int S, const float* ffeats, const float* coords, const float* times,
+                       int N, float* X, hipStream_t st);
+int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
+                     hipStream_t st);
+int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,
+                   hipStream_t st);
+int launch_state_update(const float* arena, const float* delta, float* ffeats, float* coords,
+                        const float* coords0, int B, int N, float stride, float* out_traj,
+                        float* out_vis, hipStream_t st);
+
+}  // namespace pips

@@ -1,0 +1,290 @@
+// Encoder-side kernels that are not GEMM-shaped: the 7x7 stem on the NCHW input, the
+// instance-norm statistics/apply passes, the align_corners bilinear resize into the
+// concatenated map and the 2x2 average pool of the correlation pyramid.
+// Reference: BasicEncoder.forward nets/pips.py:247-281, ResidualBlock.forward :173-181,
+// CorrBlock.__init__ :346-352.  Activations are NHWC fp32.
+#include "common.h"
+
+namespace pips {
+
+// ------------------------------------------------------------------------------ stem
+// conv1 7x7 stride 2 pad 3, 3 -> 64 (nets/pips.py:206,251) reading the caller's NCHW
+// 0..255 frames with the 2*(x/255)-1 scaling of :436 applied on load (zero padding is in
+// the scaled domain).  A block = 64 output pixels x 64 channels: each of the 4 waves owns
+// 16 output channels (weights are wave-uniform -> scalar loads, [147][64] layout) and
+// every lane one pixel.  Also emits per-(frame, tile, channel) {sum, sumsq} partials.
+constexpr int STEM_TILE = 64;
+
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ rgbs,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ out,
+                                                        float* __restrict__ stats, int H, int W,
+                                                        int Ho, int Wo) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int frame = blockIdx.z;
+    const int M = Ho * Wo;
+    const int m = blockIdx.x * STEM_TILE + lane;
+    const bool ok = m < M;
+    const int ho = ok ? m / Wo : 0, wo = ok ? m - (m / Wo) * Wo : 0;
+    const int hi0 = ho * 2 - 3, wi0 = wo * 2 - 3;
+    const float* src = rgbs + (size_t)frame * 3 * H * W;
+    const float* wv = w + wave * 16;
+
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+
+    for (int ci = 0; ci < 3; ++ci) {
+        for (int kh = 0; kh < 7; ++kh) {
+            const int hi = hi0 + kh;
+            const bool hok = ok && (unsigned)hi < (unsigned)H;
+            const float* row = src + ((size_t)ci * H + (hok ? hi : 0)) * W;
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const int wi = wi0 + kw;
+                float x = 0.f;
+                if (hok && (unsigned)wi < (unsigned)W) x = 2.0f * (row[wi] / 255.0f) - 1.0f;
+                const float* wk = wv + ((ci * 7 + kh) * 7 + kw) * 64;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x, wk[c], acc[c]);
+            }
+        }
+    }
+    float s[16], q[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        acc[c] += bias[wave * 16 + c];
+        s[c] = ok ? acc[c] : 0.f;
+        q[c] = ok ? acc[c] * acc[c] : 0.f;
+    }
+    if (ok) {
+        float4* dst = reinterpret_cast<float4*>(out + ((size_t)frame * M + m) * 64 + wave * 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            s[c] += __shfl_xor(s[c], off);
+            q[c] += __shfl_xor(q[c], off);
+        }
+    }
+    if (lane < 16) {
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (lane == c) { sv = s[c]; qv = q[c]; }
+        float* dst = stats + (((size_t)frame * gridDim.x + blockIdx.x) * 64 + wave * 16 + lane) * 2;
+        dst[0] = sv;
+        dst[1] = qv;
+    }
+}
+
+int stem_tiles_m(int rows_per_frame) { return cdiv(rows_per_frame, STEM_TILE); }
+
+int launch_stem(const float* rgbs, const float* w, const float* bias, float* out, float* stats,
+                int F, int H, int W, int Ho, int Wo, int* tiles_m, hipStream_t st) {
+    const int tiles = stem_tiles_m(Ho * Wo);
+    if (tiles_m) *tiles_m = tiles;
+    hipLaunchKernelGGL(stem_conv_kernel, dim3(tiles, 1, F), dim3(256), 0, st, rgbs, w, bias, out, stats,
+                       H, W, Ho, Wo);
+    PIPS_CHECK_LAUNCH("stem_conv_kernel");
+    return PIPS_OK;
+}
+
+// ------------------------------------------------------------------ instance-norm stats
+// partial [F][tiles][C][2] fp32 -> mean_rstd [F][C][2]; accumulation in fp64.
+// InstanceNorm2d(affine=False, eps=1e-5), biased variance (nets/pips.py:153-157,199-201).
+__global__ __launch_bounds__(256) void inorm_finalize_kernel(const float* __restrict__ partial,
+                                                             int tiles, int C, int count,
+                                                             float* __restrict__ mean_rstd) {
+    __shared__ double red[2][8][32];
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int sub = threadIdx.x >> 5;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const float* p = partial + ((size_t)f * tiles * C + c) * 2;
+        for (int t = sub; t < tiles; t += 8) {
+            const float2 v = *reinterpret_cast<const float2*>(p + (size_t)t * C * 2);
+            s += (double)v.x;
+            q += (double)v.y;
+        }
+    }
+    red[0][sub][threadIdx.x & 31] = s;
+    red[1][sub][threadIdx.x & 31] = q;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < C) {
+        s = 0.0; q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s += red[0][i][threadIdx.x]; q += red[1][i][threadIdx.x]; }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float* dst = mean_rstd + ((size_t)f * C + c) * 2;
+        dst[0] = (float)mean;
+        dst[1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+int launch_inorm_finalize(const float* partial, int F, int tiles, int C, int count, float* mean_rstd,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(cdiv(C, 32), F), dim3(256), 0, st, partial, tiles, C,
+                       count, mean_rstd);
+    PIPS_CHECK_LAUNCH("inorm_finalize_kernel");
+    return PIPS_OK;
+}
+
+// ------------------------------------------------------------------ instance-norm apply
+// MODE 0: y = relu((x-m)*r)                              nets/pips.py:175/176/252-253/274-275
+// MODE 1: y = relu(res + relu((x-m)*r))                  :176,181 (identity shortcut)
+// MODE 2: y = relu((res-m2)*r2 + relu((x-m)*r))          :169-170,179,181 (1x1 s2 shortcut + norm3)
+template <int MODE>
+__global__ __launch_bounds__(256) void inorm_apply_kernel(const float4* __restrict__ x,
+                                                          const float2* __restrict__ stats,
+                                                          const float4* __restrict__ res,
+                                                          const float2* __restrict__ res_stats,
+                                                          float4* __restrict__ y, int HW, int C4,
+                                                          size_t total4) {
+    const size_t per_frame = (size_t)HW * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / per_frame);
+        const int c4 = (int)(i % C4);
+        const float2* st = stats + ((size_t)f * C4 + c4) * 4;
+        float4 v = x[i];
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = fmaxf((o[k] - st[k].x) * st[k].y, 0.f);
+        if (MODE == 1) {
+            const float4 r = res[i];
+            o[0] = fmaxf(r.x + o[0], 0.f); o[1] = fmaxf(r.y + o[1], 0.f);
+            o[2] = fmaxf(r.z + o[2], 0.f); o[3] = fmaxf(r.w + o[3], 0.f);
+        } else if (MODE == 2) {
+            const float4 r = res[i];
+            const float2* rs = res_stats + ((size_t)f * C4 + c4) * 4;
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaxf((rr[k] - rs[k].x) * rs[k].y + o[k], 0.f);
+        }
+        y[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int launch_inorm_apply(const float* x, const float* stats, const float* res, const float* res_stats,
+                       float* y, int F, int HW, int C, hipStream_t st) {
+    PIPS_CHECK_ARG(C % 4 == 0, "inorm_apply: C %% 4");
+    const size_t total4 = (size_t)F * HW * (C / 4);
+    const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float2* s2 = reinterpret_cast<const float2*>(stats);
+    const float4* r4 = reinterpret_cast<const float4*>(res);
+    const float2* rs2 = reinterpret_cast<const float2*>(res_stats);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    if (res == nullptr)
+        hipLaunchKernelGGL(inorm_apply_kernel<0>, dim3(blocks), dim3(256), 0, st, x4, s2, r4, rs2, y4, HW, C / 4, total4);
+    else if (res_stats == nullptr)
+        hipLaunchKernelGGL(inorm_apply_kernel<1>, dim3(blocks), dim3(256), 0, st, x4, s2, r4, rs2, y4, HW, C / 4, total4);
+    else
+        hipLaunchKernelGGL(inorm_apply_kernel<2>, dim3(blocks), dim3(256), 0, st, x4, s2, r4, rs2, y4, HW, C / 4, total4);
+    PIPS_CHECK_LAUNCH("inorm_apply_kernel");
+    return PIPS_OK;
+}
+
+// ------------------------------------------------------------------------------ resize
+// F.interpolate(mode='bilinear', align_corners=True) (nets/pips.py:269-272) of an NHWC map
+// into channels [coff, coff+C) of the concatenated NHWC map (the torch.cat of :273).
+__global__ __launch_bounds__(256) void resize_into_kernel(const float* __restrict__ src, int Hs, int Ws,
+                                                          int C4, float4* __restrict__ dst, int Hd,
+                                                          int Wd, int Cdst4, int coff4, float sh,
+                                                          float sw, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        const int x = (int)(p % Wd); p /= Wd;
+        const int y = (int)(p % Hd);
+        const int f = (int)(p / Hd);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        if (Hd == Hs) { y0 = y1 = y; ly0 = 1.f; ly1 = 0.f; }
+        else {
+            const float r = sh * (float)y;
+            y0 = min((int)floorf(r), Hs - 1);
+            ly1 = fminf(fmaxf(r - (float)y0, 0.f), 1.f);
+            y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
+            ly0 = 1.f - ly1;
+        }
+        if (Wd == Ws) { x0 = x1 = x; lx0 = 1.f; lx1 = 0.f; }
+        else {
+            const float r = sw * (float)x;
+            x0 = min((int)floorf(r), Ws - 1);
+            lx1 = fminf(fmaxf(r - (float)x0, 0.f), 1.f);
+            x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+            lx0 = 1.f - lx1;
+        }
+        const float4* s4 = reinterpret_cast<const float4*>(src) + (size_t)f * Hs * Ws * C4 + c4;
+        const float4 v00 = s4[((size_t)y0 * Ws + x0) * C4], v01 = s4[((size_t)y0 * Ws + x1) * C4];
+        const float4 v10 = s4[((size_t)y1 * Ws + x0) * C4], v11 = s4[((size_t)y1 * Ws + x1) * C4];
+        float4 o;
+        o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+        o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+        o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+        o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+        dst[(((size_t)f * Hd + y) * Wd + x) * Cdst4 + coff4 + c4] = o;
+    }
+}
+
+int launch_resize_into(const float* src, int F, int Hs, int Ws, int C, float* dst, int Hd, int Wd,
+                       int Cdst, int coff, hipStream_t st) {
+    PIPS_CHECK_ARG(C % 4 == 0 && Cdst % 4 == 0 && coff % 4 == 0, "resize: channel alignment");
+    const size_t total4 = (size_t)F * Hd * Wd * (C / 4);
+    const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    // area_pixel_compute_scale(align_corners=True): (in-1)/(out-1), 0 when out == 1
+    const float sh = Hd > 1 ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
+    const float sw = Wd > 1 ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
+    hipLaunchKernelGGL(resize_into_kernel, dim3(blocks), dim3(256), 0, st, src, Hs, Ws, C / 4,
+                       reinterpret_cast<float4*>(dst), Hd, Wd, Cdst / 4, coff / 4, sh, sw, total4);
+    PIPS_CHECK_LAUNCH("resize_into_kernel");
+    return PIPS_OK;
+}
+
+// ------------------------------------------------------------------------------ avg pool
+// F.avg_pool2d(x, 2, stride=2) (nets/pips.py:349), floor output size, NHWC.
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float4* __restrict__ src, int H, int W,
+                                                       int C4, float4* __restrict__ dst, int Ho, int Wo,
+                                                       size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        const int x = (int)(p % Wo); p /= Wo;
+        const int y = (int)(p % Ho);
+        const int f = (int)(p / Ho);
+        const float4* s = src + (((size_t)f * H + 2 * y) * W + 2 * x) * C4 + c4;
+        const float4 a = s[0], b = s[C4], c = s[(size_t)W * C4], d = s[(size_t)W * C4 + C4];
+        float4 o;
+        o.x = (((a.x + b.x) + c.x) + d.x) * 0.25f;
+        o.y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
+        o.z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
+        o.w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
+        dst[i] = o;
+    }
+}
+
+int launch_avgpool2(const float* src, int F, int H, int W, int C, float* dst, hipStream_t st) {
+    const int Ho = H / 2, Wo = W / 2;
+    PIPS_CHECK_ARG(Ho >= 1 && Wo >= 1, "avgpool: map %dx%d too small", H, W);
+    const size_t total4 = (size_t)F * Ho * Wo * (C / 4);
+    const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(src), H, W, C / 4,
+                       reinterpret_cast<float4*>(dst), Ho, Wo, total4);
+    PIPS_CHECK_LAUNCH("avgpool2_kernel");
+    return PIPS_OK;
+}
+
+}  // namespace pips

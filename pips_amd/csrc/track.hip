@@ -1,0 +1,462 @@
+// Tracker-side kernels: initial point sample, the fused local-correlation gather that
+// builds the mixer input, the token-mixing half of each mixer block, the final
+// LayerNorm+mean, and the state update.  None of them is GEMM-shaped; they are laid out
+// for coalesced 512-byte channel-last reads and 64-lane waves.
+// State tensors are particle-major: row m = (b*N + n)*8 + s.
+#include "common.h"
+
+namespace pips {
+
+constexpr int S = PIPS_S;
+constexpr int C = PIPS_C;
+
+__device__ __forceinline__ float gelu_erf_t(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ------------------------------------------------------------------------ point sample
+// utils.samp.bilinear_sample2d (utils/samp.py:5-78) on frame 0 of each clip: neighbour
+// indices clamped to the border, weights unclamped, products and sums rounded one by one
+// in the reference's order (samp.py:59-65).  128 threads = 128 channels of one point.
+__global__ __launch_bounds__(128) void point_sample_kernel(const float* __restrict__ level0, int S_,
+                                                           int H, int W, const float* __restrict__ xy,
+                                                           int xy_stride, int N,
+                                                           float* __restrict__ out) {
+    const int pn = blockIdx.x;            // b*N + n
+    const int b = pn / N;
+    const float x = xy[(size_t)pn * xy_stride + 0], y = xy[(size_t)pn * xy_stride + 1];
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+    const int x0 = min(max((int)x0f, 0), W - 1), x1 = min(max((int)x0f + 1, 0), W - 1);
+    const int y0 = min(max((int)y0f, 0), H - 1), y1 = min(max((int)y0f + 1, 0), H - 1);
+    const float w00 = __fmul_rn(x1f - x, y1f - y), w01 = __fmul_rn(x - x0f, y1f - y);
+    const float w10 = __fmul_rn(x1f - x, y - y0f), w11 = __fmul_rn(x - x0f, y - y0f);
+    const float* f0 = level0 + (size_t)b * S_ * H * W * C;   // frame s = 0 of clip b
+    const int c = threadIdx.x;
+    const float v00 = f0[((size_t)y0 * W + x0) * C + c], v01 = f0[((size_t)y0 * W + x1) * C + c];
+    const float v10 = f0[((size_t)y1 * W + x0) * C + c], v11 = f0[((size_t)y1 * W + x1) * C + c];
+    float o = __fadd_rn(__fmul_rn(w00, v00), __fmul_rn(w01, v01));
+    o = __fadd_rn(o, __fmul_rn(w10, v10));
+    o = __fadd_rn(o, __fmul_rn(w11, v11));
+    out[(size_t)pn * C + c] = o;
+}
+
+int launch_point_sample_strided(const float* level0, int B, int S_, int H8, int W8, const float* xy,
+                                int xy_stride, int N, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(point_sample_kernel, dim3(B * N), dim3(128), 0, st, level0, S_, H8, W8, xy,
+                       xy_stride, N, out);
+    PIPS_CHECK_LAUNCH("point_sample_kernel");
+    return PIPS_OK;
+}
+
+int launch_point_sample(const float* level0, int B, int S_, int H8, int W8, const float* xy, int N,
+                        float* out, hipStream_t st) {
+    return launch_point_sample_strided(level0, B, S_, H8, W8, xy, 2, N, out, st);
+}
+
+// ------------------------------------------------------------------------ state init
+// nets/pips.py:450-455 (coords), :466 (ffeats repeat), :468 (coords_bak), :474 (first entry
+// of coord_predictions2).  Phase 0 writes coords; phase 1 (after the point sample) ffeats.
+__global__ void init_coords_kernel(const float* __restrict__ xys, const float* __restrict__ coords_init,
+                                   int B, int N, float stride, float* __restrict__ coords,
+                                   float* __restrict__ coords0, float* __restrict__ out_traj0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // (b*N + n)*S + s
+    if (i >= B * N * S) return;
+    const int s = i % S, pn = i / S, n = pn % N, b = pn / N;
+    float x, y;
+    if (coords_init != nullptr) {
+        const float* p = coords_init + (((size_t)b * S + s) * N + n) * 2;
+        x = p[0] / stride; y = p[1] / stride;
+    } else {
+        x = xys[(size_t)pn * 2 + 0] / stride; y = xys[(size_t)pn * 2 + 1] / stride;
+    }
+    coords[(size_t)i * 2 + 0] = x; coords[(size_t)i * 2 + 1] = y;
+    coords0[(size_t)i * 2 + 0] = x; coords0[(size_t)i * 2 + 1] = y;
+    float* o = out_traj0 + (((size_t)b * S + s) * N + n) * 2;
+    o[0] = x * stride; o[1] = y * stride;
+}
+
+__global__ void init_ffeats_kernel(const float4* __restrict__ ffeat0, int BN, float4* __restrict__ ffeats) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over BN*S*32 float4
+    if (i >= (size_t)BN * S * (C / 4)) return;
+    const size_t pn = i / (S * (C / 4));
+    ffeats[i] = ffeat0[pn * (C / 4) + (i % (C / 4))];
+}
+
+int launch_init_coords(const float* xys, const float* coords_init, int B, int N, float stride,
+                       float* coords, float* coords0, float* out_traj0, hipStream_t st) {
+    const int total = B * N * S;
+    hipLaunchKernelGGL(init_coords_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, xys, coords_init, B,
+                       N, stride, coords, coords0, out_traj0);
+    PIPS_CHECK_LAUNCH("init_coords_kernel");
+    return PIPS_OK;
+}
+
+int launch_init_ffeats(const float* ffeat0, int BN, float* ffeats, hipStream_t st) {
+    const size_t total = (size_t)BN * S * (C / 4);
+    hipLaunchKernelGGL(init_ffeats_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(ffeat0), BN, reinterpret_cast<float4*>(ffeats));
+    PIPS_CHECK_LAUNCH("init_ffeats_kernel");
+    return PIPS_OK;
+}
+
+// ------------------------------------------------------------------- mixer input build
+// CorrBlock.corr + CorrBlock.sample (nets/pips.py:384-398, 355-382) without ever forming
+// the (B,S,N,H,W) correlation volume, fused with get_3d_embedding (utils/misc.py:44-69)
+// and the concat of DeltaBlock.forward (:304-308).
+//
+// One block per mixer row m=(b,n,s); wave l handles pyramid level l.  All 49 bilinear
+// taps of a level share one fractional offset, so they live on an 8x8 integer pixel
+// window: the wave reads the window as 8 contiguous 4 KiB row segments (2 pixels x 128
+// channels per 1 KiB wave load), forms 64 dot products <ffeat, pixel> (32 lanes x float4
+// per pixel, transpose-reduced over the 32-lane halves), scales by 1/sqrt(C), and blends
+// 2x2 -> 49 taps written in the reference's transposed order (k = ix*7 + iy).
+// Out-of-map pixels contribute 0 (grid_sample zeros padding, align_corners=True).
+struct LevelTable {
+    size_t off[PIPS_LEVELS];
+    int H[PIPS_LEVELS], W[PIPS_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void mixer_input_kernel(const float* __restrict__ pyramid,
+                                                          LevelTable lv, int S_,
+                                                          const float* __restrict__ ffeats,
+                                                          const float* __restrict__ coords,
+                                                          const float* __restrict__ times, int N,
+                                                          float* __restrict__ X) {
+    __shared__ float Dw[PIPS_LEVELS][64];
+    const int m = blockIdx.x;
+    const int s = m % S, pn = m / S;
+    const int b = pn / N;
+    const int frame = b * S_ + s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int lvl = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float cxm = coords[(size_t)m * 2 + 0], cym = coords[(size_t)m * 2 + 1];
+    float* xrow = X + (size_t)m * PIPS_KIN_PAD;
+    const float* ff = ffeats + (size_t)m * C;
+
+    // ---- correlation window of this wave's level
+    {
+        const int H = lv.H[lvl], W = lv.W[lvl];
+        const float inv = 1.0f / (float)(1 << lvl);
+        const float cx = cxm * inv, cy = cym * inv;        // coords / 2**i  (:373)
+        // bilinear_sampler normalisation (:318-319) and grid_sample's un-normalisation
+        // (align_corners=True, CPU form (g+1)*((size-1)/2)), reproduced op by op
+        const float gx = __fsub_rn(__fdiv_rn(2.0f * cx, (float)(W - 1)), 1.0f);
+        const float gy = __fsub_rn(__fdiv_rn(2.0f * cy, (float)(H - 1)), 1.0f);
+        const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), (float)(W - 1) / 2.0f);
+        const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), (float)(H - 1) / 2.0f);
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const float wx = ix - fx0, wy = iy - fy0;          // east / south weights
+        const int bx = (int)fx0 - PIPS_RADIUS, by = (int)fy0 - PIPS_RADIUS;
+
+        const int hsel = lane >> 5, c4 = lane & 31;
+        const float4 f4 = *reinterpret_cast<const float4*>(ff + c4 * 4);
+        const float* base = pyramid + lv.off[lvl] + (size_t)frame * H * W * C + c4 * 4;
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int py = by + j;
+            const bool yok = (unsigned)py < (unsigned)H;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int px = bx + 2 * q + hsel;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (yok && (unsigned)px < (unsigned)W)
+                    t = *reinterpret_cast<const float4*>(base + ((size_t)py * W + px) * C);
+                v[j * 4 + q] = t.x * f4.x + t.y * f4.y + t.z * f4.z + t.w * f4.w;
+            }
+        }
+        // transpose-reduce over the 32 lanes of each half: lane r ends with sum of v[r]
+#pragma unroll
+        for (int o = 16, n = 32; o >= 1; o >>= 1, n >>= 1) {
+            const bool up = (lane & o) != 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < n / 2) {
+                    const float send = up ? v[k] : v[k + n / 2];
+                    const float keep = up ? v[k + n / 2] : v[k];
+                    v[k] = keep + __shfl_xor(send, o);
+                }
+            }
+        }
+        // lane (hsel, r=c4): window row j = r>>2, column 2*(r&3) + hsel
+        const float scale = sqrtf((float)C);
+        Dw[lvl][(c4 >> 2) * 8 + 2 * (c4 & 3) + hsel] = v[0] / scale;     // corrs / sqrt(C) (:397)
+        __syncthreads();                       // (all four waves take the same path)
+        if (lane < 49) {
+            const int ti = lane / 7, tj = lane - ti * 7;                 // x index, y index
+            const float e = 1.0f - wx, so = 1.0f - wy;
+            const float nw = Dw[lvl][tj * 8 + ti], ne = Dw[lvl][tj * 8 + ti + 1];
+            const float sw = Dw[lvl][(tj + 1) * 8 + ti], se = Dw[lvl][(tj + 1) * 8 + ti + 1];
+            float o = nw * (so * e);
+            o += ne * (so * wx);
+            o += sw * (wy * e);
+            o += se * (wy * wx);
+            xrow[C + lvl * 49 + lane] = o;                                // k = ix*7 + iy
+        }
+    }
+
+    // ---- feature copy, sin/cos embedding of (dx, dy, t), raw flow, zero pad
+    if (tid < C / 4)
+        reinterpret_cast<float4*>(xrow)[tid] = reinterpret_cast<const float4*>(ff)[tid];
+    const float dx = cxm - coords[(size_t)pn * S * 2 + 0];              // coords - coords[:,0:1] (:518)
+    const float dy = cym - coords[(size_t)pn * S * 2 + 1];
+    const float tt = times[s];                                           // linspace(0,S,S) (:519)
+    if (tid < 192) {
+        const int a = tid >> 6, i = tid & 63;
+        const float val = a == 0 ? dx : (a == 1 ? dy : tt);
+        const float freq = (float)(i >> 1) * 31.25f;                     // arange(0,64,2)*(1000/64)
+        const float arg = __fmul_rn(val, freq);
+        xrow[C + PIPS_NCORR + tid] = (i & 1) ? cosf(arg) : sinf(arg);    // misc.py:56-63
+    } else if (tid < 192 + 3) {
+        const int a = tid - 192;
+        xrow[C + PIPS_NCORR + 192 + a] = a == 0 ? dx : (a == 1 ? dy : tt);
+    } else if (tid < 192 + 3 + (PIPS_KIN_PAD - PIPS_KIN)) {
+        xrow[PIPS_KIN + (tid - 195)] = 0.f;
+    }
+}
+
+int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW,
+                       int B, int S_, const float* ffeats, const float* coords, const float* times,
+                       int N, float* X, hipStream_t st) {
+    LevelTable lv;
+    for (int l = 0; l < PIPS_LEVELS; ++l) { lv.off[l] = lvl_off[l]; lv.H[l] = lvlH[l]; lv.W[l] = lvlW[l]; }
+    hipLaunchKernelGGL(mixer_input_kernel, dim3(B * N * S), dim3(256), 0, st, pyramid, lv, S_, ffeats,
+                       coords, times, N, X);
+    PIPS_CHECK_LAUNCH("mixer_input_kernel");
+    return PIPS_OK;
+}
+
+// ------------------------------------------------------------------------ token mixing
+// First half of a mixer block + the LayerNorm of the second half (nets/pips.py:117-118):
+//   y  = x + Conv1d(32->8)(GELU(Conv1d(8->32)(LN1(x))))     tokens = the S axis
+//   xn = LN2(y)                                             (input of the 512->2048 GEMM)
+// One block per particle: its (8 tokens x 512 channels) tile lives in registers, two
+// channels per thread; LN statistics are two-pass (mean, then centred squares) in fp32.
+__device__ __forceinline__ void block_sum8(float (&v)[S], float (*red)[S]) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+        for (int t = 0; t < S; ++t) v[t] += __shfl_xor(v[t], o);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                       // previous use of red finished
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int t = 0; t < S; ++t) red[wave][t] = v[t];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < S; ++t) v[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+
+__device__ __forceinline__ void ln_stats(const float (&x0)[S], const float (&x1)[S], float (&mean)[S],
+                                         float (&rstd)[S], float (*red)[S]) {
+    float a[S];
+#pragma unroll
+    for (int t = 0; t < S; ++t) a[t] = x0[t] + x1[t];
+    block_sum8(a, red);
+#pragma unroll
+    for (int t = 0; t < S; ++t) mean[t] = a[t] * (1.0f / PIPS_DMIX);
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        const float d0 = x0[t] - mean[t], d1 = x1[t] - mean[t];
+        a[t] = d0 * d0 + d1 * d1;
+    }
+    block_sum8(a, red);
+#pragma unroll
+    for (int t = 0; t < S; ++t) rstd[t] = 1.0f / sqrtf(a[t] * (1.0f / PIPS_DMIX) + 1e-5f);
+}
+
+__global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict__ arena, MixLayerW L,
+                                                        float* __restrict__ x, float* __restrict__ xn) {
+    __shared__ float red[4][S];
+    __shared__ float wsm[32 * 8 + 32 + 8 * 32 + 8];
+    const int tid = threadIdx.x;
+    // stage the tiny token-MLP weights: w0[32][8], b0[32], w3[8][32], b3[8]
+    for (int i = tid; i < 256; i += 256) wsm[i] = arena[L.tw0 + i];
+    if (tid < 32) wsm[256 + tid] = arena[L.tb0 + tid];
+    for (int i = tid; i < 256; i += 256) wsm[288 + i] = arena[L.tw3 + i];
+    if (tid < 8) wsm[544 + tid] = arena[L.tb3 + tid];
+
+    float* xp = x + (size_t)blockIdx.x * S * PIPS_DMIX;
+    float* xnp = xn + (size_t)blockIdx.x * S * PIPS_DMIX;
+    const int c0 = tid, c1 = tid + 256;
+    float x0[S], x1[S], mean[S], rstd[S];
+#pragma unroll
+    for (int t = 0; t < S; ++t) { x0[t] = xp[t * PIPS_DMIX + c0]; x1[t] = xp[t * PIPS_DMIX + c1]; }
+    ln_stats(x0, x1, mean, rstd, red);       // (contains the barriers that publish wsm)
+
+    const float g0 = arena[L.ln1g + c0], g1 = arena[L.ln1g + c1];
+    const float be0 = arena[L.ln1b + c0], be1 = arena[L.ln1b + c1];
+    float h0[S], h1[S];
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        h0[t] = (x0[t] - mean[t]) * rstd[t] * g0 + be0;
+        h1[t] = (x1[t] - mean[t]) * rstd[t] * g1 + be1;
+    }
+    float y0[S], y1[S];
+#pragma unroll
+    for (int t = 0; t < S; ++t) { y0[t] = wsm[544 + t]; y1[t] = wsm[544 + t]; }
+#pragma unroll 4
+    for (int j = 0; j < 32; ++j) {
+        float u0 = wsm[256 + j], u1 = u0;
+#pragma unroll
+        for (int t = 0; t < S; ++t) { u0 = fmaf(wsm[j * 8 + t], h0[t], u0); u1 = fmaf(wsm[j * 8 + t], h1[t], u1); }
+        u0 = gelu_erf_t(u0); u1 = gelu_erf_t(u1);
+#pragma unroll
+        for (int t = 0; t < S; ++t) { y0[t] = fmaf(wsm[288 + t * 32 + j], u0, y0[t]); y1[t] = fmaf(wsm[288 + t * 32 + j], u1, y1[t]); }
+    }
+#pragma unroll
+    for (int t = 0; t < S; ++t) { y0[t] += x0[t]; y1[t] += x1[t]; }
+
+    ln_stats(y0, y1, mean, rstd, red);
+    const float q0 = arena[L.ln2g + c0], q1 = arena[L.ln2g + c1];
+    const float r0 = arena[L.ln2b + c0], r1 = arena[L.ln2b + c1];
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        xp[t * PIPS_DMIX + c0] = y0[t];
+        xp[t * PIPS_DMIX + c1] = y1[t];
+        xnp[t * PIPS_DMIX + c0] = (y0[t] - mean[t]) * rstd[t] * q0 + r0;
+        xnp[t * PIPS_DMIX + c1] = (y1[t] - mean[t]) * rstd[t] * q1 + r1;
+    }
+}
+
+int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(token_mix_kernel, dim3(particles), dim3(256), 0, st, arena, L, x, xn);
+    PIPS_CHECK_LAUNCH("token_mix_kernel");
+    return PIPS_OK;
+}
+
+// ------------------------------------------------------------------------ final LN + mean
+// nn.LayerNorm(512) then Reduce('b n c -> b c','mean') (nets/pips.py:120-121).
+__global__ __launch_bounds__(256) void ln_mean_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                      const float* __restrict__ bta, float* __restrict__ out) {
+    __shared__ float red[4][S];
+    const float* xp = x + (size_t)blockIdx.x * S * PIPS_DMIX;
+    const int c0 = threadIdx.x, c1 = threadIdx.x + 256;
+    float x0[S], x1[S], mean[S], rstd[S];
+#pragma unroll
+    for (int t = 0; t < S; ++t) { x0[t] = xp[t * PIPS_DMIX + c0]; x1[t] = xp[t * PIPS_DMIX + c1]; }
+    ln_stats(x0, x1, mean, rstd, red);
+    const float g0 = g[c0], g1 = g[c1], b0 = bta[c0], b1 = bta[c1];
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        a0 += (x0[t] - mean[t]) * rstd[t] * g0 + b0;
+        a1 += (x1[t] - mean[t]) * rstd[t] * g1 + b1;
+    }
+    out[(size_t)blockIdx.x * PIPS_DMIX + c0] = a0 * (1.0f / S);
+    out[(size_t)blockIdx.x * PIPS_DMIX + c1] = a1 * (1.0f / S);
+}
+
+int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(ln_mean_kernel, dim3(particles), dim3(256), 0, st, x, g, b, out);
+    PIPS_CHECK_LAUNCH("ln_mean_kernel");
+    return PIPS_OK;
+}
+
+// ------------------------------------------------------------------------ state update
+// nets/pips.py:525-539: ffeats += GELU(Linear(GroupNorm(1,128)(dfeat))); coords += dcoord;
+// frame 0 locked to the query; trajectory written in pixels as (B,S,N,2).  Optionally the
+// visibility head Linear(128->1) on the NEW features (:559).  One block per particle.
+__global__ __launch_bounds__(256) void state_update_kernel(const float* __restrict__ arena,
+                                                           size_t o_ng, size_t o_nb, size_t o_wt, size_t o_b,
+                                                           size_t o_wv, size_t o_bv,
+                                                           const float* __restrict__ delta,
+                                                           float* __restrict__ ffeats, float* __restrict__ coords,
+                                                           const float* __restrict__ coords0, int N, float stride,
+                                                           float* __restrict__ out_traj, float* __restrict__ out_vis) {
+    __shared__ __attribute__((aligned(16))) float hs[C][S];      // normalised dfeat, [k][row]
+    __shared__ float vred[4][4];
+    const int pn = blockIdx.x, tid = threadIdx.x;
+    const int b = pn / N, n = pn - b * N;
+    const float* dp = delta + (size_t)pn * PIPS_NOUT;
+
+    // LayerNorm over the 128 delta-feature channels of each of the 8 rows
+    {
+        const int row = tid >> 5, l = tid & 31;
+        const float* d = dp + row * (C + 2) + 2 + l * 4;
+        float v[4] = {d[0], d[1], d[2], d[3]};
+        float sum = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float t = v[k] - mean; sq += t * t; }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = l * 4 + k;
+            hs[c][row] = (v[k] - mean) * rstd * arena[o_ng + c] + arena[o_nb + c];
+        }
+    }
+    __syncthreads();
+
+    // Linear 128->128 (weights transposed [k][o]) + GELU + residual
+    const int o = tid & 127, r0 = (tid >> 7) * 4;
+    float acc[4];
+    const float bo = arena[o_b + o];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = bo;
+    const float* wt = arena + o_wt + o;
+#pragma unroll 8
+    for (int k = 0; k < C; ++k) {
+        const float w = wt[(size_t)k * C];
+        const float4 h = *reinterpret_cast<const float4*>(&hs[k][r0]);
+        acc[0] = fmaf(h.x, w, acc[0]); acc[1] = fmaf(h.y, w, acc[1]);
+        acc[2] = fmaf(h.z, w, acc[2]); acc[3] = fmaf(h.w, w, acc[3]);
+    }
+    float vis_part[4];
+    const float wv = out_vis != nullptr ? arena[o_wv + o] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float* fp = ffeats + ((size_t)pn * S + r0 + r) * C + o;
+        const float nf = gelu_erf_t(acc[r]) + *fp;
+        *fp = nf;
+        vis_part[r] = nf * wv;
+    }
+
+    if (tid < S) {
+        const int t = tid;
+        const size_t ci = ((size_t)pn * S + t) * 2;
+        float cx = coords[ci] + dp[t * (C + 2) + 0];
+        float cy = coords[ci + 1] + dp[t * (C + 2) + 1];
+        if (t == 0) { cx = coords0[ci]; cy = coords0[ci + 1]; }      // lock frame 0 (:535-536)
+        coords[ci] = cx; coords[ci + 1] = cy;
+        float* ot = out_traj + (((size_t)b * S + t) * N + n) * 2;
+        ot[0] = cx * stride; ot[1] = cy * stride;                     // :538
+    }
+
+    if (out_vis != nullptr) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vis_part[r] += __shfl_xor(vis_part[r], off);
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vred[tid >> 6][r] = vis_part[r];
+        __syncthreads();
+        if (tid < S) {
+            const int t = tid, grp = t >> 2, r = t & 3;             // rows 0-3: waves 0,1; rows 4-7: waves 2,3
+            const float v = vred[grp * 2][r] + vred[grp * 2 + 1][r] + arena[o_bv];
+            out_vis[((size_t)b * S + t) * N + n] = v;
+        }
+    }
+}
+
+int launch_state_update(const float* arena, const float* delta, float* ffeats, float* coords,
+                        const float* coords0, int B, int N, float stride, float* out_traj,
+                        float* out_vis, hipStream_t st) {
+    const ArenaLayout& A = arena_layout();
+    hipLaunchKernelGGL(state_update_kernel, dim3(B * N), dim3(256), 0, st, arena,
+                       A.norm_g, A.norm_b, A.w_upd_t, A.b_upd, A.w_vis, A.b_vis, delta, ffeats, coords,
+                       coords0, N, stride, out_traj, out_vis);
+    PIPS_CHECK_LAUNCH("state_update_kernel");
+    return PIPS_OK;
+}
+
+}  // namespace pips

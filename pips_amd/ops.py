@@ -1,0 +1,163 @@
+"""Thin tensor-level wrappers over the C ABI stage entry points (include/pips_hip.h).
+
+torch is used for device memory and the current stream only; every number is produced by
+libpips_hip.so.  These wrappers exist for the parity tests and for callers that keep the
+pyramid resident between calls (dense-grid / chained tracking).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .weights import param_table
+
+S = 8
+LATENT = 128
+KIN_PAD = 544
+NOUT = 1040
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    assert t.is_cuda, "pips_amd runs on the GPU only (no CPU fallback)"
+    return t.contiguous().to(torch.float32)
+
+
+def pack_weights(state_dict, device) -> torch.Tensor:
+    """state dict (reference key names/layouts) -> packed device arena (pips_repack_weights)."""
+    lib = _lib.load()
+    names = list(param_table().keys())
+    missing = [k for k in names if k not in state_dict]
+    if missing:
+        raise KeyError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+    with torch.cuda.device(device):
+        srcs = [_f32(state_dict[k].detach().to(device)) for k in names]
+        arena = torch.empty(lib.pips_weight_arena_bytes() // 4, dtype=torch.float32, device=device)
+        arr = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+        _lib.check(lib.pips_repack_weights(arr, len(srcs), _lib.ptr(arena), _stream()), "pips_repack_weights")
+        torch.cuda.current_stream().synchronize()      # srcs may be temporaries
+    return arena
+
+
+def times_table(device) -> torch.Tensor:
+    # torch.linspace(0, S, S) exactly as nets/pips.py:519 builds it
+    return torch.linspace(0, S, S, device=device, dtype=torch.float32)
+
+
+def pyramid_levels(pyr: torch.Tensor, F: int, H: int, W: int, stride: int):
+    """Views (F,H_l,W_l,128) of the packed pyramid buffer."""
+    lib = _lib.load()
+    out = []
+    h, w = H // stride, W // stride
+    for l in range(4):
+        off = lib.pips_pyramid_offset(F, H, W, stride, l)
+        out.append(pyr[off:off + F * h * w * LATENT].view(F, h, w, LATENT))
+        h, w = h // 2, w // 2
+    return out
+
+
+def encoder_fwd(arena, rgbs, stride):
+    """rgbs (F,3,H,W) 0..255 -> packed channel-last pyramid buffer."""
+    lib = _lib.load()
+    rgbs = _f32(rgbs)
+    F, _, H, W = rgbs.shape
+    with torch.cuda.device(rgbs.device):
+        pyr = torch.empty(lib.pips_pyramid_floats(F, H, W, stride), dtype=torch.float32, device=rgbs.device)
+        nb = lib.pips_encoder_workspace_bytes(F, H, W, stride)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=rgbs.device)
+        _lib.check(lib.pips_encoder_fwd(_lib.ptr(arena), _lib.ptr(rgbs), F, H, W, stride, _lib.ptr(pyr),
+                                        _lib.ptr(ws), nb, _stream()), "pips_encoder_fwd")
+    return pyr
+
+
+def point_sample(level0, B, xy):
+    """level0 (B*S,H8,W8,128), xy (B,N,2) map pixels -> (B,N,128)."""
+    lib = _lib.load()
+    xy = _f32(xy)
+    F, H8, W8, _ = level0.shape
+    N = xy.shape[1]
+    out = torch.empty(B, N, LATENT, dtype=torch.float32, device=xy.device)
+    with torch.cuda.device(xy.device):
+        _lib.check(lib.pips_point_sample(_lib.ptr(level0), B, F // B, H8, W8, _lib.ptr(xy), N, _lib.ptr(out),
+                                         _stream()), "pips_point_sample")
+    return out
+
+
+def mixer_input_build(pyr, B, H8, W8, ffeats, coords):
+    """ffeats (B*N*S,128), coords (B*N*S,2) particle-major -> X (B*N*S, 544)."""
+    lib = _lib.load()
+    ffeats, coords = _f32(ffeats), _f32(coords)
+    M = ffeats.shape[0]
+    N = M // (B * S)
+    X = torch.empty(M, KIN_PAD, dtype=torch.float32, device=ffeats.device)
+    tt = times_table(ffeats.device)
+    with torch.cuda.device(ffeats.device):
+        _lib.check(lib.pips_mixer_input_build(_lib.ptr(pyr), B, S, H8, W8, _lib.ptr(ffeats), _lib.ptr(coords),
+                                              _lib.ptr(tt), N, _lib.ptr(X), _stream()), "pips_mixer_input_build")
+    return X
+
+
+def mixer_fwd(arena, X):
+    """X (M,544) -> delta (M/8, 1040)."""
+    lib = _lib.load()
+    X = _f32(X)
+    M = X.shape[0]
+    delta = torch.empty(M // S, NOUT, dtype=torch.float32, device=X.device)
+    nb = lib.pips_mixer_workspace_bytes(M)
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _lib.check(lib.pips_mixer_fwd(_lib.ptr(arena), _lib.ptr(X), M, _lib.ptr(delta), _lib.ptr(ws), nb, _stream()),
+                   "pips_mixer_fwd")
+    return delta
+
+
+def state_update(arena, delta, ffeats, coords, coords0, B, N, stride, want_vis=False):
+    """In-place update of ffeats/coords (particle-major); returns (traj (B,S,N,2) px, vis or None)."""
+    lib = _lib.load()
+    traj = torch.empty(B, S, N, 2, dtype=torch.float32, device=delta.device)
+    vis = torch.empty(B, S, N, dtype=torch.float32, device=delta.device) if want_vis else None
+    with torch.cuda.device(delta.device):
+        _lib.check(lib.pips_state_update(_lib.ptr(arena), _lib.ptr(delta), _lib.ptr(ffeats), _lib.ptr(coords),
+                                         _lib.ptr(coords0), B, N, float(stride), _lib.ptr(traj), _lib.ptr(vis),
+                                         _stream()), "pips_state_update")
+    return traj, vis
+
+
+def gemm(A, W, bias=None, epi=0, R=None):
+    """C = epi(A @ W.T + bias).  epi: 0 none, 1 GELU, 2 + R."""
+    lib = _lib.load()
+    A, W = _f32(A), _f32(W)
+    M, K = A.shape
+    N = W.shape[0]
+    Cm = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        _lib.check(lib.pips_gemm_f32(_lib.ptr(A), K, _lib.ptr(W), _lib.ptr(bias), _lib.ptr(Cm), N, M, N, K, epi,
+                                     _lib.ptr(R), N if R is not None else 0, _stream()), "pips_gemm_f32")
+    return Cm
+
+
+def conv_nhwc(x, w_packed, bias, ksize, stride, pad, want_stats=False):
+    """x (F,H,W,Cin) NHWC, w_packed (Cout, k, k, Cin) -> (F,Ho,Wo,Cout) [+ partial stats]."""
+    lib = _lib.load()
+    x, w_packed = _f32(x), _f32(w_packed)
+    F, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    Ho = (H + 2 * pad - ksize) // stride + 1
+    Wo = (W + 2 * pad - ksize) // stride + 1
+    out = torch.empty(F, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats:
+        stats = torch.zeros(F, (Ho * Wo + 63) // 64, Cout, 2, dtype=torch.float32, device=x.device)
+    tiles = C.c_int(0)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pips_conv_nhwc_f32(_lib.ptr(x), F, H, W, Cin, _lib.ptr(w_packed), _lib.ptr(bias), Cout, ksize,
+                                          stride, pad, _lib.ptr(out), _lib.ptr(stats), C.byref(tiles), _stream()),
+                   "pips_conv_nhwc_f32")
+    if want_stats:
+        return out, stats.view(-1)[: F * tiles.value * Cout * 2].view(F, tiles.value, Cout, 2)
+    return out

@@ -1,0 +1,149 @@
+"""``Pips`` -- drop-in for ``nets.pips.Pips`` (nets/pips.py:400-611) whose forward runs
+entirely in libpips_hip.so (hand-written HIP for gfx950).
+
+Same constructor ``Pips(S=8, stride=8)``, same 200-key state dict (so
+``saverloader.load`` / ``load_state_dict`` of a reference checkpoint work unchanged),
+same ``forward(xys, rgbs, coords_init, feat_init, iters, trajs_g, vis_g, valids, sw,
+return_feat, is_train)`` signature and the same returned tuple:
+``(coord_predictions [iters x (B,S,N,2)], coord_predictions2 [iters+4], vis_e (B,S,N),
+losses)`` or, with ``return_feat=True``, ``(..., vis_e, ffeat (B,N,128), losses)``.
+
+Inference only: ``is_train=True`` raises; the tensorboard branches behind
+``sw.save_this`` are not drawn; ``losses`` carries ``(seq_loss, vis_loss, None)`` when
+``trajs_g`` is given (the score-map loss needs the dense correlation volume this path
+never forms, nets/pips.py:504-511,603).  There is no PyTorch fallback: without the HIP
+library or a GPU the forward raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .weights import init_state_dict, param_table
+
+
+class _Node(nn.Module):
+    """Bare container: only carries parameters/children under the reference's names."""
+
+
+class Pips(nn.Module):
+    def __init__(self, S: int = 8, stride: int = 8):
+        super().__init__()
+        if S != 8:
+            # the reference builds S-dependent mixer weights (nets/pips.py:295-301); the HIP
+            # kernels are specialised for the S=8 every shipped checkpoint/caller uses
+            raise ValueError("pips_amd.Pips supports S=8 only")
+        self.S = S
+        self.stride = stride
+        self.hidden_dim = 256
+        self.latent_dim = 128
+        self.corr_levels = 4
+        self.corr_radius = 3
+        init = init_state_dict(seed=0, S=S)
+        for name in param_table(S):
+            *path, leaf = name.split(".")
+            node = self
+            for p in path:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            node.register_parameter(leaf, nn.Parameter(init[name], requires_grad=False))
+        self._names = list(param_table(S).keys())
+        self._arena = None
+        self._arena_key = None
+        self._ws = {}
+        self._times = None
+
+    # ------------------------------------------------------------------ weights
+    def _packed(self, device):
+        sd = dict(self.named_parameters())
+        key = (str(device),) + tuple((sd[k].data_ptr(), sd[k]._version) for k in self._names)
+        if self._arena is None or key != self._arena_key:
+            self._arena = ops.pack_weights({k: sd[k] for k in self._names}, device)
+            self._arena_key = key
+        return self._arena
+
+    def _workspace(self, lib, dims, device):
+        k = (str(device),) + dims
+        ws = self._ws.get(k)
+        if ws is None:
+            nb = lib.pips_workspace_bytes(*dims)
+            if nb == 0:
+                raise _lib.PipsHipError(f"unsupported problem size {dims}")
+            self._ws.clear()                      # one resident workspace per module
+            ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
+            self._ws[k] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, xys, rgbs, coords_init=None, feat_init=None, iters=3, trajs_g=None, vis_g=None,
+                valids=None, sw=None, return_feat=False, is_train=False):
+        if is_train:
+            raise NotImplementedError("pips_amd.Pips is the inference path (nets/pips.py:535: is_train=False)")
+        B, N, D = xys.shape
+        assert D == 2
+        B2, S, C3, H, W = rgbs.shape
+        assert B2 == B and C3 == 3 and S == self.S
+        if not rgbs.is_cuda:
+            raise _lib.PipsHipError("pips_amd.Pips needs CUDA/HIP tensors (the reference itself calls .cuda(), "
+                                    "nets/pips.py:429); there is no CPU fallback")
+        lib = _lib.load()
+        dev = rgbs.device
+        f32 = torch.float32
+        rgbs_c = rgbs.contiguous().to(f32)
+        xys_c = xys.to(dev).contiguous().to(f32)
+        ci = None if coords_init is None else coords_init.to(dev).contiguous().to(f32)
+        fi = None if feat_init is None else feat_init.to(dev).contiguous().to(f32)
+        if ci is not None:
+            assert tuple(ci.shape) == (B, S, N, 2)
+        if fi is not None:
+            assert tuple(fi.shape) == (B, N, self.latent_dim)
+        with torch.cuda.device(dev):
+            arena = self._packed(dev)
+            if self._times is None or self._times.device != dev:
+                self._times = ops.times_table(dev)
+            ws = self._workspace(lib, (B, S, H, W, N, int(self.stride)), dev)
+            trajs = torch.empty(iters + 1, B, S, N, 2, dtype=f32, device=dev)
+            vis_e = torch.empty(B, S, N, dtype=f32, device=dev)
+            ffeat = torch.empty(B, N, self.latent_dim, dtype=f32, device=dev)
+            rc = lib.pips_forward(_lib.ptr(arena), _lib.ptr(rgbs_c), _lib.ptr(xys_c), _lib.ptr(ci), _lib.ptr(fi),
+                                  _lib.ptr(self._times), B, S, H, W, N, int(self.stride), int(iters), 0,
+                                  _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(rc, "pips_forward")
+        coord_predictions = [trajs[i + 1] for i in range(iters)]
+        # nets/pips.py:474-475,539,562-563: two copies of the start, every iterate, two of the end
+        coord_predictions2 = [trajs[0], trajs[0]] + coord_predictions + [trajs[iters], trajs[iters]]
+        losses = None
+        if trajs_g is not None:
+            losses = _inference_losses(coord_predictions, vis_e, trajs_g, vis_g, valids)
+        if return_feat:
+            return coord_predictions, coord_predictions2, vis_e, ffeat, losses
+        return coord_predictions, coord_predictions2, vis_e, losses
+
+
+def _masked_mean(x, mask):
+    return (x * mask).sum() / (mask.sum() + 1e-6)           # utils.basic.reduce_masked_mean
+
+
+def _inference_losses(preds, vis_e, trajs_g, vis_g, valids, gamma=0.8):
+    """sequence_loss / balanced_ce_loss of nets/pips.py:39-56, 14-37 on the outputs (evaluation
+    scripts pass trajs_g but discard the result, test_on_flt.py:87-100).  Plain torch on a few
+    KB of outputs -- not part of the hot path.  The score-map loss is not available."""
+    n = len(preds)
+    seq = 0.0
+    for i, p in enumerate(preds):
+        w = gamma ** (n - i - 1)
+        seq = seq + w * _masked_mean((p - trajs_g).abs().mean(dim=3), valids)
+    seq = seq / n
+    pos = (vis_g > 0.95).float()
+    neg = (vis_g < 0.05).float()
+    a = -(pos * 2.0 - 1.0) * vis_e
+    b = torch.relu(a)
+    loss = b + torch.log(torch.exp(-b) + torch.exp(a - b))
+    vis_loss = _masked_mean(loss, pos * valids) + _masked_mean(loss, neg * valids)
+    return seq, vis_loss, None

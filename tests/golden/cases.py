@@ -1,0 +1,51 @@
+"""Golden-vector case table shared by make_golden.py (which runs the REAL reference in the
+build container) and the tests (which regenerate the seeded inputs and compare).
+
+Inputs and weights are regenerated from seeds (torch CPU generators are deterministic for
+a fixed torch build; the GPU box runs the same image), so only the reference's OUTPUTS
+are stored.  The one real-image case stores its frames (uint8, half resolution)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name: (B, N, H, W, stride, iters, tamed, special)
+CASES = {
+    "s8_raw_i3": dict(B=1, N=16, H=128, W=160, stride=8, iters=3, tamed=False, border=True),
+    "s8_tamed_i6": dict(B=2, N=5, H=136, W=200, stride=8, iters=6, tamed=True, border=False),
+    "s4_raw_i2": dict(B=1, N=16, H=96, W=128, stride=4, iters=2, tamed=False, border=True),
+    "s8_init_i2": dict(B=1, N=7, H=128, W=160, stride=8, iters=2, tamed=True, border=False, init=True),
+    "demo_half_s4_i2": dict(B=1, N=16, H=180, W=320, stride=4, iters=2, tamed=True, border=False, demo=True),
+}
+
+
+def make_inputs(case: dict, seed: int = 1, S: int = 8):
+    """(xys, rgbs, coords_init, feat_init) on CPU, fp32."""
+    B, N, H, W = case["B"], case["N"], case["H"], case["W"]
+    g = torch.Generator().manual_seed(seed)
+    if case.get("demo"):
+        frames = np.load(os.path.join(HERE, "demo_half_frames.npz"))["frames"]      # (8,180,320,3) uint8
+        rgbs = torch.from_numpy(frames).permute(0, 3, 1, 2).float().unsqueeze(0)
+        # demo.py:32-36: uniform sqrt(N) x sqrt(N) grid with an 8 px margin
+        n_ = int(round(N ** 0.5))
+        gy, gx = torch.meshgrid(torch.linspace(8, H - 8, n_), torch.linspace(8, W - 8, n_), indexing="ij")
+        xys = torch.stack([gx.reshape(-1), gy.reshape(-1)], dim=-1).unsqueeze(0)
+    else:
+        rgbs = torch.randint(0, 256, (B, S, 3, H, W), generator=g).float()
+        xys = torch.rand(B, N, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])
+        if case.get("border"):
+            # exercise zero-padded window taps, clamped point samples and integer coordinates
+            xys[0, 0] = torch.tensor([0.0, 0.0])
+            xys[0, 1] = torch.tensor([W - 1.0, H - 1.0])
+            xys[0, 2] = torch.tensor([3.0, H - 2.5])
+            xys[0, 3] = torch.tensor([W - 1.25, 1.0])
+            xys[0, 4] = torch.tensor([16.0, 24.0])
+    coords_init = feat_init = None
+    if case.get("init"):
+        coords_init = xys.reshape(B, 1, N, 2).repeat(1, S, 1, 1) + torch.randn(B, S, N, 2, generator=g) * 2.0
+        feat_init = torch.randn(B, N, 128, generator=g) * 0.5
+    return xys, rgbs, coords_init, feat_init

@@ -1,0 +1,65 @@
+"""Generate the golden vectors by running the UNMODIFIED reference (build container only).
+
+    python tests/golden/make_golden.py
+
+For every case of cases.py: load seeded weights into /root/reference/nets/pips.py's Pips,
+run forward on the seeded inputs, store coord_predictions / vis_e / ffeat as float32 in
+tests/golden/<case>.npz.  Also writes state_dict_keys.json (names + shapes of the
+reference state dict) and demo_half_frames.npz (first 8 demo frames, PIL-resized to
+320x180, the only stored input).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from oracle import reference_shim as R            # noqa: E402
+from pips_amd.weights import init_state_dict      # noqa: E402
+import cases as G                                 # noqa: E402
+
+
+def make_demo_frames():
+    from PIL import Image
+    d = os.path.join(R.REFERENCE_ROOT, "demo_images")
+    names = sorted(f for f in os.listdir(d) if f.endswith(".jpg"))[:8]
+    frames = [np.asarray(Image.open(os.path.join(d, n)).convert("RGB").resize((320, 180), Image.BILINEAR)) for n in names]
+    np.savez_compressed(os.path.join(HERE, "demo_half_frames.npz"), frames=np.stack(frames).astype(np.uint8))
+
+
+def main():
+    assert R.available(), "reference not mounted at /root/reference"
+    torch.set_num_threads(os.cpu_count())
+    make_demo_frames()
+    keys = None
+    for name, case in G.CASES.items():
+        sd = init_state_dict(0, tamed=case["tamed"])
+        xys, rgbs, ci, fi = G.make_inputs(case)
+        ref = R.load_reference_pips(sd, stride=case["stride"])
+        if keys is None:
+            keys = {k: list(v.shape) for k, v in ref.state_dict().items()}
+        with torch.no_grad():
+            preds, preds2, vis, ffeat, losses = ref(xys, rgbs, coords_init=ci, feat_init=fi, iters=case["iters"],
+                                                    return_feat=True)
+        assert losses is None and len(preds2) == case["iters"] + 4
+        np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                            trajs=torch.stack(preds).numpy().astype(np.float32),
+                            traj0=preds2[0].numpy().astype(np.float32),
+                            vis=vis.numpy().astype(np.float32),
+                            ffeat=ffeat.numpy().astype(np.float32))
+        print(name, "trajs", tuple(torch.stack(preds).shape), "max|disp| px",
+              float((preds[-1] - preds2[0]).abs().max()))
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""CPU: the drop-in boundary -- state-dict compatibility, the C ABI surface, loud failure
+without a GPU.  No compute calls."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_matches_reference_keys():
+    from pips_amd import Pips
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
+        ref = json.load(f)
+    sd = Pips(S=8, stride=8).state_dict()
+    assert list(sd.keys()) == list(ref.keys())                 # same names, same order
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+    assert sum(v.numel() for v in sd.values()) == 28677713
+
+
+def test_load_reference_format_checkpoint(tmp_path, weights_tamed):
+    """saverloader.py:58-59 style: torch.load(...)['model_state_dict'] -> load_state_dict(strict=False)."""
+    from pips_amd import Pips
+    path = tmp_path / "model-000000001.pth"
+    torch.save({"model_state_dict": weights_tamed, "optimizer_state_dict": {}}, path)
+    ck = torch.load(path)
+    m = Pips(stride=4)
+    res = m.load_state_dict(ck["model_state_dict"], strict=False)
+    assert not res.missing_keys and not res.unexpected_keys
+    k = "delta_block.to_delta.15.weight"
+    assert torch.equal(m.state_dict()[k], weights_tamed[k])
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from pips_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "pips_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pips_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    assert declared == set(_lib.SIGNATURES)                    # binding table mirrors the header
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.pips_abi_version() == 1
+    assert lib.pips_weight_arena_bytes() > 28677713 * 4
+    # sizing queries are pure host functions
+    assert lib.pips_workspace_bytes(1, 8, 368, 496, 256, 8) > 0
+    assert lib.pips_workspace_bytes(1, 7, 368, 496, 256, 8) == 0          # S is fixed to 8
+    assert lib.pips_pyramid_offset(8, 368, 496, 8, 1) == 8 * 46 * 62 * 128
+    assert lib.pips_pyramid_floats(8, 368, 496, 8) >= 8 * 128 * (46 * 62 + 23 * 31 + 11 * 15 + 5 * 7)
+
+
+def test_no_cpu_fallback():
+    from pips_amd import Pips, PipsHipError
+    m = Pips()
+    with pytest.raises(PipsHipError):
+        m(torch.zeros(1, 4, 2), torch.zeros(1, 8, 3, 128, 160), iters=1)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "pips_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} references the oracle"

@@ -1,0 +1,60 @@
+"""CPU, world_size 2, gloo: the batch-shard + packed all-gather path of pips_amd.dist."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pips_amd import dist as pd
+
+
+class _FakeTracker:
+    """Stands in for Pips on CPU: deterministic function of the clip content."""
+
+    def __call__(self, xys, rgbs, iters=6, **kw):
+        B, N, _ = xys.shape
+        S = rgbs.shape[1]
+        base = xys.reshape(B, 1, N, 2).repeat(1, S, 1, 1) + rgbs.mean(dim=(2, 3, 4)).reshape(B, S, 1, 1)
+        preds = [base + i for i in range(iters)]
+        vis = base.sum(-1)
+        return preds, [base, base] + preds + [preds[-1]] * 2, vis, None
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    xys = torch.rand(4, 6, 2, generator=g)
+    rgbs = torch.rand(4, 8, 3, 16, 16, generator=g)
+    trajs, vis = pd.track_sharded(_FakeTracker(), xys, rgbs, iters=3)
+    full = _FakeTracker()(xys, rgbs, iters=3)
+    ok = torch.equal(trajs, full[0][-1]) and torch.equal(vis, full[2]) and tuple(trajs.shape) == (4, 8, 6, 2)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_all_gather_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}
+
+
+def test_shard_range():
+    assert pd.shard_range(64, 3, 8) == (24, 32)
+    try:
+        pd.shard_range(7, 0, 2)
+        assert False
+    except ValueError:
+        pass

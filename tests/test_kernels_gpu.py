@@ -1,0 +1,216 @@
+"""Stage-by-stage parity of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Tolerances: every stage is fp32 arithmetic that differs from the reference only by
+summation order, so stage outputs are compared at a few fp32 ulps of the stage's value
+scale (stated per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _oracle():
+    from oracle import pips_oracle as O
+    return O
+
+
+def _rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,epi", [
+    (2048, 2048, 512, 1),      # channel-mix up-projection + GELU (128x128 tiles)
+    (2048, 512, 2048, 2),      # channel-mix down-projection + residual (64x64 tiles)
+    (2048, 512, 544, 0),       # input projection
+    (256, 1040, 512, 0),       # head: N not a tile multiple
+    (77, 130, 64, 0),          # ragged M and N
+    (8, 32, 32, 1),            # tiny
+    (16384, 2048, 512, 1),     # config-3 per-GPU rows
+])
+def test_gemm_f32(M, N, K, epi):
+    from pips_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g) if epi == 2 else None
+    ref = A.double() @ W.double().t() + b.double()
+    if epi == 1:
+        ref = F.gelu(ref)
+    elif epi == 2:
+        ref = ref + R.double()
+    out = ops.gemm(A.to(DEV), W.to(DEV), b.to(DEV), epi, None if R is None else R.to(DEV)).cpu()
+    # asymmetric operands: a transposed C write would fail this by O(1)
+    assert _rel_err(out.double(), ref) < 2e-6
+
+
+def test_gemm_identity_asymmetric():
+    """A = I against an asymmetric W catches row/column swaps in the MFMA C/D map."""
+    from pips_amd import ops
+    K = 64
+    A = torch.eye(K)
+    W = torch.arange(96 * K, dtype=torch.float32).reshape(96, K) * 1e-3
+    out = ops.gemm(A.to(DEV), W.to(DEV)).cpu()
+    assert torch.equal(out, W.t().contiguous())
+
+
+# ----------------------------------------------------------------------------- conv
+@pytest.mark.parametrize("F_,H,W,Cin,Cout,k,s,p", [
+    (2, 46, 62, 64, 64, 3, 1, 1),
+    (2, 46, 62, 64, 96, 3, 2, 1),
+    (1, 23, 31, 96, 96, 3, 1, 1),
+    (2, 23, 31, 96, 128, 1, 2, 0),
+    (1, 16, 20, 416, 256, 3, 1, 1),
+    (1, 16, 20, 256, 128, 1, 1, 0),
+    (8, 92, 124, 64, 64, 3, 1, 1),     # enough blocks for the 128-row tile
+])
+def test_conv_nhwc(F_, H, W, Cin, Cout, k, s, p):
+    from pips_amd import ops
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = torch.randn(F_, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p).permute(0, 2, 3, 1)
+    wp = w.permute(0, 2, 3, 1).contiguous()
+    out, stats = ops.conv_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wp.to(DEV), b.to(DEV), k, s, p,
+                               want_stats=True)
+    out = out.cpu()
+    assert _rel_err(out.double(), ref) < 2e-6
+    st = stats.cpu().double().sum(dim=1)                       # (F, Cout, 2)
+    assert _rel_err(st[..., 0], ref.sum(dim=(1, 2))) < 1e-5
+    assert _rel_err(st[..., 1], (ref * ref).sum(dim=(1, 2))) < 1e-5
+
+
+# ----------------------------------------------------------------------------- encoder
+@pytest.mark.parametrize("H,W,stride", [(128, 160, 8), (96, 128, 4), (136, 200, 8)])
+def test_encoder_pyramid(H, W, stride, weights_raw, arenas):
+    from pips_amd import ops
+    O = _oracle()
+    g = torch.Generator().manual_seed(3)
+    rgbs = torch.randint(0, 256, (8, 3, H, W), generator=g).float()
+    taps = {}
+    fm = O.encoder(weights_raw, 2 * (rgbs / 255.0) - 1.0, stride, taps)
+    pyr_ref = O.build_pyramid(fm.unsqueeze(0))
+    pyr = ops.encoder_fwd(arenas["raw"], rgbs.to(DEV), stride)
+    torch.cuda.synchronize()
+    levels = ops.pyramid_levels(pyr, 8, H, W, stride)
+    for l, (got, ref) in enumerate(zip(levels, pyr_ref)):
+        ref = ref[0].permute(0, 2, 3, 1)
+        assert tuple(got.shape) == tuple(ref.shape)
+        err = float((got.cpu() - ref).abs().max())
+        # feature maps are O(1); 21 normalised convs deep, fp32 reorder noise stays < 5e-5
+        assert err < 2e-4, f"level {l}: {err}"
+
+
+# ----------------------------------------------------------------------------- tracker stages
+def _random_state(B, N, H8, W8, seed=5, spread=1.0):
+    g = torch.Generator().manual_seed(seed)
+    S, C = 8, 128
+    fmaps = torch.randn(B, S, C, H8, W8, generator=g)
+    ffeats = torch.randn(B, S, N, C, generator=g)
+    coords = torch.rand(B, S, N, 2, generator=g) * torch.tensor([W8 - 1.0, H8 - 1.0])
+    coords = coords + torch.randn(B, S, N, 2, generator=g) * spread
+    # out-of-map and border cases
+    coords[0, 0, 0] = torch.tensor([-5.0, -7.5])
+    coords[0, 1, 0] = torch.tensor([W8 + 6.0, H8 + 2.0])
+    coords[0, 2, 0] = torch.tensor([0.0, 0.0])
+    coords[0, 3, 0] = torch.tensor([W8 - 1.0, H8 - 1.0])
+    coords[0, 4, 0] = torch.tensor([2.0, 3.0])
+    coords[0, 5, 0] = torch.tensor([-0.25, H8 - 0.5])
+    return fmaps, ffeats, coords
+
+
+def _pack_pyramid(pyr_ref, B, H, W, stride):
+    """oracle pyramid list (B,S,C,h,w) -> packed channel-last device buffer."""
+    from pips_amd import _lib
+    lib = _lib.load()
+    Fr = B * 8
+    buf = torch.zeros(lib.pips_pyramid_floats(Fr, H, W, stride), dtype=torch.float32)
+    for l, p in enumerate(pyr_ref):
+        off = lib.pips_pyramid_offset(Fr, H, W, stride, l)
+        flat = p.reshape(Fr, 128, p.shape[-2], p.shape[-1]).permute(0, 2, 3, 1).reshape(-1)
+        buf[off:off + flat.numel()] = flat
+    return buf.to(DEV)
+
+
+def _pm(t):
+    """(B,S,N,X) -> particle-major (B*N*S, X)."""
+    B, S, N, X = t.shape
+    return t.permute(0, 2, 1, 3).reshape(B * N * S, X).contiguous()
+
+
+def test_point_sample():
+    from pips_amd import ops
+    O = _oracle()
+    B, N, H8, W8 = 2, 33, 16, 20
+    fmaps, _, coords = _random_state(B, N, H8, W8)
+    xy = coords[:, 0]                                                # includes (-5,-7.5): clamped indices
+    ref = O.point_sample(fmaps[:, 0], xy[..., 0], xy[..., 1])
+    lvl0 = fmaps.reshape(B * 8, 128, H8, W8).permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = ops.point_sample(lvl0, B, xy.to(DEV)).cpu()
+    assert float((out - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,H8,W8", [(1, 24, 16, 20), (2, 9, 17, 25), (1, 5, 46, 62)])
+def test_mixer_input_build(B, N, H8, W8):
+    """Fused correlation gather + embedding vs CorrBlock.corr/sample + get_3d_embedding."""
+    from pips_amd import ops
+    O = _oracle()
+    fmaps, ffeats, coords = _random_state(B, N, H8, W8)
+    pyr_ref = O.build_pyramid(fmaps)
+    X_ref = O.mixer_input(ffeats, O.corr_sample(pyr_ref, ffeats, coords), coords)      # (B*N, S, 519)
+    pyr = _pack_pyramid(pyr_ref, B, H8 * 8, W8 * 8, 8)
+    X = ops.mixer_input_build(pyr, B, H8, W8, _pm(ffeats).to(DEV), _pm(coords).to(DEV)).cpu()
+    X = X.view(B * N, 8, 544)
+    assert torch.equal(X[..., 519:], torch.zeros_like(X[..., 519:]))
+    assert torch.equal(X[..., :128], X_ref[..., :128])                                  # feature copy
+    # correlations are O(|f|^2/sqrt(C)) ~ 11 with 128-term fp32 dots: 2e-5 abs
+    err_corr = float((X[..., 128:324] - X_ref[..., 128:324]).abs().max())
+    assert err_corr < 5e-5, err_corr
+    # sin/cos of arguments up to ~1e4 rad: OCML vs SLEEF differ by <= 2 ulp of 1.0
+    err_emb = float((X[..., 324:516] - X_ref[..., 324:516]).abs().max())
+    assert err_emb < 5e-6, err_emb
+    assert torch.equal(X[..., 516:519], X_ref[..., 516:519])                            # raw flow + time
+
+
+@pytest.mark.parametrize("P", [4, 32, 256])
+def test_mixer(P, weights_raw, arenas):
+    from pips_amd import ops
+    O = _oracle()
+    g = torch.Generator().manual_seed(P)
+    x = torch.randn(P, 8, 519, generator=g)
+    ref = O.mixer(weights_raw, x)
+    X = torch.zeros(P * 8, 544)
+    X[:, :519] = x.reshape(P * 8, 519)
+    out = ops.mixer_fwd(arenas["raw"], X.to(DEV)).cpu()
+    # 12 residual blocks of fp32 GEMMs with K up to 2048; outputs O(1)
+    assert float((out - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_state_update(weights_raw, arenas):
+    from pips_amd import ops
+    O = _oracle()
+    B, N = 2, 19
+    g = torch.Generator().manual_seed(11)
+    ffeats = torch.randn(B, 8, N, 128, generator=g)
+    coords = torch.rand(B, 8, N, 2, generator=g) * 40
+    coords0 = coords + 0.5
+    delta = torch.randn(B * N, 8, 130, generator=g)
+    ff_ref, co_ref = O.update_step(weights_raw, ffeats, coords, coords0, delta)
+    vis_ref = F.linear(ff_ref.reshape(-1, 128), weights_raw["vis_predictor.0.weight"],
+                       weights_raw["vis_predictor.0.bias"]).reshape(B, 8, N)
+    ff = _pm(ffeats).to(DEV)
+    co = _pm(coords).to(DEV)
+    traj, vis = ops.state_update(arenas["raw"], delta.reshape(B * N, 1040).to(DEV), ff, co, _pm(coords0).to(DEV),
+                                 B, N, 8.0, want_vis=True)
+    assert float((ff.cpu() - _pm(ff_ref)).abs().max()) < 2e-5
+    assert float((co.cpu() - _pm(co_ref)).abs().max()) < 1e-5
+    assert float((traj.cpu() - co_ref * 8.0).abs().max()) < 1e-4
+    assert float((vis.cpu() - vis_ref).abs().max()) < 2e-5
+    assert torch.equal(traj.cpu()[:, 0], (coords0 * 8.0)[:, 0])                         # frame 0 locked
