@@ -126,7 +126,8 @@ def cpu_baseline():
     """The CPU oracle (port of nets/pips.py forward) on this host: same workload, bounded sample."""
     from oracle import pips_oracle as O
     from pips_amd.weights import init_state_dict
-    cores = os.cpu_count() or 1
+    from oracle.hostinfo import effective_cpus
+    cores = effective_cpus()                      # cgroup quota, not the 256 logical CPUs
     torch.set_num_threads(cores)
     sd = init_state_dict(0)
     g = torch.Generator().manual_seed(1)

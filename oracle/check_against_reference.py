@@ -29,7 +29,6 @@ def make_inputs(B, N, H, W, seed=1, S=8):
 
 def main():
     assert R.available(), "reference not mounted"
-    torch.set_num_threads(os.cpu_count())
     worst = 0.0
     for (B, N, H, W, stride, iters, tamed) in [
         (1, 16, 128, 160, 8, 3, False),

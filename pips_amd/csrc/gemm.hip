@@ -8,12 +8,18 @@
 // order.  Tiling is for 64-lane waves: each wave owns TM x TN tiles of 32x32, a lane
 // feeds A[row = lane&31][k = lane>>5] / B[k = lane>>5][col = lane&31] per MFMA.
 //
-// LDS image: As[BM][36], Bs[BN][36] floats (32 K-values + 4 pad: the 144-byte row stride
-// makes the ds_read_b128 fragment reads conflict-free for every 16-lane service group).
-// Within a 32-wide K block the two lane halves take interleaved groups of four K values
-// (half h reads k = 8*kk + 4*h + j), the same permutation on A and B, so one
-// ds_read_b128 per operand feeds four MFMAs.
+// A block is WGM x WGN x KS waves: WGM x WGN tile the BM x BN output, the KS wave groups
+// split every staged K block (32*KS wide) between them and are summed through LDS at the
+// end -- small problems (M = 2048 rows at B=1) get two waves per SIMD without shrinking
+// the tile.  LDS image per stage: As[BM][32*KS+4], Bs[BN][32*KS+4] floats; the 16-byte row
+// pad makes the ds_read_b128 fragment reads conflict-free for every 16-lane service
+// group.  Within a 32-wide K slice the two lane halves take interleaved groups of four K
+// values (half h reads k = 8*kk + 4*h + j), the same permutation on A and B, so one
+// ds_read_b128 per operand feeds four MFMAs.  Two LDS stages, one barrier per K block:
+//   global(kb+1) -> registers  ||  MFMA on stage kb&1 ;  registers -> stage (kb+1)&1.
 #include "common.h"
+
+#include <cstdlib>
 
 namespace pips {
 
@@ -24,26 +30,28 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-constexpr int BK = 32;
-constexpr int LDS_LD = 36;
-
-template <int BM, int BN, int WGM, int WGN, bool CONV>
-__global__ __launch_bounds__(WGM * WGN * 64) void igemm_f32_kernel(GemmArgs p) {
-    constexpr int NT = WGM * WGN * 64;
+template <int BM, int BN, int WGM, int WGN, int KS, bool CONV>
+__global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs p) {
+    constexpr int NT = WGM * WGN * KS * 64;
+    constexpr int BKB = 32 * KS;                    // K values staged per iteration
+    constexpr int LD = BKB + 4;                     // LDS row stride (floats)
+    constexpr int TPR = BKB / 4;                    // loader threads per row (float4 each)
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int ROWS_PER_PASS = NT / 8;
+    constexpr int ROWS_PER_PASS = NT / TPR;
     constexpr int PA = BM / ROWS_PER_PASS, PB = BN / ROWS_PER_PASS;
+    constexpr int STAGE = (BM + BN) * LD;           // floats per LDS stage
     static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/loader mismatch");
     static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be 32-granular");
+    static_assert(KS == 1 || (KS - 1) * BM * BN <= 2 * STAGE, "K-split reduction does not fit the stages");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + BM * LDS_LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // two stages: [As | Bs] x 2
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int ks = wave / (WGM * WGN);
+    const int wmn = wave - ks * (WGM * WGN);
+    const int wm = wmn / WGN, wn = wmn % WGN;
     const int l31 = lane & 31, half = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int frame = blockIdx.z;
@@ -55,32 +63,32 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_f32_kernel(GemmArgs p) {
         Cbase += (size_t)frame * p.M * p.ldc;
     }
 
-    // loader coordinates: thread -> (row = tid/8 + pass*ROWS_PER_PASS, 4 floats at cg*4)
-    const int lrow = tid >> 3, cg = tid & 7;
+    // loader coordinates: thread -> (row = tid/TPR + pass*ROWS_PER_PASS, 4 floats at cg*4).
+    // Rows past M / N are clamped to a valid row instead of predicated: an output row
+    // (column) depends only on its own A row (W row) and is never stored when out of range.
+    const int lrow = tid / TPR, cg = tid % TPR;
     int a_hi0[PA], a_wi0[PA];
-    bool a_ok[PA];
-    const float* a_ptr[PA];
+    unsigned a_off[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int m = m0 + lrow + i * ROWS_PER_PASS;
-        a_ok[i] = m < p.M;
+        int m = m0 + lrow + i * ROWS_PER_PASS;
+        m = m < p.M ? m : p.M - 1;
         if (CONV) {
             const int ho = m / p.Wo, wo = m - ho * p.Wo;
             a_hi0[i] = ho * p.cstride - p.pad;
             a_wi0[i] = wo * p.cstride - p.pad;
-            a_ptr[i] = nullptr;
+            a_off[i] = 0;
         } else {
             a_hi0[i] = a_wi0[i] = 0;
-            a_ptr[i] = Abase + (size_t)(a_ok[i] ? m : 0) * p.lda + cg * 4;
+            a_off[i] = (unsigned)m * (unsigned)p.lda + cg * 4;
         }
     }
-    const float* b_ptr[PB];
-    bool b_ok[PB];
+    unsigned b_off[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const int n = n0 + lrow + i * ROWS_PER_PASS;
-        b_ok[i] = n < p.N;
-        b_ptr[i] = p.W + (size_t)(b_ok[i] ? n : 0) * p.K + cg * 4;
+        int n = n0 + lrow + i * ROWS_PER_PASS;
+        n = n < p.N ? n : p.N - 1;
+        b_off[i] = (unsigned)n * (unsigned)p.K + cg * 4;
     }
 
     f32x16 acc[TM][TN];
@@ -92,74 +100,122 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_f32_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[PA], rb[PB];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    auto load_tiles = [&](int kb) {
-        const int k0 = kb * BK;
-        if (CONV) {
-            const int tap = k0 / p.Cin;
-            const int c0 = k0 - tap * p.Cin;
-            const int kh = tap / p.KW, kw = tap - kh * p.KW;
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
-                const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.Win;
-                ra[i] = ok ? *reinterpret_cast<const float4*>(
-                                 Abase + ((size_t)hi * p.Win + wi) * p.Cin + c0 + cg * 4)
-                           : zero4;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < PA; ++i)
-                ra[i] = a_ok[i] ? *reinterpret_cast<const float4*>(a_ptr[i] + k0) : zero4;
-        }
-#pragma unroll
-        for (int i = 0; i < PB; ++i)
-            rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(b_ptr[i] + k0) : zero4;
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int i = 0; i < PA; ++i)
-            *reinterpret_cast<float4*>(&As[(lrow + i * ROWS_PER_PASS) * LDS_LD + cg * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < PB; ++i)
-            *reinterpret_cast<float4*>(&Bs[(lrow + i * ROWS_PER_PASS) * LDS_LD + cg * 4]) = rb[i];
-    };
+    // (macros, not lambdas: by-reference lambda captures sent ra/rb to scratch memory)
+#define PIPS_LOAD_TILES(kb_)                                                                        \
+    {                                                                                               \
+        const int k0_ = (kb_) * BKB;                                                                \
+        if (CONV) {                                                                                 \
+            /* Cin % BKB == 0: a staged K block never straddles a filter tap */                     \
+            const int tap_ = k0_ / p.Cin;                                                           \
+            const int c0_ = k0_ - tap_ * p.Cin;                                                     \
+            const int kh_ = tap_ / p.KW, kw_ = tap_ - kh_ * p.KW;                                   \
+            _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                        \
+                const int hi_ = a_hi0[i] + kh_, wi_ = a_wi0[i] + kw_;                               \
+                const bool ok_ = (unsigned)hi_ < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.Win;  \
+                const int hc_ = ok_ ? hi_ : 0, wc_ = ok_ ? wi_ : 0;                                 \
+                float4 v_ = *reinterpret_cast<const float4*>(                                       \
+                    Abase + ((size_t)hc_ * p.Win + wc_) * p.Cin + c0_ + cg * 4);                    \
+                ra[i] = ok_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                 \
+            }                                                                                       \
+        } else {                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < PA; ++i)                                          \
+                ra[i] = *reinterpret_cast<const float4*>(Abase + a_off[i] + k0_);                   \
+        }                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < PB; ++i)                                              \
+            rb[i] = *reinterpret_cast<const float4*>(p.W + b_off[i] + k0_);                         \
+    }
+#define PIPS_STORE_TILES(buf_)                                                                      \
+    {                                                                                               \
+        float* As_ = smem + (buf_) * STAGE;                                                         \
+        float* Bs_ = As_ + BM * LD;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i)                                              \
+            *reinterpret_cast<float4*>(&As_[(lrow + i * ROWS_PER_PASS) * LD + cg * 4]) = ra[i];     \
+        _Pragma("unroll") for (int i = 0; i < PB; ++i)                                              \
+            *reinterpret_cast<float4*>(&Bs_[(lrow + i * ROWS_PER_PASS) * LD + cg * 4]) = rb[i];     \
+    }
+#define PIPS_FRAGS(dst_a, dst_b, kk_)                                                               \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+            dst_a[i] = *reinterpret_cast<const float4*>(a_frag + i * 32 * LD + (kk_) * 8);          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
+            dst_b[j] = *reinterpret_cast<const float4*>(b_frag + j * 32 * LD + (kk_) * 8);          \
+    }
+#define PIPS_MFMA4(fa, fb)                                                                          \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0); \
+    }
+    // fragments of K sub-step kk+1 are read from LDS before the MFMAs of sub-step kk issue
+#define PIPS_COMPUTE(buf_)                                                                          \
+    {                                                                                               \
+        const float* a_frag = smem + (buf_) * STAGE + (wm * WTM + l31) * LD + ks * 32 + half * 4;   \
+        const float* b_frag = smem + (buf_) * STAGE + BM * LD + (wn * WTN + l31) * LD + ks * 32 + half * 4; \
+        float4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];                                                  \
+        PIPS_FRAGS(fa0, fb0, 0);                                                                    \
+        PIPS_FRAGS(fa1, fb1, 1);                                                                    \
+        PIPS_MFMA4(fa0, fb0);                                                                       \
+        PIPS_FRAGS(fa0, fb0, 2);                                                                    \
+        PIPS_MFMA4(fa1, fb1);                                                                       \
+        PIPS_FRAGS(fa1, fb1, 3);                                                                    \
+        PIPS_MFMA4(fa0, fb0);                                                                       \
+        PIPS_MFMA4(fa1, fb1);                                                                       \
+    }
 
-    const int nk = p.K / BK;
-    load_tiles(0);
-    store_tiles();
+    const int nk = p.K / BKB;
+    PIPS_LOAD_TILES(0);
+    PIPS_STORE_TILES(0);
     __syncthreads();
+    int buf = 0;
+    for (int kb = 0; kb + 1 < nk; ++kb) {
+        PIPS_LOAD_TILES(kb + 1);
+        PIPS_COMPUTE(buf);
+        PIPS_STORE_TILES(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    PIPS_COMPUTE(buf);
+#undef PIPS_LOAD_TILES
+#undef PIPS_STORE_TILES
+#undef PIPS_FRAGS
+#undef PIPS_MFMA4
+#undef PIPS_COMPUTE
 
-    const float* a_frag = &As[(wm * WTM + l31) * LDS_LD + half * 4];
-    const float* b_frag = &Bs[(wn * WTN + l31) * LDS_LD + half * 4];
-
-    for (int kb = 0; kb < nk; ++kb) {
-        if (kb + 1 < nk) load_tiles(kb + 1);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float4 a[TM], b[TN];
+    // ---- K-split reduction: groups ks>0 hand their accumulators to group 0 through LDS
+    if (KS > 1) {
+        __syncthreads();                                  // all waves are done with the stages
+        float* red = smem;                                // [(KS-1)][WGM*WGN][TM*TN*16][64]
+        if (ks > 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const float4*>(a_frag + i * 32 * LDS_LD + kk * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const float4*>(b_frag + j * 32 * LDS_LD + kk * 8);
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
+                    for (int r = 0; r < 16; ++r)
+                        red[((((ks - 1) * (WGM * WGN) + wmn) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane] =
+                            acc[i][j][r];
         }
         __syncthreads();
-        if (kb + 1 < nk) {
-            store_tiles();
-            __syncthreads();
-        }
+        if (ks > 0) return;
+#pragma unroll
+        for (int g = 0; g < KS - 1; ++g)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][j][r] += red[(((g * (WGM * WGN) + wmn) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane];
     }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -190,9 +246,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_f32_kernel(GemmArgs p) {
     }
 
     if (CONV && p.stats != nullptr) {
-        // per-column partial sums of this m-tile: lanes l and l+32 hold the same column
-        __syncthreads();                      // As is free now
-        float* red = As;                      // [WGM][BN][2]
+        // per-column partial sums of this m-tile: lanes l and l+32 hold the same column.
+        // (CONV instantiations use KS == 1, so every wave of the block reaches this point.)
+        __syncthreads();                      // every wave is done with the LDS stages
+        float* red = smem;                    // [WGM][BN][2]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s = csum[j] + __shfl_xor(csum[j], 32);
@@ -221,25 +278,62 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_f32_kernel(GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool CONV>
+template <int BM, int BN, int WGM, int WGN, int KS, bool CONV>
 static int launch_tile(const GemmArgs& a, int frames, hipStream_t st) {
+    static_assert(!CONV || KS == 1, "conv statistics assume KS == 1");
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), frames);
-    dim3 block(WGM * WGN * 64);
-    size_t lds = (size_t)(BM + BN) * LDS_LD * sizeof(float);
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, CONV>), grid, block, lds, st, a);
+    dim3 block(WGM * WGN * KS * 64);
+    size_t lds = (size_t)2 * (BM + BN) * (32 * KS + 4) * sizeof(float);
+    auto kern = igemm_f32_kernel<BM, BN, WGM, WGN, KS, CONV>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;          // idempotent attribute, set once per instantiation
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     PIPS_CHECK_LAUNCH("igemm_f32_kernel");
     return PIPS_OK;
 }
 
+// Debug/tuning hook: PIPS_GEMM_TILE=<id> forces one tile configuration for plain GEMMs.
+static int forced_tile() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("PIPS_GEMM_TILE");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    PIPS_CHECK_ARG(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of 32", a.K);
-    PIPS_CHECK_ARG(a.M > 0 && a.N > 0, "gemm: empty problem");
+    PIPS_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
+    PIPS_CHECK_ARG(a.K % 32 == 0, "gemm: K=%d must be a multiple of 32", a.K);
     PIPS_CHECK_ARG((a.lda % 4) == 0, "gemm: lda must be a multiple of 4 floats");
+    PIPS_CHECK_ARG((unsigned long long)a.M * (unsigned long long)a.lda < (1ull << 32) &&
+                       (unsigned long long)a.N * (unsigned long long)a.K < (1ull << 32),
+                   "gemm: operand exceeds 2^32 elements");
+    const bool k64 = a.K % 64 == 0;
+    switch (forced_tile()) {
+        case 0: return launch_tile<128, 128, 2, 2, 1, false>(a, 1, st);
+        case 1: return launch_tile<128, 64, 2, 2, 1, false>(a, 1, st);
+        case 2: return launch_tile<64, 128, 2, 2, 1, false>(a, 1, st);
+        case 3: return launch_tile<64, 64, 2, 2, 1, false>(a, 1, st);
+        case 4: if (k64) return launch_tile<128, 128, 2, 2, 2, false>(a, 1, st); break;
+        case 5: if (k64) return launch_tile<64, 64, 2, 2, 2, false>(a, 1, st); break;
+        case 6: if (k64) return launch_tile<128, 64, 2, 2, 2, false>(a, 1, st); break;
+        default: break;
+    }
+    // Measured on MI355X (tools/gemm_bench.py): with >= ~2 blocks per CU of 128x128 the big
+    // tile wins (90-105 TF at M=16384); the M=2048 mixer GEMMs are prologue/epilogue bound
+    // and want many small blocks (64x64: 86 TF at N=2048) or, when even 64x64 gives only one
+    // block per CU (N=512), two K-split wave groups per block (70 TF vs 59).
     const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-    const long b64x128 = (long)cdiv(a.M, 64) * cdiv(a.N, 128);
-    if (b128 >= 200) return launch_tile<128, 128, 2, 2, false>(a, 1, st);
-    if (b64x128 >= 200) return launch_tile<64, 128, 2, 2, false>(a, 1, st);
-    return launch_tile<64, 64, 2, 2, false>(a, 1, st);
+    const long b64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
+    if (b128 >= 400) return launch_tile<128, 128, 2, 2, 1, false>(a, 1, st);
+    if (b64 >= 800 || !k64) return launch_tile<64, 64, 2, 2, 1, false>(a, 1, st);
+    return launch_tile<64, 64, 2, 2, 2, false>(a, 1, st);
 }
 
 // tile choice of launch_conv, shared with the stats consumer
@@ -257,21 +351,21 @@ int conv_tiles_m(int rows_per_frame, int Cout, int frames) {
 }
 
 int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) {
-    PIPS_CHECK_ARG(a.Cin % BK == 0, "conv: Cin=%d must be a multiple of 32", a.Cin);
+    PIPS_CHECK_ARG(a.Cin % 32 == 0, "conv: Cin=%d must be a multiple of 32", a.Cin);
     PIPS_CHECK_ARG(a.N % 32 == 0 && (a.N % 64 == 0 || a.N % 96 == 0), "conv: unsupported Cout=%d", a.N);
     PIPS_CHECK_ARG(a.K == a.KH * a.KW * a.Cin, "conv: K mismatch");
     int bm, bn;
     conv_tile(a.M, a.N, frames, &bm, &bn);
     if (tiles_m) *tiles_m = cdiv(a.M, bm);
     if (bn == 128) {
-        return bm == 128 ? launch_tile<128, 128, 2, 2, true>(a, frames, st)
-                         : launch_tile<64, 128, 2, 2, true>(a, frames, st);
+        return bm == 128 ? launch_tile<128, 128, 2, 2, 1, true>(a, frames, st)
+                         : launch_tile<64, 128, 2, 2, 1, true>(a, frames, st);
     } else if (bn == 96) {
-        return bm == 128 ? launch_tile<128, 96, 4, 1, true>(a, frames, st)
-                         : launch_tile<64, 96, 2, 1, true>(a, frames, st);
+        return bm == 128 ? launch_tile<128, 96, 4, 1, 1, true>(a, frames, st)
+                         : launch_tile<64, 96, 2, 1, 1, true>(a, frames, st);
     }
-    return bm == 128 ? launch_tile<128, 64, 2, 2, true>(a, frames, st)
-                     : launch_tile<64, 64, 2, 2, true>(a, frames, st);
+    return bm == 128 ? launch_tile<128, 64, 2, 2, 1, true>(a, frames, st)
+                     : launch_tile<64, 64, 2, 2, 1, true>(a, frames, st);
 }
 
 }  // namespace pips

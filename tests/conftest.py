@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    from oracle.hostinfo import effective_cpus
+    torch.set_num_threads(effective_cpus())      # respect the cgroup CPU quota (CPU oracle speed)
 
 
 @pytest.fixture(scope="session")

@@ -37,7 +37,6 @@ def make_demo_frames():
 
 def main():
     assert R.available(), "reference not mounted at /root/reference"
-    torch.set_num_threads(os.cpu_count())
     make_demo_frames()
     keys = None
     for name, case in G.CASES.items():

@@ -92,7 +92,6 @@ def _config2_inputs(B=1, N=256, H=368, W=496, seed=1):
 def test_config2_against_oracle_tamed(weights_tamed):
     from oracle import pips_oracle as O
     xys, rgbs = _config2_inputs()
-    torch.set_num_threads(os.cpu_count())
     ref_p, ref_p2, ref_vis, ref_ff = O.forward(weights_tamed, xys, rgbs, iters=6, stride=8)
     preds, preds2, vis, ffeat, _ = _run(_model(weights_tamed, 8), xys, rgbs, iters=6)
     err = [float((a.cpu() - b).abs().max()) for a, b in zip(preds, ref_p)]
