@@ -10,7 +10,7 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpips_hip.so")
+LIB_PATH = os.environ.get("PIPS_LIB_PATH", os.path.join(HERE, "libpips_hip.so"))   # override: tuning builds only
 
 c_void_p, c_int, c_size_t, c_float = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 fp = c_void_p  # device float pointer

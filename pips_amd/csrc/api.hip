@@ -158,7 +158,7 @@ int pips_repack_weights(const void* const* params, int nparams, void* arena_v, v
 int pips_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N,
                   int K, int epi, const float* R, int ldr, void* stream) {
     PIPS_CHECK_ARG(A && W && C, "gemm: null pointer");
-    PIPS_CHECK_ARG(epi >= 0 && epi <= 2 && (epi != EPI_RESIDUAL || R != nullptr), "gemm: bad epilogue");
+    PIPS_CHECK_ARG((epi & 0xff) <= 2 && ((epi & 0xff) != EPI_RESIDUAL || R != nullptr), "gemm: bad epilogue");
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.W = W; g.bias = bias; g.C = C; g.R = R;

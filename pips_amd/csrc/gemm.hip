@@ -66,30 +66,37 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
     // loader coordinates: thread -> (row = tid/TPR + pass*ROWS_PER_PASS, 4 floats at cg*4).
     // Rows past M / N are clamped to a valid row instead of predicated: an output row
     // (column) depends only on its own A row (W row) and is never stored when out of range.
+    // Per-pass state lives in NAMED scalars (macro-expanded for passes 0..5), not arrays:
+    // with the compiler barrier that pins the prefetch, hipcc leaves arrays in scratch.
     const int lrow = tid / TPR, cg = tid % TPR;
-    int a_hi0[PA], a_wi0[PA];
-    unsigned a_off[PA];
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        int m = m0 + lrow + i * ROWS_PER_PASS;
-        m = m < p.M ? m : p.M - 1;
-        if (CONV) {
-            const int ho = m / p.Wo, wo = m - ho * p.Wo;
-            a_hi0[i] = ho * p.cstride - p.pad;
-            a_wi0[i] = wo * p.cstride - p.pad;
-            a_off[i] = 0;
-        } else {
-            a_hi0[i] = a_wi0[i] = 0;
-            a_off[i] = (unsigned)m * (unsigned)p.lda + cg * 4;
-        }
+    static_assert(PA <= 4 && PB <= 6, "extend the pass macros");
+#define PIPS_PASSES_A(X) X(0) X(1) X(2) X(3)
+#define PIPS_PASSES_B(X) X(0) X(1) X(2) X(3) X(4) X(5)
+#define PIPS_DECL_A(i) int a_hi##i = 0, a_wi##i = 0; unsigned a_off##i = 0; float4 ra##i = make_float4(0.f, 0.f, 0.f, 0.f);
+#define PIPS_DECL_B(i) unsigned b_off##i = 0; float4 rb##i = make_float4(0.f, 0.f, 0.f, 0.f);
+    PIPS_PASSES_A(PIPS_DECL_A)
+    PIPS_PASSES_B(PIPS_DECL_B)
+#define PIPS_INIT_A(i)                                                        \
+    if constexpr (i < PA) {                                                   \
+        int m_ = m0 + lrow + i * ROWS_PER_PASS;                               \
+        m_ = m_ < p.M ? m_ : p.M - 1;                                         \
+        if (CONV) {                                                           \
+            const int ho_ = m_ / p.Wo, wo_ = m_ - ho_ * p.Wo;                 \
+            a_hi##i = ho_ * p.cstride - p.pad;                                \
+            a_wi##i = wo_ * p.cstride - p.pad;                                \
+        } else {                                                              \
+            a_off##i = (unsigned)m_ * (unsigned)p.lda + cg * 4;               \
+        }                                                                     \
     }
-    unsigned b_off[PB];
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        int n = n0 + lrow + i * ROWS_PER_PASS;
-        n = n < p.N ? n : p.N - 1;
-        b_off[i] = (unsigned)n * (unsigned)p.K + cg * 4;
+#define PIPS_INIT_B(i)                                                        \
+    if constexpr (i < PB) {                                                   \
+        int n_ = n0 + lrow + i * ROWS_PER_PASS;                               \
+        n_ = n_ < p.N ? n_ : p.N - 1;                                         \
+        b_off##i = (unsigned)n_ * (unsigned)p.K + cg * 4;                     \
     }
+    PIPS_PASSES_A(PIPS_INIT_A)
+    PIPS_PASSES_B(PIPS_INIT_B)
+    (void)a_hi0; (void)a_wi0; (void)a_off0;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -99,9 +106,19 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[PA], rb[PB];
-
-    // (macros, not lambdas: by-reference lambda captures sent ra/rb to scratch memory)
+#define PIPS_LOADC_A(i)                                                                             \
+    if constexpr (i < PA) {                                                                         \
+        const int hi_ = a_hi##i + kh_, wi_ = a_wi##i + kw_;                                         \
+        const bool ok_ = (unsigned)hi_ < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.Win;          \
+        const int hc_ = ok_ ? hi_ : 0, wc_ = ok_ ? wi_ : 0;                                         \
+        const float4 v_ = *reinterpret_cast<const float4*>(                                         \
+            Abase + ((size_t)hc_ * p.Win + wc_) * p.Cin + c0_ + cg * 4);                            \
+        ra##i = ok_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                         \
+    }
+#define PIPS_LOADP_A(i) \
+    if constexpr (i < PA) ra##i = *reinterpret_cast<const float4*>(Abase + a_off##i + k0_);
+#define PIPS_LOAD_B(i) \
+    if constexpr (i < PB) rb##i = *reinterpret_cast<const float4*>(p.W + b_off##i + k0_);
 #define PIPS_LOAD_TILES(kb_)                                                                        \
     {                                                                                               \
         const int k0_ = (kb_) * BKB;                                                                \
@@ -110,29 +127,22 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
             const int tap_ = k0_ / p.Cin;                                                           \
             const int c0_ = k0_ - tap_ * p.Cin;                                                     \
             const int kh_ = tap_ / p.KW, kw_ = tap_ - kh_ * p.KW;                                   \
-            _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                        \
-                const int hi_ = a_hi0[i] + kh_, wi_ = a_wi0[i] + kw_;                               \
-                const bool ok_ = (unsigned)hi_ < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.Win;  \
-                const int hc_ = ok_ ? hi_ : 0, wc_ = ok_ ? wi_ : 0;                                 \
-                float4 v_ = *reinterpret_cast<const float4*>(                                       \
-                    Abase + ((size_t)hc_ * p.Win + wc_) * p.Cin + c0_ + cg * 4);                    \
-                ra[i] = ok_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                 \
-            }                                                                                       \
+            PIPS_PASSES_A(PIPS_LOADC_A)                                                             \
         } else {                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < PA; ++i)                                          \
-                ra[i] = *reinterpret_cast<const float4*>(Abase + a_off[i] + k0_);                   \
+            PIPS_PASSES_A(PIPS_LOADP_A)                                                             \
         }                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < PB; ++i)                                              \
-            rb[i] = *reinterpret_cast<const float4*>(p.W + b_off[i] + k0_);                         \
+        PIPS_PASSES_B(PIPS_LOAD_B)                                                                  \
     }
+#define PIPS_STORE_A(i) \
+    if constexpr (i < PA) *reinterpret_cast<float4*>(&As_[(lrow + i * ROWS_PER_PASS) * LD + cg * 4]) = ra##i;
+#define PIPS_STORE_B(i) \
+    if constexpr (i < PB) *reinterpret_cast<float4*>(&Bs_[(lrow + i * ROWS_PER_PASS) * LD + cg * 4]) = rb##i;
 #define PIPS_STORE_TILES(buf_)                                                                      \
     {                                                                                               \
         float* As_ = smem + (buf_) * STAGE;                                                         \
         float* Bs_ = As_ + BM * LD;                                                                 \
-        _Pragma("unroll") for (int i = 0; i < PA; ++i)                                              \
-            *reinterpret_cast<float4*>(&As_[(lrow + i * ROWS_PER_PASS) * LD + cg * 4]) = ra[i];     \
-        _Pragma("unroll") for (int i = 0; i < PB; ++i)                                              \
-            *reinterpret_cast<float4*>(&Bs_[(lrow + i * ROWS_PER_PASS) * LD + cg * 4]) = rb[i];     \
+        PIPS_PASSES_A(PIPS_STORE_A)                                                                 \
+        PIPS_PASSES_B(PIPS_STORE_B)                                                                 \
     }
 #define PIPS_FRAGS(dst_a, dst_b, kk_)                                                               \
     {                                                                                               \
@@ -177,16 +187,45 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
     PIPS_STORE_TILES(0);
     __syncthreads();
     int buf = 0;
+#ifdef PIPS_GEMM_ABLATE
+    const bool ab_ld = !(p.epi & 0x100), ab_st = !(p.epi & 0x200), ab_bar = !(p.epi & 0x400);
+    for (int kb = 0; kb + 1 < nk; ++kb) {
+        if (ab_ld) PIPS_LOAD_TILES(kb + 1);
+        asm volatile("" ::: "memory");
+        PIPS_COMPUTE(buf);
+        asm volatile("" ::: "memory");
+        if (ab_st) PIPS_STORE_TILES(buf ^ 1);
+        if (ab_bar) __syncthreads();
+        buf ^= 1;
+    }
+#else
     for (int kb = 0; kb + 1 < nk; ++kb) {
         PIPS_LOAD_TILES(kb + 1);
+        // keep the global loads ahead of the MFMA phase: left alone, the scheduler sinks them
+        // next to the ds_writes and exposes the full memory latency every iteration
+        // (a compiler memory barrier; __builtin_amdgcn_sched_barrier here leaves ra/rb in scratch)
+        asm volatile("" ::: "memory");
         PIPS_COMPUTE(buf);
+        asm volatile("" ::: "memory");
         PIPS_STORE_TILES(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
+#endif
     PIPS_COMPUTE(buf);
 #undef PIPS_LOAD_TILES
 #undef PIPS_STORE_TILES
+#undef PIPS_PASSES_A
+#undef PIPS_PASSES_B
+#undef PIPS_DECL_A
+#undef PIPS_DECL_B
+#undef PIPS_INIT_A
+#undef PIPS_INIT_B
+#undef PIPS_LOADC_A
+#undef PIPS_LOADP_A
+#undef PIPS_LOAD_B
+#undef PIPS_STORE_A
+#undef PIPS_STORE_B
 #undef PIPS_FRAGS
 #undef PIPS_MFMA4
 #undef PIPS_COMPUTE
@@ -235,8 +274,8 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
                 const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < p.M && col_ok) {
                     float v = acc[i][j][r] + bv;
-                    if (p.epi == EPI_GELU) v = gelu_erf(v);
-                    else if (p.epi == EPI_RESIDUAL) v += p.R[(size_t)row * p.ldr + col];
+                    if ((p.epi & 0xff) == EPI_GELU) v = gelu_erf(v);
+                    else if ((p.epi & 0xff) == EPI_RESIDUAL) v += p.R[(size_t)row * p.ldr + col];
                     Cbase[(size_t)row * p.ldc + col] = v;
                     csum[j] += v;
                     csq[j] += v * v;
