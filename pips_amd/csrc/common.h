@@ -39,6 +39,7 @@ struct GemmArgs {
     int M, N, K;
     int lda, ldc, ldr;
     int epi;
+    int swz;             // XCD-aware tile order (set by the launcher)
     // implicit-GEMM geometry (conv only); M = Ho*Wo rows per frame, gridDim.z = frames
     int H, Win, Cin, Ho, Wo, KH, KW, cstride, pad;
 };

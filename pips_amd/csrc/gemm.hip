@@ -53,7 +53,21 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
     const int wmn = wave - ks * (WGM * WGN);
     const int wm = wmn / WGN, wn = wmn % WGN;
     const int l31 = lane & 31, half = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs in linear
+    // id order, each XCD with a private 4 MiB L2.  Re-deal the (m,n) tiles of a frame so that
+    // every XCD owns one contiguous run of tiles (m fastest): a run shares W rows / conv halo
+    // rows inside one L2 instead of spreading every operand over all eight.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.swz) {
+        const int T = gridDim.x * gridDim.y;
+        const int id = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = id & 7, local = id >> 3;
+        const int q = T >> 3, r = T & 7;
+        const int nid = xcd * q + (xcd < r ? xcd : r) + local;      // bijective for any T
+        by = nid / gridDim.x;
+        bx = nid - by * gridDim.x;
+    }
+    const int m0 = bx * BM, n0 = by * BN;
     const int frame = blockIdx.z;
 
     const float* __restrict__ Abase = p.A;
@@ -151,20 +165,18 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
             dst_b[j] = *reinterpret_cast<const float4*>(b_frag + j * 32 * LD + (kk_) * 8);          \
     }
+// Plain GEMMs accumulate C^T (W fragment as the MFMA A operand): a lane then holds four
+// CONSECUTIVE output columns per register quad -> 16-byte bias/residual loads and C stores.
+// Convolutions keep C (column sums for the instance-norm statistics stay in-lane).
+#define PIPS_MFMA1(c_)                                                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
+                acc[i][j] = CONV ? __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i].c_, fb_[j].c_, acc[i][j], 0, 0, 0) \
+                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(fb_[j].c_, fa_[i].c_, acc[i][j], 0, 0, 0);
 #define PIPS_MFMA4(fa, fb)                                                                          \
     {                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0); \
+        const float4* fa_ = fa; const float4* fb_ = fb;                                             \
+        PIPS_MFMA1(x) PIPS_MFMA1(y) PIPS_MFMA1(z) PIPS_MFMA1(w)                                     \
     }
     // fragments of K sub-step kk+1 are read from LDS before the MFMAs of sub-step kk issue
 #define PIPS_COMPUTE(buf_)                                                                          \
@@ -227,6 +239,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
 #undef PIPS_STORE_A
 #undef PIPS_STORE_B
 #undef PIPS_FRAGS
+#undef PIPS_MFMA1
 #undef PIPS_MFMA4
 #undef PIPS_COMPUTE
 
@@ -261,6 +274,51 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
     float csum[TN], csq[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
+    const int epi = p.epi & 0xff;
+
+    if (!CONV) {
+        // transposed accumulators: MFMA row index = output column n, MFMA column = output row m
+        const bool vec_ok = (p.ldc & 3) == 0 && (epi != EPI_RESIDUAL || (p.ldr & 3) == 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * WTM + i * 32 + l31;
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + wn * WTN + j * 32 + 8 * g + 4 * half;
+                    if (col >= p.N) continue;
+                    float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    if (vec_ok && col + 3 < p.N) {
+                        if (p.bias != nullptr) {
+                            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col);
+                            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                        }
+                        if (epi == EPI_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        } else if (epi == EPI_RESIDUAL) {
+                            const float4 r4 = *reinterpret_cast<const float4*>(p.R + (size_t)row * p.ldr + col);
+                            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                        }
+                        *reinterpret_cast<float4*>(Cbase + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (col + e < p.N) {
+                                float t = v[e] + (p.bias != nullptr ? p.bias[col + e] : 0.f);
+                                if (epi == EPI_GELU) t = gelu_erf(t);
+                                else if (epi == EPI_RESIDUAL) t += p.R[(size_t)row * p.ldr + col + e];
+                                Cbase[(size_t)row * p.ldc + col + e] = t;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
 
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -273,9 +331,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < p.M && col_ok) {
-                    float v = acc[i][j][r] + bv;
-                    if ((p.epi & 0xff) == EPI_GELU) v = gelu_erf(v);
-                    else if ((p.epi & 0xff) == EPI_RESIDUAL) v += p.R[(size_t)row * p.ldr + col];
+                    const float v = acc[i][j][r] + bv;
                     Cbase[(size_t)row * p.ldc + col] = v;
                     csum[j] += v;
                     csq[j] += v * v;
@@ -309,7 +365,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
             }
             const int col = n0 + c;
             if (col < p.N) {
-                float* dst = p.stats + (((size_t)frame * gridDim.x + blockIdx.x) * p.N + col) * 2;
+                float* dst = p.stats + (((size_t)frame * gridDim.x + bx) * p.N + col) * 2;
                 dst[0] = s;
                 dst[1] = q;
             }
@@ -317,11 +373,22 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
     }
 }
 
+static int swizzle_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PIPS_GEMM_SWZ");
+        v = e ? (atoi(e) != 0) : 0;     // measured neutral on MI355X at the mixer/encoder sizes: off
+    }
+    return v;
+}
+
 template <int BM, int BN, int WGM, int WGN, int KS, bool CONV>
-static int launch_tile(const GemmArgs& a, int frames, hipStream_t st) {
+static int launch_tile(const GemmArgs& a_in, int frames, hipStream_t st) {
     static_assert(!CONV || KS == 1, "conv statistics assume KS == 1");
+    GemmArgs a = a_in;
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), frames);
     dim3 block(WGM * WGN * KS * 64);
+    a.swz = swizzle_on() && (grid.x * grid.y >= 16);
     size_t lds = (size_t)2 * (BM + BN) * (32 * KS + 4) * sizeof(float);
     auto kern = igemm_f32_kernel<BM, BN, WGM, WGN, KS, CONV>;
     if (lds > 64 * 1024) {
