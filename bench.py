@@ -81,27 +81,16 @@ def stage_profile(model, xys, rgbs, device):
     out["state_update"] = ev_time_ms(
         lambda: ops.state_update(arena, delta, ffeats, coords, c0, B_PER_GPU, NPTS, float(STRIDE)), 10) * ITERS
 
-    # dominant kernel: the channel-mix GEMMs (igemm_f32_kernel), cycling over the 12 layers' weights
-    # arena offsets are not exported; time on standalone weights of the real shapes instead
-    w1 = [torch.randn(2048, 512, generator=g).to(device) / 22.6 for _ in range(MIX_DEPTH)]
-    w2 = [torch.randn(512, 2048, generator=g).to(device) / 45.3 for _ in range(MIX_DEPTH)]
-    b1 = torch.zeros(2048, device=device)
-    b2 = torch.zeros(512, device=device)
-    xn = torch.randn(M, 512, generator=g).to(device)
-    hbuf = torch.randn(M, 2048, generator=g).to(device)
-    res = torch.randn(M, 512, generator=g).to(device)
-    ops.gemm(xn, w1[0], b1, 1)
-    ops.gemm(hbuf, w2[0], b2, 2, res)
-
-    def up():
-        for d in range(MIX_DEPTH):
-            ops.gemm(xn, w1[d], b1, 1)
-
-    def down():
-        for d in range(MIX_DEPTH):
-            ops.gemm(hbuf, w2[d], b2, 2, res)
-    t_up = ev_time_ms(up, 5) / MIX_DEPTH
-    t_down = ev_time_ms(down, 5) / MIX_DEPTH
+    # dominant kernel: the channel-mix GEMMs (igemm_f32_kernel), timed IN SITU: a real mixer pass
+    # on the real weights/activations with a HIP event pair around every GEMM launch on the
+    # launch stream (pips_mixer_fwd_timed); mean over the 12 layers and 5 passes.
+    ups, downs = [], []
+    for _ in range(5):
+        _, t = ops.mixer_fwd_timed(arena, X)
+        ups.append(t["up_proj"])
+        downs.append(t["down_proj"])
+    t_up = sum(ups) / len(ups)
+    t_down = sum(downs) / len(downs)
     flops = 2.0 * M * 2048 * 512
     kern = {
         "up_proj(M=%d,N=2048,K=512)" % M: {"ms": t_up, "tflops": flops / t_up / 1e9},

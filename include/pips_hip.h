@@ -111,6 +111,13 @@ size_t pips_mixer_workspace_bytes(int M);
 int    pips_mixer_fwd(const void* arena, const float* X, int M, float* delta,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Profiling variant (the ONLY entry point that creates events and synchronises): same work as
+ * pips_mixer_fwd with a hipEvent pair around every GEMM launch on `stream`; ms_host[4] receives
+ * {in-proj, mean of the 12 up-projections (512->2048 +GELU), mean of the 12 down-projections
+ * (2048->512 +residual), head} in milliseconds.  Used by bench.py for the roofline object. */
+int    pips_mixer_fwd_timed(const void* arena, const float* X, int M, float* delta,
+                            void* workspace, size_t workspace_bytes, void* stream, float* ms_host);
+
 /* State update nets/pips.py:525-539 (+ vis head :559 when out_vis != NULL).
  * delta (B*N,1040); ffeats/coords updated in place; coords0 = locked frame-0 coords;
  * out_traj (B,S,N,2) receives coords*stride. */

@@ -387,8 +387,9 @@ size_t pips_mixer_workspace_bytes(int M) {
     return b.off * sizeof(float);
 }
 
-int pips_mixer_fwd(const void* arena_v, const float* X, int M, float* delta, void* workspace, size_t workspace_bytes,
-                   void* stream) {
+// ev != nullptr: record ev[2g], ev[2g+1] around GEMM g (g = 0 in-proj, 1+2d up, 2+2d down, 25 head)
+static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, void* workspace,
+                      size_t workspace_bytes, void* stream, hipEvent_t* ev) {
     PIPS_CHECK_ARG(arena_v && X && delta && workspace, "mixer: null pointer");
     PIPS_CHECK_ARG(M > 0 && M % PIPS_S == 0, "mixer: M=%d must be a positive multiple of %d", M, PIPS_S);
     if (workspace_bytes < pips_mixer_workspace_bytes(M)) {
@@ -405,21 +406,59 @@ int pips_mixer_fwd(const void* arena_v, const float* X, int M, float* delta, voi
     float* h = ws + b.take((size_t)M * 4 * PIPS_DMIX);
     float* pooled = ws + b.take((size_t)(M / PIPS_S) * PIPS_DMIX);
     const int P = M / PIPS_S;
+    int g = 0;
+#define TIMED(call)                                                        \
+    do {                                                                   \
+        if (ev) (void)hipEventRecord(ev[2 * g], st);                       \
+        RUN(call);                                                         \
+        if (ev) (void)hipEventRecord(ev[2 * g + 1], st);                   \
+        ++g;                                                               \
+    } while (0)
 
-    RUN(pips_gemm_f32(X, PIPS_KIN_PAD, arena + A.w_in, arena + A.b_in, x, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
-                      EPI_BIAS, nullptr, 0, stream));
+    TIMED(pips_gemm_f32(X, PIPS_KIN_PAD, arena + A.w_in, arena + A.b_in, x, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
+                        EPI_BIAS, nullptr, 0, stream));
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
         RUN(launch_token_mix(arena, L, x, xn, P, st));
-        RUN(pips_gemm_f32(xn, PIPS_DMIX, arena + L.w1, arena + L.b1, h, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX, PIPS_DMIX,
-                          EPI_GELU, nullptr, 0, stream));
-        RUN(pips_gemm_f32(h, 4 * PIPS_DMIX, arena + L.w2, arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
-                          EPI_RESIDUAL, x, PIPS_DMIX, stream));
+        TIMED(pips_gemm_f32(xn, PIPS_DMIX, arena + L.w1, arena + L.b1, h, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX, PIPS_DMIX,
+                            EPI_GELU, nullptr, 0, stream));
+        TIMED(pips_gemm_f32(h, 4 * PIPS_DMIX, arena + L.w2, arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
+                            EPI_RESIDUAL, x, PIPS_DMIX, stream));
     }
     RUN(launch_ln_mean(x, arena + A.lnf_g, arena + A.lnf_b, pooled, P, st));
-    RUN(pips_gemm_f32(pooled, PIPS_DMIX, arena + A.w_head, arena + A.b_head, delta, PIPS_NOUT, P, PIPS_NOUT, PIPS_DMIX,
-                      EPI_BIAS, nullptr, 0, stream));
+    TIMED(pips_gemm_f32(pooled, PIPS_DMIX, arena + A.w_head, arena + A.b_head, delta, PIPS_NOUT, P, PIPS_NOUT,
+                        PIPS_DMIX, EPI_BIAS, nullptr, 0, stream));
+#undef TIMED
     return PIPS_OK;
+}
+
+int pips_mixer_fwd(const void* arena_v, const float* X, int M, float* delta, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+    return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr);
+}
+
+int pips_mixer_fwd_timed(const void* arena_v, const float* X, int M, float* delta, void* workspace,
+                         size_t workspace_bytes, void* stream, float* ms_host) {
+    PIPS_CHECK_ARG(ms_host != nullptr, "mixer_timed: null output");
+    constexpr int NG = 2 * PIPS_DEPTH + 2;
+    hipEvent_t ev[2 * NG];
+    for (int i = 0; i < 2 * NG; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) { set_error("hipEventCreate failed"); return PIPS_E_LAUNCH; }
+    int rc = mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, ev);
+    if (rc == PIPS_OK && hipEventSynchronize(ev[2 * NG - 1]) != hipSuccess) rc = PIPS_E_LAUNCH;
+    if (rc == PIPS_OK) {
+        float up = 0.f, down = 0.f, t = 0.f;
+        (void)hipEventElapsedTime(&ms_host[0], ev[0], ev[1]);
+        for (int d = 0; d < PIPS_DEPTH; ++d) {
+            (void)hipEventElapsedTime(&t, ev[2 * (1 + 2 * d)], ev[2 * (1 + 2 * d) + 1]); up += t;
+            (void)hipEventElapsedTime(&t, ev[2 * (2 + 2 * d)], ev[2 * (2 + 2 * d) + 1]); down += t;
+        }
+        ms_host[1] = up / PIPS_DEPTH;
+        ms_host[2] = down / PIPS_DEPTH;
+        (void)hipEventElapsedTime(&ms_host[3], ev[2 * (NG - 1)], ev[2 * (NG - 1) + 1]);
+    }
+    for (int i = 0; i < 2 * NG; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }
 
 int pips_state_update(const void* arena, const float* delta, float* ffeats, float* coords, const float* coords0,

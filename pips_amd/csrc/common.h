@@ -23,6 +23,36 @@ void set_error(const char* fmt, ...);
         }                                                                           \
     } while (0)
 
+// ---------------------------------------------------------------- exact-form GELU
+// nn.GELU() default = 0.5*x*(1+erf(x/sqrt(2))) (nets/pips.py:105,419).  erf is a branch-free
+// fp32 minimax pair fitted for this path (tools: see DESIGN.md): |x| <= 0.875: x*P5(x^2);
+// otherwise sign(x)*(1 - exp(-t*Q7(t))), t = min(|x|, 4) (erf(4) rounds to 1.0f).  Max abs
+// error 1.2e-7 (~2 ulp at 1.0), below the 4.5e-7 the fp32 formula itself carries; ~22
+// instructions against ~40 for OCML's erff, which matters in the 64-values-per-lane epilogues.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float t = fminf(fabsf(x), 4.0f);
+    const float u = x * x;
+    float p = -6.218503113e-04f;
+    p = fmaf(p, u, 5.035122391e-03f);
+    p = fmaf(p, u, -2.679345198e-02f);
+    p = fmaf(p, u, 1.128251031e-01f);
+    p = fmaf(p, u, -3.761255443e-01f);
+    p = fmaf(p, u, 1.128379107e+00f);
+    float q = -8.686167803e-07f;
+    q = fmaf(q, t, 3.125615694e-05f);
+    q = fmaf(q, t, -4.758332507e-04f);
+    q = fmaf(q, t, 4.213109612e-03f);
+    q = fmaf(q, t, -2.493269742e-02f);
+    q = fmaf(q, t, 1.075836346e-01f);
+    q = fmaf(q, t, 6.343385577e-01f);
+    q = fmaf(q, t, 1.128848195e+00f);
+    const float big = copysignf(1.0f - __expf(-q * t), x);
+    return t > 0.875f ? big : x * p;
+}
+__device__ __forceinline__ float gelu_exact(float x) {
+    return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -41,11 +41,15 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
             const int hi = hi0 + kh;
             const bool hok = ok && (unsigned)hi < (unsigned)H;
             const float* row = src + ((size_t)ci * H + (hok ? hi : 0)) * W;
+            // unconditional (clamped) loads of the 7 taps first, select the zero padding after:
+            // a branch per tap would serialise the loads behind their own FMAs
+            float xr[7];
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) xr[kw] = row[min(max(wi0 + kw, 0), W - 1)];
 #pragma unroll
             for (int kw = 0; kw < 7; ++kw) {
                 const int wi = wi0 + kw;
-                float x = 0.f;
-                if (hok && (unsigned)wi < (unsigned)W) x = 2.0f * (row[wi] / 255.0f) - 1.0f;
+                const float x = (hok && (unsigned)wi < (unsigned)W) ? 2.0f * (xr[kw] / 255.0f) - 1.0f : 0.f;
                 const float* wk = wv + ((ci * 7 + kh) * 7 + kw) * 64;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) acc[c] = fmaf(x, wk[c], acc[c]);

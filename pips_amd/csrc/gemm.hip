@@ -25,10 +25,6 @@ namespace pips {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float gelu_erf(float x) {
-    // nn.GELU() default = exact erf form (nets/pips.py:105)
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
 
 template <int BM, int BN, int WGM, int WGN, int KS, bool CONV>
 __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs p) {
@@ -297,7 +293,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
                         }
                         if (epi == EPI_GELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
                         } else if (epi == EPI_RESIDUAL) {
                             const float4 r4 = *reinterpret_cast<const float4*>(p.R + (size_t)row * p.ldr + col);
                             v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
@@ -308,7 +304,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
                         for (int e = 0; e < 4; ++e) {
                             if (col + e < p.N) {
                                 float t = v[e] + (p.bias != nullptr ? p.bias[col + e] : 0.f);
-                                if (epi == EPI_GELU) t = gelu_erf(t);
+                                if (epi == EPI_GELU) t = gelu_exact(t);
                                 else if (epi == EPI_RESIDUAL) t += p.R[(size_t)row * p.ldr + col + e];
                                 Cbase[(size_t)row * p.ldc + col + e] = t;
                             }

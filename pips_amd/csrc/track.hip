@@ -10,9 +10,6 @@ namespace pips {
 constexpr int S = PIPS_S;
 constexpr int C = PIPS_C;
 
-__device__ __forceinline__ float gelu_erf_t(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
 
 // ------------------------------------------------------------------------ point sample
 // utils.samp.bilinear_sample2d (utils/samp.py:5-78) on frame 0 of each clip: neighbour
@@ -117,7 +114,9 @@ struct LevelTable {
     int H[PIPS_LEVELS], W[PIPS_LEVELS];
 };
 
-__global__ __launch_bounds__(256) void mixer_input_kernel(const float* __restrict__ pyramid,
+// waves_per_eu(2,4): let the compiler spend up to 128 VGPRs so 16 x 1 KiB loads stay in flight per
+// wave (left alone it squeezes into 64 VGPRs for 8 waves/SIMD and issues the loads two at a time)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void mixer_input_kernel(const float* __restrict__ pyramid,
                                                           LevelTable lv, int S_,
                                                           const float* __restrict__ ffeats,
                                                           const float* __restrict__ coords,
@@ -152,33 +151,47 @@ __global__ __launch_bounds__(256) void mixer_input_kernel(const float* __restric
         const int hsel = lane >> 5, c4 = lane & 31;
         const float4 f4 = *reinterpret_cast<const float4*>(ff + c4 * 4);
         const float* base = pyramid + lv.off[lvl] + (size_t)frame * H * W * C + c4 * 4;
+        // Loads are UNCONDITIONAL (out-of-map pixels read a clamped in-map address and are
+        // zeroed afterwards): a branch per load would fence each load behind its own use and
+        // serialise 32 L2 round trips per wave.  Two batches of 16 x 1 KiB loads in flight.
         float v[32];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int py = by + j;
-            const bool yok = (unsigned)py < (unsigned)H;
+        for (int hb = 0; hb < 2; ++hb) {
+            float4 t[16];
+            bool ok[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int px = bx + 2 * q + hsel;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (yok && (unsigned)px < (unsigned)W)
-                    t = *reinterpret_cast<const float4*>(base + ((size_t)py * W + px) * C);
-                v[j * 4 + q] = t.x * f4.x + t.y * f4.y + t.z * f4.z + t.w * f4.w;
+            for (int jj = 0; jj < 4; ++jj) {
+                const int py = by + hb * 4 + jj;
+                const bool yok = (unsigned)py < (unsigned)H;
+                const int pyc = min(max(py, 0), H - 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int px = bx + 2 * q + hsel;
+                    ok[jj * 4 + q] = yok && (unsigned)px < (unsigned)W;
+                    const int pxc = min(max(px, 0), W - 1);
+                    t[jj * 4 + q] = *reinterpret_cast<const float4*>(base + ((size_t)pyc * W + pxc) * C);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float d = t[e].x * f4.x + t[e].y * f4.y + t[e].z * f4.z + t[e].w * f4.w;
+                v[hb * 16 + e] = ok[e] ? d : 0.f;
             }
         }
         // transpose-reduce over the 32 lanes of each half: lane r ends with sum of v[r]
-#pragma unroll
-        for (int o = 16, n = 32; o >= 1; o >>= 1, n >>= 1) {
-            const bool up = (lane & o) != 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k < n / 2) {
-                    const float send = up ? v[k] : v[k + n / 2];
-                    const float keep = up ? v[k + n / 2] : v[k];
-                    v[k] = keep + __shfl_xor(send, o);
-                }
-            }
+        // (one macro instance per level: a two-variable loop here was left rolled by hipcc and
+        // v[] became a 4000-instruction compare/select emulation of dynamic register indexing)
+#define PIPS_TR_STEP(O, NH)                                                    \
+        {                                                                      \
+            const bool up = (lane & (O)) != 0;                                 \
+            _Pragma("unroll") for (int k = 0; k < (NH); ++k) {                 \
+                const float send = up ? v[k] : v[k + (NH)];                    \
+                const float keep = up ? v[k + (NH)] : v[k];                    \
+                v[k] = keep + __shfl_xor(send, (O));                           \
+            }                                                                  \
         }
+        PIPS_TR_STEP(16, 16) PIPS_TR_STEP(8, 8) PIPS_TR_STEP(4, 4) PIPS_TR_STEP(2, 2) PIPS_TR_STEP(1, 1)
+#undef PIPS_TR_STEP
         // lane (hsel, r=c4): window row j = r>>2, column 2*(r&3) + hsel
         const float scale = sqrtf((float)C);
         Dw[lvl][(c4 >> 2) * 8 + 2 * (c4 & 3) + hsel] = v[0] / scale;     // corrs / sqrt(C) (:397)
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
         float u0 = wsm[256 + j], u1 = u0;
 #pragma unroll
         for (int t = 0; t < S; ++t) { u0 = fmaf(wsm[j * 8 + t], h0[t], u0); u1 = fmaf(wsm[j * 8 + t], h1[t], u1); }
-        u0 = gelu_erf_t(u0); u1 = gelu_erf_t(u1);
+        u0 = gelu_exact(u0); u1 = gelu_exact(u1);
 #pragma unroll
         for (int t = 0; t < S; ++t) { y0[t] = fmaf(wsm[288 + t * 32 + j], u0, y0[t]); y1[t] = fmaf(wsm[288 + t * 32 + j], u1, y1[t]); }
     }
@@ -415,7 +428,7 @@ __global__ __launch_bounds__(256) void state_update_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float* fp = ffeats + ((size_t)pn * S + r0 + r) * C + o;
-        const float nf = gelu_erf_t(acc[r]) + *fp;
+        const float nf = gelu_exact(acc[r]) + *fp;
         *fp = nf;
         vis_part[r] = nf * wv;
     }

@@ -116,6 +116,22 @@ def mixer_fwd(arena, X):
     return delta
 
 
+def mixer_fwd_timed(arena, X):
+    """Profiling: one mixer pass with HIP events around every GEMM launch.
+    Returns (delta, {in_proj, up_proj, down_proj, head} milliseconds per launch)."""
+    lib = _lib.load()
+    X = _f32(X)
+    M = X.shape[0]
+    delta = torch.empty(M // S, NOUT, dtype=torch.float32, device=X.device)
+    nb = lib.pips_mixer_workspace_bytes(M)
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
+    ms = (C.c_float * 4)()
+    with torch.cuda.device(X.device):
+        _lib.check(lib.pips_mixer_fwd_timed(_lib.ptr(arena), _lib.ptr(X), M, _lib.ptr(delta), _lib.ptr(ws), nb,
+                                            _stream(), ms), "pips_mixer_fwd_timed")
+    return delta, {"in_proj": ms[0], "up_proj": ms[1], "down_proj": ms[2], "head": ms[3]}
+
+
 def state_update(arena, delta, ffeats, coords, coords0, B, N, stride, want_vis=False):
     """In-place update of ffeats/coords (particle-major); returns (traj (B,S,N,2) px, vis or None)."""
     lib = _lib.load()
