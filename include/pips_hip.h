@@ -112,9 +112,10 @@ int    pips_mixer_fwd(const void* arena, const float* X, int M, float* delta,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Profiling variant (the ONLY entry point that creates events and synchronises): same work as
- * pips_mixer_fwd with a hipEvent pair around every GEMM launch on `stream`; ms_host[4] receives
+ * pips_mixer_fwd with a hipEvent pair around every GEMM launch on `stream`; ms_host[5] receives
  * {in-proj, mean of the 12 up-projections (512->2048 +GELU), mean of the 12 down-projections
- * (2048->512 +residual), head} in milliseconds.  Used by bench.py for the roofline object. */
+ * (2048->512 +residual), head, marker-pair overhead (empty event pair)} in milliseconds, the
+ * first four RAW (not overhead-corrected).  Used by bench.py for the roofline object. */
 int    pips_mixer_fwd_timed(const void* arena, const float* X, int M, float* delta,
                             void* workspace, size_t workspace_bytes, void* stream, float* ms_host);
 

@@ -441,13 +441,20 @@ int pips_mixer_fwd_timed(const void* arena_v, const float* X, int M, float* delt
                          size_t workspace_bytes, void* stream, float* ms_host) {
     PIPS_CHECK_ARG(ms_host != nullptr, "mixer_timed: null output");
     constexpr int NG = 2 * PIPS_DEPTH + 2;
-    hipEvent_t ev[2 * NG];
+    constexpr int NCAL = 8;                      // empty event pairs: the marker-to-marker overhead
+    hipEvent_t ev[2 * NG], cal[2 * NCAL];
     for (int i = 0; i < 2 * NG; ++i)
         if (hipEventCreate(&ev[i]) != hipSuccess) { set_error("hipEventCreate failed"); return PIPS_E_LAUNCH; }
+    for (int i = 0; i < 2 * NCAL; ++i)
+        if (hipEventCreate(&cal[i]) != hipSuccess) { set_error("hipEventCreate failed"); return PIPS_E_LAUNCH; }
+    hipStream_t st = (hipStream_t)stream;
     int rc = mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, ev);
-    if (rc == PIPS_OK && hipEventSynchronize(ev[2 * NG - 1]) != hipSuccess) rc = PIPS_E_LAUNCH;
+    for (int i = 0; i < 2 * NCAL; ++i) (void)hipEventRecord(cal[i], st);
+    if (rc == PIPS_OK && hipEventSynchronize(cal[2 * NCAL - 1]) != hipSuccess) rc = PIPS_E_LAUNCH;
     if (rc == PIPS_OK) {
-        float up = 0.f, down = 0.f, t = 0.f;
+        float up = 0.f, down = 0.f, t = 0.f, ovh = 0.f;
+        for (int i = 0; i < NCAL; ++i) { (void)hipEventElapsedTime(&t, cal[2 * i], cal[2 * i + 1]); ovh += t; }
+        ovh /= NCAL;
         (void)hipEventElapsedTime(&ms_host[0], ev[0], ev[1]);
         for (int d = 0; d < PIPS_DEPTH; ++d) {
             (void)hipEventElapsedTime(&t, ev[2 * (1 + 2 * d)], ev[2 * (1 + 2 * d) + 1]); up += t;
@@ -456,8 +463,10 @@ int pips_mixer_fwd_timed(const void* arena_v, const float* X, int M, float* delt
         ms_host[1] = up / PIPS_DEPTH;
         ms_host[2] = down / PIPS_DEPTH;
         (void)hipEventElapsedTime(&ms_host[3], ev[2 * (NG - 1)], ev[2 * (NG - 1) + 1]);
+        ms_host[4] = ovh;
     }
     for (int i = 0; i < 2 * NG; ++i) (void)hipEventDestroy(ev[i]);
+    for (int i = 0; i < 2 * NCAL; ++i) (void)hipEventDestroy(cal[i]);
     return rc;
 }
 

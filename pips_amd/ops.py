@@ -125,11 +125,11 @@ def mixer_fwd_timed(arena, X):
     delta = torch.empty(M // S, NOUT, dtype=torch.float32, device=X.device)
     nb = lib.pips_mixer_workspace_bytes(M)
     ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
-    ms = (C.c_float * 4)()
+    ms = (C.c_float * 5)()
     with torch.cuda.device(X.device):
         _lib.check(lib.pips_mixer_fwd_timed(_lib.ptr(arena), _lib.ptr(X), M, _lib.ptr(delta), _lib.ptr(ws), nb,
                                             _stream(), ms), "pips_mixer_fwd_timed")
-    return delta, {"in_proj": ms[0], "up_proj": ms[1], "down_proj": ms[2], "head": ms[3]}
+    return delta, {"in_proj": ms[0], "up_proj": ms[1], "down_proj": ms[2], "head": ms[3], "event_overhead": ms[4]}
 
 
 def state_update(arena, delta, ffeats, coords, coords0, B, N, stride, want_vis=False):
