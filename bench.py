@@ -206,9 +206,19 @@ def main():
     if rank == 0 and not args.no_stage_profile:
         stages, kern, gather = stage_profile(model, xys, rgbs, device)
         dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
+        # HBM-side bytes per launch of that kernel from the committed PMC passes (separate rocprofv3
+        # --pmc FETCH_SIZE / WRITE_SIZE runs of this command; profiles/r1_pmc_traffic.json)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
+            key = "pips::igemm_f32_kernel<64, 64, 2, 2, 1, false>" if dom[0].startswith("up") else \
+                "pips::igemm_f32_kernel<64, 64, 2, 2, 2, false>"
+            traffic = pmc[key]["hbm_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         # both GEMM shapes run the same kernel template; report the slower (dominant) launch
         res["roofline"] = {"bound": "mfma", "achieved": dom[1]["tflops"], "peak": PEAK_F32_MFMA_TF,
-                           "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_F32_MFMA_TF, "traffic": None,
+                           "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_F32_MFMA_TF, "traffic": traffic,
                            "kernel": "igemm_f32_kernel " + dom[0], "launch_ms": dom[1]["ms"],
                            "timing": "HIP event pair around each in-situ launch, empty-pair overhead subtracted",
                            "all": kern}
