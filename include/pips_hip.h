@@ -82,6 +82,23 @@ int    pips_forward(const void* arena, const float* rgbs, const float* xys,
                     void* workspace, size_t workspace_bytes,
                     float* out_trajs, float* out_vis, float* out_ffeat0, void* stream);
 
+/* ---- tracker on cached maps ------------------------------------------------------------
+ * Replaces: Pips.forward minus the encoder, for callers that re-run the tracker on maps they
+ * already have: the dense-grid loop of test_on_davis.py:103-130 (one encoder pass, many query
+ * chunks) and the visibility-aware chaining of chain_demo.py:40-83 / test_on_badja.py:64-112
+ * (one encoder pass per video frame instead of per particle and hop).
+ *   pyramid    packed 4-level channel-last maps of B clips x T frames (pips_encoder_fwd with
+ *              F = B*T; per-frame InstanceNorm makes a frame's maps independent of its clip)
+ *   win_start  (B*N) int32 first frame of each particle's 8-frame window, or NULL (= 0);
+ *              frames past T-1 repeat frame T-1 (chain_demo.py:50-52)
+ * All other arguments as pips_forward.  T = 8 and win_start = NULL is exactly the forward. */
+size_t pips_track_workspace_bytes(int B, int N);
+int    pips_track(const void* arena, const float* pyramid, int B, int T, int H8, int W8,
+                  const float* xys, const float* coords_init, const float* feat_init,
+                  const int* win_start, const float* times, int N, int stride, int iters,
+                  void* workspace, size_t workspace_bytes,
+                  float* out_trajs, float* out_vis, float* out_ffeat0, void* stream);
+
 /* ---- stages (same kernels, exposed for parity tests and for callers that cache maps) --*/
 
 /* BasicEncoder.forward (nets/pips.py:247-281) incl. the 2*(x/255)-1 of :436 and

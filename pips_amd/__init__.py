@@ -4,7 +4,7 @@
 (reference nets/pips.py:400-611); all arithmetic runs in libpips_hip.so behind the C ABI
 declared in include/pips_hip.h.
 """
-from .pips import Pips  # noqa: F401
+from .pips import Pips, FeatureCache  # noqa: F401
 from ._lib import PipsHipError  # noqa: F401
 
-__all__ = ["Pips", "PipsHipError"]
+__all__ = ["Pips", "FeatureCache", "PipsHipError"]

@@ -24,6 +24,9 @@ SIGNATURES = {
     "pips_workspace_bytes": (c_size_t, [c_int] * 6),
     "pips_forward": (c_int, [c_void_p, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_void_p, c_size_t, fp, fp, fp, c_void_p]),
+    "pips_track_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pips_track": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p, fp, c_int, c_int, c_int,
+                           c_void_p, c_size_t, fp, fp, fp, c_void_p]),
     "pips_encoder_workspace_bytes": (c_size_t, [c_int] * 4),
     "pips_pyramid_floats": (c_size_t, [c_int] * 4),
     "pips_pyramid_offset": (c_size_t, [c_int] * 5),

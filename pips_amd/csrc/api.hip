@@ -358,7 +358,7 @@ int pips_point_sample(const float* level0, int B, int S, int H8, int W8, const f
 }
 
 static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats, const float* coords,
-                       const float* times, int N, float* X, hipStream_t st) {
+                       const float* times, int N, const int* win_start, float* X, hipStream_t st) {
     size_t off[PIPS_LEVELS];
     int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
     lh[0] = H8; lw[0] = W8;
@@ -369,14 +369,14 @@ static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const
         o += ((size_t)B * S * lh[l] * lw[l] * PIPS_C + 63) / 64 * 64;
     }
     PIPS_CHECK_ARG(lh[PIPS_LEVELS - 1] >= 1 && lw[PIPS_LEVELS - 1] >= 1, "mixer_input: map too small");
-    return launch_mixer_input(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, st);
+    return launch_mixer_input(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, win_start, X, st);
 }
 
 int pips_mixer_input_build(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats,
                            const float* coords, const float* times, int N, float* X, void* stream) {
     PIPS_CHECK_ARG(pyramid && ffeats && coords && times && X, "mixer_input: null pointer");
-    PIPS_CHECK_ARG(S == PIPS_S && B > 0 && N > 0, "mixer_input: S must be %d", PIPS_S);
-    return mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, X, (hipStream_t)stream);
+    PIPS_CHECK_ARG(S >= 1 && B > 0 && N > 0, "mixer_input: empty problem");
+    return mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, nullptr, X, (hipStream_t)stream);
 }
 
 size_t pips_mixer_workspace_bytes(int M) {
@@ -478,17 +478,13 @@ int pips_state_update(const void* arena, const float* delta, float* ffeats, floa
                                (hipStream_t)stream);
 }
 
-// ------------------------------------------------------------------ whole forward
+// ------------------------------------------------------------------ tracker driver / whole forward
 namespace {
-struct FwdPlan {
-    size_t pyramid, enc, coords, coords0, ffeats, ffeat0, X, delta, mixer, total;   // floats
-};
-FwdPlan plan_forward(int B, int S, int H, int W, int N, int stride) {
-    FwdPlan P;
+struct TrackPlan { size_t coords, coords0, ffeats, ffeat0, X, delta, mixer, total; };   // floats
+TrackPlan plan_track(int B, int N) {
+    TrackPlan P;
     Bump b;
-    const int F = B * S, M = B * N * S;
-    P.pyramid = b.take(pips_pyramid_floats(F, H, W, stride));
-    P.enc = b.take(pips_encoder_workspace_bytes(F, H, W, stride) / sizeof(float));
+    const int M = B * N * PIPS_S;
     P.coords = b.take((size_t)M * 2);
     P.coords0 = b.take((size_t)M * 2);
     P.ffeats = b.take((size_t)M * PIPS_C);
@@ -499,7 +495,59 @@ FwdPlan plan_forward(int B, int S, int H, int W, int N, int stride) {
     P.total = b.off;
     return P;
 }
+struct FwdPlan { size_t pyramid, enc, track, total; };   // floats
+FwdPlan plan_forward(int B, int S, int H, int W, int N, int stride) {
+    FwdPlan P;
+    Bump b;
+    const int F = B * S;
+    P.pyramid = b.take(pips_pyramid_floats(F, H, W, stride));
+    P.enc = b.take(pips_encoder_workspace_bytes(F, H, W, stride) / sizeof(float));
+    P.track = b.take(plan_track(B, N).total);
+    P.total = b.off;
+    return P;
+}
 }  // namespace
+
+size_t pips_track_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return plan_track(B, N).total * sizeof(float);
+}
+
+int pips_track(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
+               const float* coords_init, const float* feat_init, const int* win_start, const float* times, int N,
+               int stride, int iters, void* workspace, size_t workspace_bytes, float* out_trajs, float* out_vis,
+               float* out_ffeat0, void* stream) {
+    PIPS_CHECK_ARG(arena && pyramid && xys && times && workspace && out_trajs && out_vis, "track: null pointer");
+    PIPS_CHECK_ARG(B > 0 && N > 0 && T >= 1 && iters >= 1 && stride >= 1, "track: need B,N,T,iters,stride >= 1");
+    PIPS_CHECK_ARG(H8 >= 8 && W8 >= 8, "track: map %dx%d too small for a 4-level pyramid", H8, W8);
+    const TrackPlan P = plan_track(B, N);
+    if (workspace_bytes < P.total * sizeof(float)) {
+        set_error("track: workspace %zu < %zu bytes", workspace_bytes, P.total * sizeof(float));
+        return PIPS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const int S = PIPS_S, M = B * N * S;
+    float* coords = ws + P.coords; float* coords0 = ws + P.coords0; float* ffeats = ws + P.ffeats;
+    float* ffeat0 = out_ffeat0 != nullptr ? out_ffeat0 : ws + P.ffeat0;
+    const size_t traj_sz = (size_t)B * S * N * 2;
+    RUN(launch_init_coords(xys, coords_init, B, N, (float)stride, coords, coords0, out_trajs, st));
+    if (feat_init != nullptr) {
+        if (feat_init != ffeat0)
+            (void)hipMemcpyAsync(ffeat0, feat_init, (size_t)B * N * PIPS_C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    } else {
+        RUN(launch_point_sample_strided(pyramid, B, T, H8, W8, coords, S * 2, N, win_start, ffeat0, st));   // :463
+    }
+    RUN(launch_init_ffeats(ffeat0, B * N, ffeats, st));                                                      // :466
+    for (int it = 0; it < iters; ++it) {                                                                     // :499
+        RUN(mixer_input(pyramid, B, T, H8, W8, ffeats, coords, times, N, win_start, ws + P.X, st));
+        RUN(pips_mixer_fwd(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes(M), stream));
+        RUN(launch_state_update((const float*)arena, ws + P.delta, ffeats, coords, coords0, B, N, (float)stride,
+                                out_trajs + (size_t)(it + 1) * traj_sz, it + 1 == iters ? out_vis : nullptr, st));
+    }
+    PIPS_CHECK_LAUNCH("pips_track");
+    return PIPS_OK;
+}
 
 size_t pips_workspace_bytes(int B, int S, int H, int W, int N, int stride) {
     if (B <= 0 || S != PIPS_S || H <= 0 || W <= 0 || N <= 0 || stride < 1) return 0;
@@ -520,33 +568,14 @@ int pips_forward(const void* arena, const float* rgbs, const float* xys, const f
         set_error("forward: workspace %zu < %zu bytes", workspace_bytes, P.total * sizeof(float));
         return PIPS_E_WORKSPACE;
     }
-    hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
-    const int F = B * S, M = B * N * S;
-    const int H8 = H / stride, W8 = W / stride;
     float* pyramid = ws + P.pyramid;
     if (!(flags & 1))
-        RUN(pips_encoder_fwd(arena, rgbs, F, H, W, stride, pyramid, ws + P.enc,
-                             pips_encoder_workspace_bytes(F, H, W, stride), stream));
-    float* coords = ws + P.coords; float* coords0 = ws + P.coords0; float* ffeats = ws + P.ffeats;
-    float* ffeat0 = out_ffeat0 != nullptr ? out_ffeat0 : ws + P.ffeat0;
-    const size_t traj_sz = (size_t)B * S * N * 2;
-    RUN(launch_init_coords(xys, coords_init, B, N, (float)stride, coords, coords0, out_trajs, st));
-    if (feat_init != nullptr) {
-        if (feat_init != ffeat0)
-            (void)hipMemcpyAsync(ffeat0, feat_init, (size_t)B * N * PIPS_C * sizeof(float), hipMemcpyDeviceToDevice, st);
-    } else {
-        RUN(launch_point_sample_strided(pyramid, B, S, H8, W8, coords, S * 2, N, ffeat0, st));   // :463
-    }
-    RUN(launch_init_ffeats(ffeat0, B * N, ffeats, st));                                          // :466
-    for (int it = 0; it < iters; ++it) {                                                         // :499
-        RUN(mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, ws + P.X, st));
-        RUN(pips_mixer_fwd(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes(M), stream));
-        RUN(launch_state_update((const float*)arena, ws + P.delta, ffeats, coords, coords0, B, N, (float)stride,
-                                out_trajs + (size_t)(it + 1) * traj_sz, it + 1 == iters ? out_vis : nullptr, st));
-    }
-    PIPS_CHECK_LAUNCH("pips_forward");
-    return PIPS_OK;
+        RUN(pips_encoder_fwd(arena, rgbs, B * S, H, W, stride, pyramid, ws + P.enc,
+                             pips_encoder_workspace_bytes(B * S, H, W, stride), stream));
+    return pips_track(arena, pyramid, B, S, H / stride, W / stride, xys, coords_init, feat_init, nullptr, times, N,
+                      stride, iters, ws + P.track, plan_track(B, N).total * sizeof(float), out_trajs, out_vis,
+                      out_ffeat0, stream);
 }
 
 }  // extern "C"

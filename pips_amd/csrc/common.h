@@ -114,13 +114,13 @@ int launch_avgpool2(const float* src, int F, int H, int W, int C, float* dst, hi
 int launch_point_sample(const float* level0, int B, int S, int H8, int W8, const float* xy, int N,
                         float* out, hipStream_t st);
 int launch_point_sample_strided(const float* level0, int B, int S, int H8, int W8, const float* xy,
-                                int xy_stride, int N, float* out, hipStream_t st);
+                                int xy_stride, int N, const int* win_start, float* out, hipStream_t st);
 int launch_init_coords(const float* xys, const float* coords_init, int B, int N, float stride,
                        float* coords, float* coords0, float* out_traj0, hipStream_t st);
 int launch_init_ffeats(const float* ffeat0, int BN, float* ffeats, hipStream_t st);
 int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW,
                        int B, int S, const float* ffeats, const float* coords, const float* times,
-                       int N, float* X, hipStream_t st);
+                       int N, const int* win_start, float* X, hipStream_t st);
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
                      hipStream_t st);
 int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,

@@ -18,6 +18,7 @@ constexpr int C = PIPS_C;
 __global__ __launch_bounds__(128) void point_sample_kernel(const float* __restrict__ level0, int S_,
                                                            int H, int W, const float* __restrict__ xy,
                                                            int xy_stride, int N,
+                                                           const int* __restrict__ win_start,
                                                            float* __restrict__ out) {
     const int pn = blockIdx.x;            // b*N + n
     const int b = pn / N;
@@ -28,7 +29,8 @@ __global__ __launch_bounds__(128) void point_sample_kernel(const float* __restri
     const int y0 = min(max((int)y0f, 0), H - 1), y1 = min(max((int)y0f + 1, 0), H - 1);
     const float w00 = __fmul_rn(x1f - x, y1f - y), w01 = __fmul_rn(x - x0f, y1f - y);
     const float w10 = __fmul_rn(x1f - x, y - y0f), w11 = __fmul_rn(x - x0f, y - y0f);
-    const float* f0 = level0 + (size_t)b * S_ * H * W * C;   // frame s = 0 of clip b
+    const int f_first = win_start != nullptr ? min(max(win_start[pn], 0), S_ - 1) : 0;
+    const float* f0 = level0 + ((size_t)b * S_ + f_first) * H * W * C;   // first frame of the window
     const int c = threadIdx.x;
     const float v00 = f0[((size_t)y0 * W + x0) * C + c], v01 = f0[((size_t)y0 * W + x1) * C + c];
     const float v10 = f0[((size_t)y1 * W + x0) * C + c], v11 = f0[((size_t)y1 * W + x1) * C + c];
@@ -39,16 +41,16 @@ __global__ __launch_bounds__(128) void point_sample_kernel(const float* __restri
 }
 
 int launch_point_sample_strided(const float* level0, int B, int S_, int H8, int W8, const float* xy,
-                                int xy_stride, int N, float* out, hipStream_t st) {
+                                int xy_stride, int N, const int* win_start, float* out, hipStream_t st) {
     hipLaunchKernelGGL(point_sample_kernel, dim3(B * N), dim3(128), 0, st, level0, S_, H8, W8, xy,
-                       xy_stride, N, out);
+                       xy_stride, N, win_start, out);
     PIPS_CHECK_LAUNCH("point_sample_kernel");
     return PIPS_OK;
 }
 
 int launch_point_sample(const float* level0, int B, int S_, int H8, int W8, const float* xy, int N,
                         float* out, hipStream_t st) {
-    return launch_point_sample_strided(level0, B, S_, H8, W8, xy, 2, N, out, st);
+    return launch_point_sample_strided(level0, B, S_, H8, W8, xy, 2, N, nullptr, out, st);
 }
 
 // ------------------------------------------------------------------------ state init
@@ -121,12 +123,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                                                           const float* __restrict__ ffeats,
                                                           const float* __restrict__ coords,
                                                           const float* __restrict__ times, int N,
+                                                          const int* __restrict__ win_start,
                                                           float* __restrict__ X) {
     __shared__ float Dw[PIPS_LEVELS][64];
     const int m = blockIdx.x;
     const int s = m % S, pn = m / S;
     const int b = pn / N;
-    const int frame = b * S_ + s;
+    // The map buffer holds S_ frames per clip.  S_ = 8 with win_start == null is the plain
+    // forward; a longer cache + per-particle window start gives chained tracking, where frames
+    // past the end repeat the last one (chain_demo.py:50-52) = a clamp of the frame index.
+    const int fstart = win_start != nullptr ? win_start[pn] : 0;
+    const int frame = b * S_ + min(max(fstart + s, 0), S_ - 1);
     const int tid = threadIdx.x, lane = tid & 63;
     const int lvl = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float cxm = coords[(size_t)m * 2 + 0], cym = coords[(size_t)m * 2 + 1];
@@ -231,11 +238,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 
 int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW,
                        int B, int S_, const float* ffeats, const float* coords, const float* times,
-                       int N, float* X, hipStream_t st) {
+                       int N, const int* win_start, float* X, hipStream_t st) {
     LevelTable lv;
     for (int l = 0; l < PIPS_LEVELS; ++l) { lv.off[l] = lvl_off[l]; lv.H[l] = lvlH[l]; lv.W[l] = lvlW[l]; }
     hipLaunchKernelGGL(mixer_input_kernel, dim3(B * N * S), dim3(256), 0, st, pyramid, lv, S_, ffeats,
-                       coords, times, N, X);
+                       coords, times, N, win_start, X);
     PIPS_CHECK_LAUNCH("mixer_input_kernel");
     return PIPS_OK;
 }
@@ -279,63 +286,100 @@ __device__ __forceinline__ void ln_stats(const float (&x0)[S], const float (&x1)
     for (int t = 0; t < S; ++t) rstd[t] = 1.0f / sqrtf(a[t] * (1.0f / PIPS_DMIX) + 1e-5f);
 }
 
-__global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict__ arena, MixLayerW L,
+// LayerNorm statistics of 8 rows x 512 channels held one channel per thread by a 512-thread
+// block: ONE reduction with the parallel (Chan) mean/M2 merge instead of two passes --
+// numerically equivalent to the two-pass form, half the barriers.  Equal counts at every
+// merge: mean = (ma+mb)/2, M2 = M2a + M2b + (mb-ma)^2 * c/2.
+__device__ __forceinline__ void ln_stats512(const float (&x)[S], float (&mean)[S], float (&rstd)[S],
+                                            float (*red)[S][2]) {
+    float m[S], q[S];
+#pragma unroll
+    for (int t = 0; t < S; ++t) { m[t] = x[t]; q[t] = 0.f; }
+#define PIPS_WELFORD_STEP(O, HALF_C)                                              \
+    _Pragma("unroll") for (int t = 0; t < S; ++t) {                               \
+        const float om = __shfl_xor(m[t], (O)), oq = __shfl_xor(q[t], (O));      \
+        const float d = om - m[t];                                                \
+        m[t] = 0.5f * (m[t] + om);                                                \
+        q[t] = (q[t] + oq) + d * d * (HALF_C);                                    \
+    }
+    PIPS_WELFORD_STEP(1, 0.5f) PIPS_WELFORD_STEP(2, 1.0f) PIPS_WELFORD_STEP(4, 2.0f)
+    PIPS_WELFORD_STEP(8, 4.0f) PIPS_WELFORD_STEP(16, 8.0f) PIPS_WELFORD_STEP(32, 16.0f)
+#undef PIPS_WELFORD_STEP
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                                   // previous readers of red are done
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int t = 0; t < S; ++t) { red[wave][t][0] = m[t]; red[wave][t][1] = q[t]; }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        float pm[8], pq[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { pm[w] = red[w][t][0]; pq[w] = red[w][t][1]; }
+        // 8 -> 4 -> 2 -> 1 groups of 64, 128, 256 channels (written out: keeps pm/pq in registers)
+#define PIPS_MERGE(dst, a_, b_, HALF_C)                                   \
+        { const float d = pm[b_] - pm[a_];                                 \
+          pq[dst] = (pq[a_] + pq[b_]) + d * d * (HALF_C);                  \
+          pm[dst] = 0.5f * (pm[a_] + pm[b_]); }
+        PIPS_MERGE(0, 0, 1, 32.0f) PIPS_MERGE(1, 2, 3, 32.0f) PIPS_MERGE(2, 4, 5, 32.0f) PIPS_MERGE(3, 6, 7, 32.0f)
+        PIPS_MERGE(0, 0, 1, 64.0f) PIPS_MERGE(1, 2, 3, 64.0f)
+        PIPS_MERGE(0, 0, 1, 128.0f)
+#undef PIPS_MERGE
+        mean[t] = pm[0];
+        rstd[t] = 1.0f / sqrtf(pq[0] * (1.0f / PIPS_DMIX) + 1e-5f);
+    }
+}
+
+__global__ __launch_bounds__(512) void token_mix_kernel(const float* __restrict__ arena, MixLayerW L,
                                                         float* __restrict__ x, float* __restrict__ xn) {
-    __shared__ float red[4][S];
+    __shared__ float red[8][S][2];
     __shared__ float wsm[32 * 8 + 32 + 8 * 32 + 8];
     const int tid = threadIdx.x;
     // stage the tiny token-MLP weights: w0[32][8], b0[32], w3[8][32], b3[8]
-    for (int i = tid; i < 256; i += 256) wsm[i] = arena[L.tw0 + i];
+    if (tid < 256) wsm[tid] = arena[L.tw0 + tid];
+    else wsm[288 + (tid - 256)] = arena[L.tw3 + (tid - 256)];
     if (tid < 32) wsm[256 + tid] = arena[L.tb0 + tid];
-    for (int i = tid; i < 256; i += 256) wsm[288 + i] = arena[L.tw3 + i];
-    if (tid < 8) wsm[544 + tid] = arena[L.tb3 + tid];
+    if (tid >= 64 && tid < 72) wsm[544 + (tid - 64)] = arena[L.tb3 + (tid - 64)];
 
     float* xp = x + (size_t)blockIdx.x * S * PIPS_DMIX;
     float* xnp = xn + (size_t)blockIdx.x * S * PIPS_DMIX;
-    const int c0 = tid, c1 = tid + 256;
-    float x0[S], x1[S], mean[S], rstd[S];
+    const int c = tid;
+    float xv[S], mean[S], rstd[S];
 #pragma unroll
-    for (int t = 0; t < S; ++t) { x0[t] = xp[t * PIPS_DMIX + c0]; x1[t] = xp[t * PIPS_DMIX + c1]; }
-    ln_stats(x0, x1, mean, rstd, red);       // (contains the barriers that publish wsm)
+    for (int t = 0; t < S; ++t) xv[t] = xp[t * PIPS_DMIX + c];
+    const float g1 = arena[L.ln1g + c], be1 = arena[L.ln1b + c];
+    const float g2 = arena[L.ln2g + c], be2 = arena[L.ln2b + c];
+    ln_stats512(xv, mean, rstd, red);        // (its barriers also publish wsm)
 
-    const float g0 = arena[L.ln1g + c0], g1 = arena[L.ln1g + c1];
-    const float be0 = arena[L.ln1b + c0], be1 = arena[L.ln1b + c1];
-    float h0[S], h1[S];
+    float h[S], y[S];
 #pragma unroll
     for (int t = 0; t < S; ++t) {
-        h0[t] = (x0[t] - mean[t]) * rstd[t] * g0 + be0;
-        h1[t] = (x1[t] - mean[t]) * rstd[t] * g1 + be1;
+        h[t] = (xv[t] - mean[t]) * rstd[t] * g1 + be1;
+        y[t] = wsm[544 + t];
     }
-    float y0[S], y1[S];
-#pragma unroll
-    for (int t = 0; t < S; ++t) { y0[t] = wsm[544 + t]; y1[t] = wsm[544 + t]; }
-#pragma unroll 4
+#pragma unroll 8
     for (int j = 0; j < 32; ++j) {
-        float u0 = wsm[256 + j], u1 = u0;
+        float u = wsm[256 + j];
 #pragma unroll
-        for (int t = 0; t < S; ++t) { u0 = fmaf(wsm[j * 8 + t], h0[t], u0); u1 = fmaf(wsm[j * 8 + t], h1[t], u1); }
-        u0 = gelu_exact(u0); u1 = gelu_exact(u1);
+        for (int t = 0; t < S; ++t) u = fmaf(wsm[j * 8 + t], h[t], u);
+        u = gelu_exact(u);
 #pragma unroll
-        for (int t = 0; t < S; ++t) { y0[t] = fmaf(wsm[288 + t * 32 + j], u0, y0[t]); y1[t] = fmaf(wsm[288 + t * 32 + j], u1, y1[t]); }
+        for (int t = 0; t < S; ++t) y[t] = fmaf(wsm[288 + t * 32 + j], u, y[t]);
     }
 #pragma unroll
-    for (int t = 0; t < S; ++t) { y0[t] += x0[t]; y1[t] += x1[t]; }
+    for (int t = 0; t < S; ++t) y[t] += xv[t];
 
-    ln_stats(y0, y1, mean, rstd, red);
-    const float q0 = arena[L.ln2g + c0], q1 = arena[L.ln2g + c1];
-    const float r0 = arena[L.ln2b + c0], r1 = arena[L.ln2b + c1];
+    ln_stats512(y, mean, rstd, red);
 #pragma unroll
     for (int t = 0; t < S; ++t) {
-        xp[t * PIPS_DMIX + c0] = y0[t];
-        xp[t * PIPS_DMIX + c1] = y1[t];
-        xnp[t * PIPS_DMIX + c0] = (y0[t] - mean[t]) * rstd[t] * q0 + r0;
-        xnp[t * PIPS_DMIX + c1] = (y1[t] - mean[t]) * rstd[t] * q1 + r1;
+        xp[t * PIPS_DMIX + c] = y[t];
+        xnp[t * PIPS_DMIX + c] = (y[t] - mean[t]) * rstd[t] * g2 + be2;
     }
 }
 
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
                      hipStream_t st) {
-    hipLaunchKernelGGL(token_mix_kernel, dim3(particles), dim3(256), 0, st, arena, L, x, xn);
+    hipLaunchKernelGGL(token_mix_kernel, dim3(particles), dim3(512), 0, st, arena, L, x, xn);
     PIPS_CHECK_LAUNCH("token_mix_kernel");
     return PIPS_OK;
 }

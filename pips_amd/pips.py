@@ -25,6 +25,20 @@ from . import _lib, ops
 from .weights import init_state_dict, param_table
 
 
+class FeatureCache:
+    """Encoder output kept on the device for re-use: the packed 4-level channel-last pyramid of
+    ``B`` clips x ``T`` frames (``T`` need not be 8).  Produced by ``Pips.encode``, consumed by
+    ``Pips.track``.  Per-frame InstanceNorm (nets/pips.py:153-157) makes a frame's maps
+    independent of which clip/window it sits in, so the cache is exact for any window."""
+
+    def __init__(self, pyr, B, T, H, W, stride):
+        self.pyr, self.B, self.T, self.H, self.W, self.stride = pyr, B, T, H, W, stride
+
+    @property
+    def map_size(self):
+        return self.H // self.stride, self.W // self.stride
+
+
 class _Node(nn.Module):
     """Bare container: only carries parameters/children under the reference's names."""
 
@@ -73,7 +87,7 @@ class Pips(nn.Module):
             nb = lib.pips_workspace_bytes(*dims)
             if nb == 0:
                 raise _lib.PipsHipError(f"unsupported problem size {dims}")
-            self._ws.clear()                      # one resident workspace per module
+            self._ws = {k2: v for k2, v in self._ws.items() if k2[0] == "track"}   # one forward workspace per module
             ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
             self._ws[k] = ws
         return ws
@@ -124,6 +138,79 @@ class Pips(nn.Module):
         if return_feat:
             return coord_predictions, coord_predictions2, vis_e, ffeat, losses
         return coord_predictions, coord_predictions2, vis_e, losses
+
+
+    # ------------------------------------------------------------------ encoder / tracker split
+    @torch.no_grad()
+    def encode(self, rgbs, frames_per_pass: int = 16) -> FeatureCache:
+        """BasicEncoder + pyramid of every frame of ``rgbs (B,T,3,H,W)`` (0..255), once.
+        Replaces the per-chunk / per-hop encoder re-runs of test_on_davis.py:116-118 and
+        chain_demo.py:54.  Frames are encoded ``frames_per_pass`` at a time to bound the
+        activation workspace for long videos."""
+        if not rgbs.is_cuda:
+            raise _lib.PipsHipError("pips_amd.Pips needs CUDA/HIP tensors; there is no CPU fallback")
+        lib = _lib.load()
+        B, T, C3, H, W = rgbs.shape
+        assert C3 == 3
+        dev, st = rgbs.device, int(self.stride)
+        F = B * T
+        with torch.cuda.device(dev):
+            arena = self._packed(dev)
+            frames = rgbs.contiguous().to(torch.float32).reshape(F, 3, H, W)
+            if F <= frames_per_pass:
+                pyr = ops.encoder_fwd(arena, frames, st)
+            else:
+                pyr = torch.empty(lib.pips_pyramid_floats(F, H, W, st), dtype=torch.float32, device=dev)
+                dst = ops.pyramid_levels(pyr, F, H, W, st)
+                for f0 in range(0, F, frames_per_pass):
+                    f1 = min(F, f0 + frames_per_pass)
+                    part = ops.encoder_fwd(arena, frames[f0:f1], st)
+                    for d, p in zip(dst, ops.pyramid_levels(part, f1 - f0, H, W, st)):
+                        d[f0:f1].copy_(p)
+        return FeatureCache(pyr, B, T, H, W, st)
+
+    @torch.no_grad()
+    def track(self, cache: FeatureCache, xys, coords_init=None, feat_init=None, iters=3, win_start=None,
+              return_feat=False):
+        """The update loop of ``forward`` (nets/pips.py:450-563) on cached maps.  ``win_start``
+        ``(B,N)`` int = first frame of each particle's 8-frame window inside the ``T`` cached
+        frames (default 0); frames past the end repeat the last one (chain_demo.py:50-52).
+        Returns the same tuple as ``forward`` (losses = None)."""
+        lib = _lib.load()
+        B, N, D = xys.shape
+        assert D == 2 and B == cache.B
+        dev, f32, S = cache.pyr.device, torch.float32, self.S
+        H8, W8 = cache.map_size
+        xys_c = xys.to(dev).contiguous().to(f32)
+        ci = None if coords_init is None else coords_init.to(dev).contiguous().to(f32)
+        fi = None if feat_init is None else feat_init.to(dev).contiguous().to(f32)
+        ws_i = None if win_start is None else win_start.to(dev).contiguous().to(torch.int32)
+        if ws_i is not None:
+            assert tuple(ws_i.shape) == (B, N)
+        elif cache.T != S:
+            ws_i = torch.zeros(B, N, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            arena = self._packed(dev)
+            if self._times is None or self._times.device != dev:
+                self._times = ops.times_table(dev)
+            nb = lib.pips_track_workspace_bytes(B, N)
+            key = ("track", str(dev), B, N)
+            ws = self._ws.get(key)
+            if ws is None:
+                ws = self._ws[key] = torch.empty(nb // 4, dtype=f32, device=dev)
+            trajs = torch.empty(iters + 1, B, S, N, 2, dtype=f32, device=dev)
+            vis_e = torch.empty(B, S, N, dtype=f32, device=dev)
+            ffeat = torch.empty(B, N, self.latent_dim, dtype=f32, device=dev)
+            rc = lib.pips_track(_lib.ptr(arena), _lib.ptr(cache.pyr), B, cache.T, H8, W8, _lib.ptr(xys_c), _lib.ptr(ci),
+                                _lib.ptr(fi), _lib.ptr(ws_i), _lib.ptr(self._times), N, int(cache.stride), int(iters),
+                                _lib.ptr(ws), nb, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(rc, "pips_track")
+        preds = [trajs[i + 1] for i in range(iters)]
+        preds2 = [trajs[0], trajs[0]] + preds + [trajs[iters], trajs[iters]]
+        if return_feat:
+            return preds, preds2, vis_e, ffeat, None
+        return preds, preds2, vis_e, None
 
 
 def _masked_mean(x, mask):
