@@ -123,6 +123,16 @@ int    pips_mixer_input_build(const float* pyramid, int B, int S, int H8, int W8
                               const float* ffeats, const float* coords, const float* times,
                               int N, float* X, void* stream);
 
+/* Same result as pips_mixer_input_build through the LDS-tiled kernel meant for dense query sets
+ * (particles binned by 16x16 map tile, the tile's halo region staged in LDS once per tile).
+ * Opt-in: slower than the direct kernel at the measured sizes, kept for the
+ * dense-grid work of later rounds; pips_track uses it only under PIPS_GATHER_TILED=1.  scratch
+ * holds the per-frame sort; values agree with the direct kernel to fp32 summation order. */
+size_t pips_gather_scratch_bytes(int B, int N, int H8, int W8);
+int    pips_mixer_input_build_tiled(const float* pyramid, int B, int S, int H8, int W8,
+                                    const float* ffeats, const float* coords, const float* times,
+                                    int N, float* X, void* scratch, size_t scratch_bytes, void* stream);
+
 /* MLPMixer (nets/pips.py:111-123): X (M,544) -> delta (M/8, 1040).  M = B*N*8. */
 size_t pips_mixer_workspace_bytes(int M);
 int    pips_mixer_fwd(const void* arena, const float* X, int M, float* delta,

@@ -357,8 +357,10 @@ int pips_point_sample(const float* level0, int B, int S, int H8, int W8, const f
     return launch_point_sample(level0, B, S, H8, W8, xy, N, out, (hipStream_t)stream);
 }
 
+// scratch != null and a dense, un-windowed query set: LDS-tiled kernel; otherwise the direct one
 static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats, const float* coords,
-                       const float* times, int N, const int* win_start, float* X, hipStream_t st) {
+                       const float* times, int N, const int* win_start, float* X, hipStream_t st,
+                       void* scratch = nullptr, size_t scratch_bytes = 0, int force_tiled = -1) {
     size_t off[PIPS_LEVELS];
     int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
     lh[0] = H8; lw[0] = W8;
@@ -369,6 +371,13 @@ static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const
         o += ((size_t)B * S * lh[l] * lw[l] * PIPS_C + 63) / 64 * 64;
     }
     PIPS_CHECK_ARG(lh[PIPS_LEVELS - 1] >= 1 && lw[PIPS_LEVELS - 1] >= 1, "mixer_input: map too small");
+    const bool can_tile = scratch != nullptr && win_start == nullptr && S == PIPS_S &&
+                          scratch_bytes >= tiled_gather_scratch_bytes(B, N, H8, W8);
+    const bool tiled = force_tiled >= 0 ? (force_tiled != 0) : tiled_gather_wanted(N, H8, W8);
+    if (tiled && can_tile)
+        return launch_mixer_input_tiled(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, scratch, scratch_bytes, st);
+    PIPS_CHECK_ARG(force_tiled != 1, "tiled gather needs scratch of %zu bytes, no win_start and 8 frames per clip",
+                   tiled_gather_scratch_bytes(B, N, H8, W8));
     return launch_mixer_input(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, win_start, X, st);
 }
 
@@ -377,6 +386,20 @@ int pips_mixer_input_build(const float* pyramid, int B, int S, int H8, int W8, c
     PIPS_CHECK_ARG(pyramid && ffeats && coords && times && X, "mixer_input: null pointer");
     PIPS_CHECK_ARG(S >= 1 && B > 0 && N > 0, "mixer_input: empty problem");
     return mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, nullptr, X, (hipStream_t)stream);
+}
+
+size_t pips_gather_scratch_bytes(int B, int N, int H8, int W8) {
+    if (B <= 0 || N <= 0 || H8 <= 0 || W8 <= 0) return 0;
+    return tiled_gather_scratch_bytes(B, N, H8, W8);
+}
+
+int pips_mixer_input_build_tiled(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats,
+                                 const float* coords, const float* times, int N, float* X, void* scratch,
+                                 size_t scratch_bytes, void* stream) {
+    PIPS_CHECK_ARG(pyramid && ffeats && coords && times && X && scratch, "mixer_input_tiled: null pointer");
+    PIPS_CHECK_ARG(S == PIPS_S && B > 0 && N > 0, "mixer_input_tiled: S must be %d", PIPS_S);
+    return mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, nullptr, X, (hipStream_t)stream, scratch,
+                       scratch_bytes, 1);
 }
 
 size_t pips_mixer_workspace_bytes(int M) {
@@ -540,7 +563,9 @@ int pips_track(const void* arena, const float* pyramid, int B, int T, int H8, in
     }
     RUN(launch_init_ffeats(ffeat0, B * N, ffeats, st));                                                      // :466
     for (int it = 0; it < iters; ++it) {                                                                     // :499
-        RUN(mixer_input(pyramid, B, T, H8, W8, ffeats, coords, times, N, win_start, ws + P.X, st));
+        // the mixer workspace is idle while the gather runs: it doubles as the binning scratch
+        RUN(mixer_input(pyramid, B, T, H8, W8, ffeats, coords, times, N, win_start, ws + P.X, st, ws + P.mixer,
+                        pips_mixer_workspace_bytes(M)));
         RUN(pips_mixer_fwd(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes(M), stream));
         RUN(launch_state_update((const float*)arena, ws + P.delta, ffeats, coords, coords0, B, N, (float)stride,
                                 out_trajs + (size_t)(it + 1) * traj_sz, it + 1 == iters ? out_vis : nullptr, st));

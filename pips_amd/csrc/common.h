@@ -121,6 +121,12 @@ int launch_init_ffeats(const float* ffeat0, int BN, float* ffeats, hipStream_t s
 int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW,
                        int B, int S, const float* ffeats, const float* coords, const float* times,
                        int N, const int* win_start, float* X, hipStream_t st);
+// LDS-tiled gather for dense query sets (gather_tiled.hip)
+size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8);
+bool tiled_gather_wanted(int N, int H8, int W8);
+int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B,
+                             int S, const float* ffeats, const float* coords, const float* times, int N,
+                             float* X, void* scratch, size_t scratch_bytes, hipStream_t st);
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
                      hipStream_t st);
 int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,

@@ -102,6 +102,23 @@ def mixer_input_build(pyr, B, H8, W8, ffeats, coords):
     return X
 
 
+def mixer_input_build_tiled(pyr, B, H8, W8, ffeats, coords):
+    """Same as mixer_input_build through the LDS-tiled kernel for dense query sets."""
+    lib = _lib.load()
+    ffeats, coords = _f32(ffeats), _f32(coords)
+    M = ffeats.shape[0]
+    N = M // (B * S)
+    X = torch.empty(M, KIN_PAD, dtype=torch.float32, device=ffeats.device)
+    tt = times_table(ffeats.device)
+    nb = lib.pips_gather_scratch_bytes(B, N, H8, W8)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=ffeats.device)
+    with torch.cuda.device(ffeats.device):
+        _lib.check(lib.pips_mixer_input_build_tiled(_lib.ptr(pyr), B, S, H8, W8, _lib.ptr(ffeats), _lib.ptr(coords),
+                                                    _lib.ptr(tt), N, _lib.ptr(X), _lib.ptr(scratch), nb, _stream()),
+                   "pips_mixer_input_build_tiled")
+    return X
+
+
 def mixer_fwd(arena, X):
     """X (M,544) -> delta (M/8, 1040)."""
     lib = _lib.load()

@@ -179,6 +179,30 @@ def test_mixer_input_build(B, N, H8, W8):
     assert torch.equal(X[..., 516:519], X_ref[..., 516:519])                            # raw flow + time
 
 
+@pytest.mark.parametrize("B,N,H8,W8,spread", [(1, 300, 46, 62, 0.7), (2, 1024, 33, 40, 3.0), (1, 77, 16, 20, 0.0)])
+def test_mixer_input_build_tiled(B, N, H8, W8, spread):
+    """LDS-tiled gather (dense query sets) vs the oracle and vs the direct kernel."""
+    from pips_amd import ops
+    O = _oracle()
+    fmaps, ffeats, coords = _random_state(B, N, H8, W8, seed=9, spread=spread)
+    # a dense grid in frame 0 of clip 0 (many particles per 16x16 tile) plus far-out points
+    n_ = int(N ** 0.5)
+    gy, gx = torch.meshgrid(torch.linspace(0, H8 - 1, n_), torch.linspace(0, W8 - 1, n_), indexing="ij")
+    coords[0, 0, :n_ * n_] = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1)
+    coords[0, 6, 1] = torch.tensor([-40.0, 3.0])
+    coords[0, 7, 1] = torch.tensor([W8 + 3.5, H8 + 9.0])
+    pyr_ref = O.build_pyramid(fmaps)
+    X_ref = O.mixer_input(ffeats, O.corr_sample(pyr_ref, ffeats, coords), coords)
+    pyr = _pack_pyramid(pyr_ref, B, H8 * 8, W8 * 8, 8)
+    ff, co = _pm(ffeats).to(DEV), _pm(coords).to(DEV)
+    X = ops.mixer_input_build_tiled(pyr, B, H8, W8, ff, co).cpu().view(B * N, 8, 544)
+    Xd = ops.mixer_input_build(pyr, B, H8, W8, ff, co).cpu().view(B * N, 8, 544)
+    assert torch.equal(X[..., :128], X_ref[..., :128]) and torch.equal(X[..., 519:], torch.zeros_like(X[..., 519:]))
+    assert float((X[..., 128:324] - X_ref[..., 128:324]).abs().max()) < 5e-5
+    assert float((X[..., 128:324] - Xd[..., 128:324]).abs().max()) < 5e-5
+    assert torch.equal(X[..., 324:], Xd[..., 324:])                       # embedding: same instructions
+
+
 @pytest.mark.parametrize("P", [4, 32, 256])
 def test_mixer(P, weights_raw, arenas):
     from pips_amd import ops

@@ -39,6 +39,8 @@ ffeats = torch.randn(M, 128, device=dev)
 for jitter in (0.0, 2.0):
     c = coords + torch.randn(M, 2, device=dev) * jitter
     tg = ev(lambda: ops.mixer_input_build(pyr, B, H8, W8, ffeats, c), 5)
+    tt_ = ev(lambda: ops.mixer_input_build_tiled(pyr, B, H8, W8, ffeats, c), 5)
+    print(f"  tiled gather (jitter {jitter}): {tt_*1e3:.1f} us   direct: {tg*1e3:.1f} us", flush=True)
     lv = sum((H8 >> l) * (W8 >> l) for l in range(4))
     comp = F * lv * 512 + M * (512 + 8) + M * 544 * 4
     gath = M * (4 * 64 * 512 + 512 + 8 + 544 * 4)
