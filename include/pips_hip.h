@@ -47,6 +47,11 @@ extern "C" {
 #define PIPS_NOUT     1040     /* S*(C+2)                    nets/pips.py:299        */
 #define PIPS_NPARAMS  200      /* tensors in the reference state dict                */
 
+/* flags of pips_forward / pips_track */
+#define PIPS_FLAG_REUSE_MAPS  1   /* pips_forward: skip the encoder, the workspace already holds the maps */
+#define PIPS_FLAG_BF16_MIXER  2   /* bf16 MFMA operands in the channel-mix and head Linear layers (BASELINE
+                                     config 3); accumulation, norms, GELU, residual stream, gather stay fp32 */
+
 const char* pips_last_error(void);
 int         pips_abi_version(void);
 
@@ -73,8 +78,8 @@ int    pips_repack_weights(const void* const* params_host, int nparams, void* ar
  *   out_vis     (B,S,N) logits             (nets/pips.py:559)
  *   out_ffeat0  (B,N,128) initial feature  (nets/pips.py:463, returned when return_feat)
  * stride is 4 or 8 in the reference's callers; any value >=1 with non-empty level-3 map.
- * flags: bit0 = skip the encoder and reuse the pyramid already in the workspace
- *        (same B,S,H,W,stride as the call that produced it). */
+ * flags: PIPS_FLAG_REUSE_MAPS = skip the encoder and reuse the pyramid already in the workspace
+ *        (same B,S,H,W,stride as the call that produced it); PIPS_FLAG_BF16_MIXER. */
 size_t pips_workspace_bytes(int B, int S, int H, int W, int N, int stride);
 int    pips_forward(const void* arena, const float* rgbs, const float* xys,
                     const float* coords_init, const float* feat_init, const float* times,
@@ -95,7 +100,7 @@ int    pips_forward(const void* arena, const float* rgbs, const float* xys,
 size_t pips_track_workspace_bytes(int B, int N);
 int    pips_track(const void* arena, const float* pyramid, int B, int T, int H8, int W8,
                   const float* xys, const float* coords_init, const float* feat_init,
-                  const int* win_start, const float* times, int N, int stride, int iters,
+                  const int* win_start, const float* times, int N, int stride, int iters, int flags,
                   void* workspace, size_t workspace_bytes,
                   float* out_trajs, float* out_vis, float* out_ffeat0, void* stream);
 
@@ -137,6 +142,11 @@ int    pips_mixer_input_build_tiled(const float* pyramid, int B, int S, int H8, 
 size_t pips_mixer_workspace_bytes(int M);
 int    pips_mixer_fwd(const void* arena, const float* X, int M, float* delta,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same with bf16 MFMA operands (PIPS_FLAG_BF16_MIXER): weights converted once at pack time,
+ * activations rounded to bf16 (RNE) as they are staged, fp32 accumulation and epilogues. */
+int    pips_mixer_fwd_bf16(const void* arena, const float* X, int M, float* delta,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* Profiling variant (the ONLY entry point that creates events and synchronises): same work as
  * pips_mixer_fwd with a hipEvent pair around every GEMM launch on `stream`; ms_host[5] receives

@@ -26,7 +26,7 @@ SIGNATURES = {
                              c_void_p, c_size_t, fp, fp, fp, c_void_p]),
     "pips_track_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pips_track": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p, fp, c_int, c_int, c_int,
-                           c_void_p, c_size_t, fp, fp, fp, c_void_p]),
+                           c_int, c_void_p, c_size_t, fp, fp, fp, c_void_p]),
     "pips_encoder_workspace_bytes": (c_size_t, [c_int] * 4),
     "pips_pyramid_floats": (c_size_t, [c_int] * 4),
     "pips_pyramid_offset": (c_size_t, [c_int] * 5),
@@ -38,6 +38,7 @@ SIGNATURES = {
                                              c_void_p]),
     "pips_mixer_workspace_bytes": (c_size_t, [c_int]),
     "pips_mixer_fwd": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
+    "pips_mixer_fwd_bf16": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_timed": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p, C.POINTER(c_float)]),
     "pips_state_update": (c_int, [c_void_p, fp, fp, fp, fp, c_int, c_int, c_float, fp, fp, c_void_p]),
     "pips_gemm_f32": (c_int, [fp, c_int, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, c_int, c_void_p]),

@@ -61,6 +61,14 @@ static ArenaLayout build_layout() {
     A.w_upd_t = take(PIPS_C * PIPS_C); A.b_upd = take(PIPS_C);
     A.w_vis = take(PIPS_C); A.b_vis = take(1);
     A.total = off;
+    size_t hoff = 0;
+    auto take_h = [&](size_t n) { size_t o = hoff; hoff += (n + 127) / 128 * 128; return o; };   // 256-B aligned
+    for (int d = 0; d < PIPS_DEPTH; ++d) {
+        A.h_w1[d] = take_h((size_t)4 * PIPS_DMIX * PIPS_DMIX);
+        A.h_w2[d] = take_h((size_t)4 * PIPS_DMIX * PIPS_DMIX);
+    }
+    A.h_head = take_h((size_t)PIPS_NOUT * PIPS_DMIX);
+    A.total_h = hoff;
     return A;
 }
 
@@ -94,6 +102,12 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict
     dst[i] = k < Kin ? src[(size_t)r * Kin + k] : 0.f;
 }
 
+// fp32 -> bf16 (round to nearest even, hardware v_cvt_pk_bf16_f32)
+__global__ void cvt_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (__bf16)src[i];
+}
+
 static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace pips
@@ -105,7 +119,9 @@ extern "C" {
 const char* pips_last_error(void) { return g_err; }
 int pips_abi_version(void) { return 1; }
 
-size_t pips_weight_arena_bytes(void) { return arena_layout().total * sizeof(float); }
+size_t pips_weight_arena_bytes(void) {
+    return arena_layout().total * sizeof(float) + arena_layout().total_h * sizeof(unsigned short);
+}
 
 int pips_repack_weights(const void* const* params, int nparams, void* arena_v, void* stream) {
     PIPS_CHECK_ARG(params != nullptr && arena_v != nullptr, "repack: null pointer");
@@ -150,6 +166,16 @@ int pips_repack_weights(const void* const* params, int nparams, void* arena_v, v
                        PIPS_C, PIPS_C);
     copy(A.b_upd, PIPS_C);
     copy(A.w_vis, PIPS_C); copy(A.b_vis, 1);
+    // bf16 copies of the channel-mix / head weights (bf16-operand mixer)
+    __bf16* hb = reinterpret_cast<__bf16*>(arena + A.total);
+    auto to_h = [&](size_t src_off, size_t dst_off, size_t n) {
+        hipLaunchKernelGGL(cvt_bf16_kernel, dim3(nblk(n)), dim3(256), 0, st, arena + src_off, hb + dst_off, n);
+    };
+    for (int d = 0; d < PIPS_DEPTH; ++d) {
+        to_h(A.mix[d].w1, A.h_w1[d], (size_t)4 * PIPS_DMIX * PIPS_DMIX);
+        to_h(A.mix[d].w2, A.h_w2[d], (size_t)4 * PIPS_DMIX * PIPS_DMIX);
+    }
+    to_h(A.w_head, A.h_head, (size_t)PIPS_NOUT * PIPS_DMIX);
     PIPS_CHECK_LAUNCH("pips_repack_weights");
     return pi == PIPS_NPARAMS ? PIPS_OK : PIPS_E_ARG;
 }
@@ -411,8 +437,20 @@ size_t pips_mixer_workspace_bytes(int M) {
 }
 
 // ev != nullptr: record ev[2g], ev[2g+1] around GEMM g (g = 0 in-proj, 1+2d up, 2+2d down, 25 head)
+static int gemm_h(const float* A, int a_bf16, int lda, const unsigned short* W, const float* bias, float* C,
+                  int out_bf16, int ldc, int M, int N, int K, int epi, const float* R, int ldr, hipStream_t st) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.W = reinterpret_cast<const float*>(W); g.bias = bias; g.C = C; g.R = R;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.epi = epi;
+    return launch_gemm_bf16(g, a_bf16, out_bf16, st);
+}
+
+// bf16 != 0: bf16 MFMA operands for the channel-mix and head GEMMs (weights pre-converted, the
+// 2048-wide hidden activation stored as bf16, everything else fp32); the 544-wide input
+// projection stays on the fp32 path (K is not a multiple of 64).
 static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, void* workspace,
-                      size_t workspace_bytes, void* stream, hipEvent_t* ev) {
+                      size_t workspace_bytes, void* stream, hipEvent_t* ev, int bf16 = 0) {
     PIPS_CHECK_ARG(arena_v && X && delta && workspace, "mixer: null pointer");
     PIPS_CHECK_ARG(M > 0 && M % PIPS_S == 0, "mixer: M=%d must be a positive multiple of %d", M, PIPS_S);
     if (workspace_bytes < pips_mixer_workspace_bytes(M)) {
@@ -443,14 +481,28 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
         RUN(launch_token_mix(arena, L, x, xn, P, st));
+        if (bf16) {
+            const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
+            TIMED(gemm_h(xn, 0, PIPS_DMIX, hw + A.h_w1[d], arena + L.b1, h, 1, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX,
+                         PIPS_DMIX, EPI_GELU, nullptr, 0, st));
+            TIMED(gemm_h(h, 1, 4 * PIPS_DMIX, hw + A.h_w2[d], arena + L.b2, x, 0, PIPS_DMIX, M, PIPS_DMIX,
+                         4 * PIPS_DMIX, EPI_RESIDUAL, x, PIPS_DMIX, st));
+            continue;
+        }
         TIMED(pips_gemm_f32(xn, PIPS_DMIX, arena + L.w1, arena + L.b1, h, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX, PIPS_DMIX,
                             EPI_GELU, nullptr, 0, stream));
         TIMED(pips_gemm_f32(h, 4 * PIPS_DMIX, arena + L.w2, arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
                             EPI_RESIDUAL, x, PIPS_DMIX, stream));
     }
     RUN(launch_ln_mean(x, arena + A.lnf_g, arena + A.lnf_b, pooled, P, st));
-    TIMED(pips_gemm_f32(pooled, PIPS_DMIX, arena + A.w_head, arena + A.b_head, delta, PIPS_NOUT, P, PIPS_NOUT,
-                        PIPS_DMIX, EPI_BIAS, nullptr, 0, stream));
+    if (bf16) {
+        const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
+        TIMED(gemm_h(pooled, 0, PIPS_DMIX, hw + A.h_head, arena + A.b_head, delta, 0, PIPS_NOUT, P, PIPS_NOUT,
+                     PIPS_DMIX, EPI_BIAS, nullptr, 0, st));
+    } else {
+        TIMED(pips_gemm_f32(pooled, PIPS_DMIX, arena + A.w_head, arena + A.b_head, delta, PIPS_NOUT, P, PIPS_NOUT,
+                            PIPS_DMIX, EPI_BIAS, nullptr, 0, stream));
+    }
 #undef TIMED
     return PIPS_OK;
 }
@@ -458,6 +510,11 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
 int pips_mixer_fwd(const void* arena_v, const float* X, int M, float* delta, void* workspace, size_t workspace_bytes,
                    void* stream) {
     return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr);
+}
+
+int pips_mixer_fwd_bf16(const void* arena_v, const float* X, int M, float* delta, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 1);
 }
 
 int pips_mixer_fwd_timed(const void* arena_v, const float* X, int M, float* delta, void* workspace,
@@ -538,8 +595,8 @@ size_t pips_track_workspace_bytes(int B, int N) {
 
 int pips_track(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
                const float* coords_init, const float* feat_init, const int* win_start, const float* times, int N,
-               int stride, int iters, void* workspace, size_t workspace_bytes, float* out_trajs, float* out_vis,
-               float* out_ffeat0, void* stream) {
+               int stride, int iters, int flags, void* workspace, size_t workspace_bytes, float* out_trajs,
+               float* out_vis, float* out_ffeat0, void* stream) {
     PIPS_CHECK_ARG(arena && pyramid && xys && times && workspace && out_trajs && out_vis, "track: null pointer");
     PIPS_CHECK_ARG(B > 0 && N > 0 && T >= 1 && iters >= 1 && stride >= 1, "track: need B,N,T,iters,stride >= 1");
     PIPS_CHECK_ARG(H8 >= 8 && W8 >= 8, "track: map %dx%d too small for a 4-level pyramid", H8, W8);
@@ -566,7 +623,8 @@ int pips_track(const void* arena, const float* pyramid, int B, int T, int H8, in
         // the mixer workspace is idle while the gather runs: it doubles as the binning scratch
         RUN(mixer_input(pyramid, B, T, H8, W8, ffeats, coords, times, N, win_start, ws + P.X, st, ws + P.mixer,
                         pips_mixer_workspace_bytes(M)));
-        RUN(pips_mixer_fwd(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes(M), stream));
+        RUN(mixer_impl(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes(M), stream, nullptr,
+                       (flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0));
         RUN(launch_state_update((const float*)arena, ws + P.delta, ffeats, coords, coords0, B, N, (float)stride,
                                 out_trajs + (size_t)(it + 1) * traj_sz, it + 1 == iters ? out_vis : nullptr, st));
     }
@@ -584,7 +642,7 @@ int pips_forward(const void* arena, const float* rgbs, const float* xys, const f
                  int iters, int flags, void* workspace, size_t workspace_bytes, float* out_trajs, float* out_vis,
                  float* out_ffeat0, void* stream) {
     PIPS_CHECK_ARG(arena && xys && times && workspace && out_trajs && out_vis, "forward: null pointer");
-    PIPS_CHECK_ARG((flags & 1) || rgbs != nullptr, "forward: rgbs is null");
+    PIPS_CHECK_ARG((flags & PIPS_FLAG_REUSE_MAPS) || rgbs != nullptr, "forward: rgbs is null");
     PIPS_CHECK_ARG(S == PIPS_S, "forward: S=%d, the mixer weights fix S=%d (nets/pips.py:295-301)", S, PIPS_S);
     PIPS_CHECK_ARG(B > 0 && N > 0 && iters >= 1, "forward: need B,N >= 1 and iters >= 1");
     RUN(check_geometry(B * S, H, W, stride));
@@ -595,11 +653,11 @@ int pips_forward(const void* arena, const float* rgbs, const float* xys, const f
     }
     float* ws = (float*)workspace;
     float* pyramid = ws + P.pyramid;
-    if (!(flags & 1))
+    if (!(flags & PIPS_FLAG_REUSE_MAPS))
         RUN(pips_encoder_fwd(arena, rgbs, B * S, H, W, stride, pyramid, ws + P.enc,
                              pips_encoder_workspace_bytes(B * S, H, W, stride), stream));
     return pips_track(arena, pyramid, B, S, H / stride, W / stride, xys, coords_init, feat_init, nullptr, times, N,
-                      stride, iters, ws + P.track, plan_track(B, N).total * sizeof(float), out_trajs, out_vis,
+                      stride, iters, flags, ws + P.track, plan_track(B, N).total * sizeof(float), out_trajs, out_vis,
                       out_ffeat0, stream);
 }
 

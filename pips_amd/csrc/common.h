@@ -77,6 +77,8 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, hipStream_t st);          // plain GEMM, picks a tile
 int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
 int conv_tiles_m(int rows_per_frame, int Cout, int frames);  // tile count launch_conv will use
+// bf16-operand GEMM (gemm_bf16.hip): A fp32 or bf16, W bf16, C fp32 or bf16; pointers passed as float*
+int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
 
 // ---------------------------------------------------------------- weight arena
 // Offsets in floats into the packed arena (see api.hip: build_layout()).
@@ -88,7 +90,10 @@ struct ArenaLayout {
     MixLayerW mix[PIPS_DEPTH];
     size_t lnf_g, lnf_b, w_head, b_head;
     size_t norm_g, norm_b, w_upd_t, b_upd, w_vis, b_vis;
-    size_t total;            // floats
+    size_t total;            // floats (fp32 section)
+    // bf16 copies of the big Linear weights for the bf16-operand mixer, in ushort units from
+    // the end of the fp32 section (arena + total)
+    size_t h_w1[PIPS_DEPTH], h_w2[PIPS_DEPTH], h_head, total_h;
 };
 const ArenaLayout& arena_layout();
 

@@ -1,0 +1,248 @@
+// bf16-operand GEMM for the mixer's Linear layers (BASELINE config 3: "bf16 MFMA operands").
+//
+// C[M,N] = epi(A[M,K] * W[N,K]^T + bias): A is fp32 (converted to bf16 with the hardware
+// round-to-nearest-even v_cvt_pk_bf16_f32 while it is staged into LDS) or already bf16 (the
+// 2048-wide hidden activation, the one tensor worth storing narrow); W is bf16 (converted once
+// at weight-pack time); products are exact, accumulation is fp32 (v_mfma_f32_32x32x16_bf16),
+// bias / GELU / residual / LayerNorm inputs and the residual stream stay fp32.  Same block
+// structure as gemm.hip (two LDS stages, one barrier per K block, K-split wave groups, C^T
+// accumulators for 16-byte epilogue accesses); a staged K block is 64 elements = the same 128
+// bytes per row, so the conflict-free 16-byte-padded LDS image and the fragment addressing
+// (lane -> row lane&31, 16 bytes at 32*kk + 16*(lane>>5)) carry over unchanged: per MFMA a lane
+// supplies 8 consecutive K values.
+#include "common.h"
+
+namespace pips {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint4 pack_bf16x8(const float4& lo, const float4& hi) {
+    f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    bf16x8 b = __builtin_convertvector(v, bf16x8);
+    return *reinterpret_cast<uint4*>(&b);
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS, bool A_BF16, bool OUT_BF16>
+__global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs p) {
+    constexpr int NT = WGM * WGN * KS * 64;
+    constexpr int BKB = 64 * KS;                    // K elements staged per iteration
+    constexpr int LDB = BKB * 2 + 16;               // LDS row stride in BYTES (16-byte pad)
+    constexpr int TPR = BKB / 8;                    // loader threads per row (8 elements each)
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int ROWS_PER_PASS = NT / TPR;
+    constexpr int PA = BM / ROWS_PER_PASS, PB = BN / ROWS_PER_PASS;
+    constexpr int STAGE = (BM + BN) * LDB;          // bytes per LDS stage
+    static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/loader mismatch");
+    static_assert(PA <= 4 && PB <= 4, "extend the pass macros");
+    static_assert(KS == 1 || (KS - 1) * BM * BN * 4 <= 2 * STAGE, "K-split reduction does not fit the stages");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ks = wave / (WGM * WGN);
+    const int wmn = wave - ks * (WGM * WGN);
+    const int wm = wmn / WGN, wn = wmn % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int lrow = tid / TPR, cg = tid % TPR;
+
+    const float* __restrict__ Af = p.A;                                          // A_BF16 == false
+    const unsigned short* __restrict__ Ab = reinterpret_cast<const unsigned short*>(p.A);   // A_BF16 == true
+    const unsigned short* __restrict__ Wb = reinterpret_cast<const unsigned short*>(p.W);
+
+#define PIPS_PASSES(X) X(0) X(1) X(2) X(3)
+#define PIPS_DECL(i)                                                                     \
+    unsigned a_off##i = 0, b_off##i = 0;                                                 \
+    float4 ra##i##l = make_float4(0.f, 0.f, 0.f, 0.f), ra##i##h = ra##i##l;              \
+    uint4 rq##i = make_uint4(0, 0, 0, 0), rb##i = rq##i;
+    PIPS_PASSES(PIPS_DECL)
+#define PIPS_INIT(i)                                                                     \
+    if constexpr (i < PA) {                                                              \
+        int m_ = m0 + lrow + i * ROWS_PER_PASS;                                          \
+        m_ = m_ < p.M ? m_ : p.M - 1;                                                    \
+        a_off##i = (unsigned)m_ * (unsigned)p.lda + cg * 8;                              \
+    }                                                                                    \
+    if constexpr (i < PB) {                                                              \
+        int n_ = n0 + lrow + i * ROWS_PER_PASS;                                          \
+        n_ = n_ < p.N ? n_ : p.N - 1;                                                    \
+        b_off##i = (unsigned)n_ * (unsigned)p.K + cg * 8;                                \
+    }
+    PIPS_PASSES(PIPS_INIT)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define PIPS_LOAD(i)                                                                                 \
+    if constexpr (i < PA) {                                                                          \
+        if constexpr (A_BF16) rq##i = *reinterpret_cast<const uint4*>(Ab + a_off##i + k0_);          \
+        else {                                                                                       \
+            ra##i##l = *reinterpret_cast<const float4*>(Af + a_off##i + k0_);                        \
+            ra##i##h = *reinterpret_cast<const float4*>(Af + a_off##i + k0_ + 4);                    \
+        }                                                                                            \
+    }                                                                                                \
+    if constexpr (i < PB) rb##i = *reinterpret_cast<const uint4*>(Wb + b_off##i + k0_);
+#define PIPS_LOAD_TILES(kb_) { const int k0_ = (kb_) * BKB; PIPS_PASSES(PIPS_LOAD) }
+#define PIPS_STORE(i)                                                                                \
+    if constexpr (i < PA)                                                                            \
+        *reinterpret_cast<uint4*>(As_ + (lrow + i * ROWS_PER_PASS) * LDB + cg * 16) =               \
+            A_BF16 ? rq##i : pack_bf16x8(ra##i##l, ra##i##h);                                        \
+    if constexpr (i < PB)                                                                            \
+        *reinterpret_cast<uint4*>(Bs_ + (lrow + i * ROWS_PER_PASS) * LDB + cg * 16) = rb##i;
+#define PIPS_STORE_TILES(buf_) { char* As_ = smem + (buf_) * STAGE; char* Bs_ = As_ + BM * LDB; PIPS_PASSES(PIPS_STORE) }
+#define PIPS_COMPUTE(buf_)                                                                           \
+    {                                                                                                \
+        const char* a_frag = smem + (buf_) * STAGE + (wm * WTM + l31) * LDB + ks * 128 + half * 16;  \
+        const char* b_frag = smem + (buf_) * STAGE + BM * LDB + (wn * WTN + l31) * LDB + ks * 128 + half * 16; \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                           \
+            uint4 fa[TM], fb[TN];                                                                    \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+                fa[i] = *reinterpret_cast<const uint4*>(a_frag + i * 32 * LDB + kk * 32);            \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                           \
+                fb[j] = *reinterpret_cast<const uint4*>(b_frag + j * 32 * LDB + kk * 32);            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                       \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                             \
+                        *reinterpret_cast<const bf16x8*>(&fb[j]), *reinterpret_cast<const bf16x8*>(&fa[i]), \
+                        acc[i][j], 0, 0, 0);                                                         \
+        }                                                                                            \
+    }
+
+    const int nk = p.K / BKB;
+    PIPS_LOAD_TILES(0);
+    PIPS_STORE_TILES(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kb = 0; kb + 1 < nk; ++kb) {
+        PIPS_LOAD_TILES(kb + 1);
+        asm volatile("" ::: "memory");              // keep the prefetch ahead of the MFMA phase (see gemm.hip)
+        PIPS_COMPUTE(buf);
+        asm volatile("" ::: "memory");
+        PIPS_STORE_TILES(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    PIPS_COMPUTE(buf);
+#undef PIPS_PASSES
+#undef PIPS_DECL
+#undef PIPS_INIT
+#undef PIPS_LOAD
+#undef PIPS_LOAD_TILES
+#undef PIPS_STORE
+#undef PIPS_STORE_TILES
+#undef PIPS_COMPUTE
+
+    if (KS > 1) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (ks > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((ks - 1) * (WGM * WGN) + wmn) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane] =
+                            acc[i][j][r];
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int g = 0; g < KS - 1; ++g)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][j][r] += red[(((g * (WGM * WGN) + wmn) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane];
+    }
+
+    // epilogue on C^T accumulators: MFMA row index = output column n, MFMA column = output row m
+    const int epi = p.epi & 0xff;
+    float* __restrict__ Cf = p.C;
+    unsigned short* __restrict__ Cb = reinterpret_cast<unsigned short*>(p.C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * WTM + i * 32 + l31;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + wn * WTN + j * 32 + 8 * g + 4 * half;
+                if (col + 3 >= p.N) continue;                      // N % 4 == 0 (checked by the launcher)
+                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (p.bias != nullptr) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col);
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                }
+                if (epi == EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+                } else if (epi == EPI_RESIDUAL) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(p.R + (size_t)row * p.ldr + col);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                if (OUT_BF16) {
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    f32x4 t = {v[0], v[1], v[2], v[3]};
+                    bf16x4 o = __builtin_convertvector(t, bf16x4);
+                    *reinterpret_cast<uint2*>(Cb + (size_t)row * p.ldc + col) = *reinterpret_cast<uint2*>(&o);
+                } else {
+                    *reinterpret_cast<float4*>(Cf + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS, bool A_BF16, bool OUT_BF16>
+static int launch_bf16_tile(const GemmArgs& a, hipStream_t st) {
+    dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), 1);
+    dim3 block(WGM * WGN * KS * 64);
+    const size_t lds = (size_t)2 * (BM + BN) * (64 * KS * 2 + 16);
+    auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, KS, A_BF16, OUT_BF16>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    PIPS_CHECK_LAUNCH("gemm_bf16_kernel");
+    return PIPS_OK;
+}
+
+template <bool A_BF16, bool OUT_BF16>
+static int pick_tile(const GemmArgs& a, hipStream_t st) {
+    const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+    const long b64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
+    if (b128 >= 400) return launch_bf16_tile<128, 128, 2, 2, 1, A_BF16, OUT_BF16>(a, st);
+    if (b64 >= 800 || a.K % 128 != 0) return launch_bf16_tile<64, 64, 2, 2, 1, A_BF16, OUT_BF16>(a, st);
+    return launch_bf16_tile<64, 64, 2, 2, 2, A_BF16, OUT_BF16>(a, st);
+}
+
+// A: fp32 [M][lda] (a_bf16 = 0) or bf16 [M][lda]; W: bf16 [N][K]; C: fp32 or bf16 [M][ldc]
+int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st) {
+    PIPS_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm_bf16: empty problem");
+    PIPS_CHECK_ARG(a.K % 64 == 0, "gemm_bf16: K=%d must be a multiple of 64", a.K);
+    PIPS_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0 && a.lda % 8 == 0, "gemm_bf16: N, ldc %% 4 and lda %% 8 required");
+    PIPS_CHECK_ARG((unsigned long long)a.M * (unsigned long long)a.lda < (1ull << 32) &&
+                       (unsigned long long)a.N * (unsigned long long)a.K < (1ull << 32),
+                   "gemm_bf16: operand exceeds 2^32 elements");
+    if (a_bf16) return out_bf16 ? pick_tile<true, true>(a, st) : pick_tile<true, false>(a, st);
+    return out_bf16 ? pick_tile<false, true>(a, st) : pick_tile<false, false>(a, st);
+}
+
+}  // namespace pips

@@ -119,8 +119,8 @@ def mixer_input_build_tiled(pyr, B, H8, W8, ffeats, coords):
     return X
 
 
-def mixer_fwd(arena, X):
-    """X (M,544) -> delta (M/8, 1040)."""
+def mixer_fwd(arena, X, bf16=False):
+    """X (M,544) -> delta (M/8, 1040).  bf16: bf16 MFMA operands in the channel-mix/head GEMMs."""
     lib = _lib.load()
     X = _f32(X)
     M = X.shape[0]
@@ -128,8 +128,8 @@ def mixer_fwd(arena, X):
     nb = lib.pips_mixer_workspace_bytes(M)
     ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
-        _lib.check(lib.pips_mixer_fwd(_lib.ptr(arena), _lib.ptr(X), M, _lib.ptr(delta), _lib.ptr(ws), nb, _stream()),
-                   "pips_mixer_fwd")
+        fn = lib.pips_mixer_fwd_bf16 if bf16 else lib.pips_mixer_fwd
+        _lib.check(fn(_lib.ptr(arena), _lib.ptr(X), M, _lib.ptr(delta), _lib.ptr(ws), nb, _stream()), "pips_mixer_fwd")
     return delta
 
 

@@ -65,6 +65,10 @@ class Pips(nn.Module):
                     node.add_module(p, _Node())
                 node = node._modules[p]
             node.register_parameter(leaf, nn.Parameter(init[name], requires_grad=False))
+        # torch.float32 (default) or torch.bfloat16: operand type of the mixer's channel-mix / head
+        # GEMMs (BASELINE config 3).  Also switched on by an enclosing
+        # ``torch.autocast("cuda", dtype=torch.bfloat16)``, the way the reference would be run in bf16.
+        self.mixer_dtype = torch.float32
         self._names = list(param_table(S).keys())
         self._arena = None
         self._arena_key = None
@@ -79,6 +83,11 @@ class Pips(nn.Module):
             self._arena = ops.pack_weights({k: sd[k] for k in self._names}, device)
             self._arena_key = key
         return self._arena
+
+    def _flags(self):
+        bf16 = self.mixer_dtype == torch.bfloat16 or (
+            torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        return 2 if bf16 else 0                      # PIPS_FLAG_BF16_MIXER
 
     def _workspace(self, lib, dims, device):
         k = (str(device),) + dims
@@ -125,7 +134,7 @@ class Pips(nn.Module):
             vis_e = torch.empty(B, S, N, dtype=f32, device=dev)
             ffeat = torch.empty(B, N, self.latent_dim, dtype=f32, device=dev)
             rc = lib.pips_forward(_lib.ptr(arena), _lib.ptr(rgbs_c), _lib.ptr(xys_c), _lib.ptr(ci), _lib.ptr(fi),
-                                  _lib.ptr(self._times), B, S, H, W, N, int(self.stride), int(iters), 0,
+                                  _lib.ptr(self._times), B, S, H, W, N, int(self.stride), int(iters), self._flags(),
                                   _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "pips_forward")
@@ -203,7 +212,7 @@ class Pips(nn.Module):
             ffeat = torch.empty(B, N, self.latent_dim, dtype=f32, device=dev)
             rc = lib.pips_track(_lib.ptr(arena), _lib.ptr(cache.pyr), B, cache.T, H8, W8, _lib.ptr(xys_c), _lib.ptr(ci),
                                 _lib.ptr(fi), _lib.ptr(ws_i), _lib.ptr(self._times), N, int(cache.stride), int(iters),
-                                _lib.ptr(ws), nb, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
+                                self._flags(), _lib.ptr(ws), nb, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "pips_track")
         preds = [trajs[i + 1] for i in range(iters)]

@@ -126,6 +126,25 @@ def test_config2_properties(weights_raw):
     assert torch.equal(preds_p[0], preds[0][:, :, perm.to(DEV)])
 
 
+def test_bf16_mixer_operands_config3_tolerance(weights_tamed):
+    """BASELINE config 3 numerics: bf16 MFMA operands in the mixer.  The reference's own
+    bf16-autocast run differs from its fp32 run by 2.5e-3 .. 1.3e-2 px over 6 iterations on these
+    weights; gate at 2e-2 px against the fp32 oracle."""
+    from oracle import pips_oracle as O
+    xys, rgbs = _config2_inputs(B=2, N=64, H=184, W=248)
+    ref_p, _, ref_vis, _ = O.forward(weights_tamed, xys, rgbs, iters=6, stride=8)
+    m = _model(weights_tamed, 8)
+    m.mixer_dtype = torch.bfloat16
+    preds, _, vis, _, _ = _run(m, xys, rgbs, iters=6)
+    err = [float((a.cpu() - b).abs().max()) for a, b in zip(preds, ref_p)]
+    print("bf16-operand mixer, per-iteration max |dtraj| px:", err)
+    assert max(err) < 2e-2 and max(err) > 1e-5
+    m.mixer_dtype = torch.float32
+    with torch.autocast("cuda", dtype=torch.bfloat16):          # the drop-in switch
+        preds_ac = m(xys.to(DEV), rgbs.to(DEV), iters=6)[0]
+    assert torch.equal(preds_ac[-1], preds[-1])
+
+
 def test_clips_are_independent(weights_tamed):
     """Batch sharding premise: a clip's result does not depend on its batch mates."""
     m = _model(weights_tamed, 8)

@@ -217,6 +217,29 @@ def test_mixer(P, weights_raw, arenas):
     assert float((out - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("P", [32, 256, 2048])
+def test_mixer_bf16_operands(P, weights_raw, arenas):
+    """bf16 MFMA operands (config 3): against the fp32 oracle at bf16-level tolerance, and much
+    closer to an oracle whose big Linear weights/activations are rounded to bf16 the same way."""
+    from pips_amd import ops
+    O = _oracle()
+    g = torch.Generator().manual_seed(P + 1)
+    x = torch.randn(min(P, 256), 8, 519, generator=g)
+    if P > 256:
+        x = x.repeat(P // 256, 1, 1) + 0.01 * torch.randn(P, 8, 519, generator=g)
+    ref = O.mixer(weights_raw, x)
+    X = torch.zeros(P * 8, 544)
+    X[:, :519] = x.reshape(P * 8, 519)
+    out = ops.mixer_fwd(arenas["raw"], X.to(DEV), bf16=True).cpu()
+    out32 = ops.mixer_fwd(arenas["raw"], X.to(DEV)).cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    e_bf16 = float((out - ref).abs().max()) / scale
+    e_f32 = float((out32 - ref).abs().max()) / scale
+    print(f"P={P}: bf16-operand mixer rel err {e_bf16:.2e} (fp32 path {e_f32:.2e})")
+    assert e_f32 < 1e-4
+    assert 1e-5 < e_bf16 < 3e-2          # bf16 operand rounding (2^-9 per product) through 25 GEMMs
+
+
 def test_state_update(weights_raw, arenas):
     from pips_amd import ops
     O = _oracle()
