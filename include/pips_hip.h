@@ -49,6 +49,8 @@ extern "C" {
 
 /* flags of pips_forward / pips_track */
 #define PIPS_FLAG_REUSE_MAPS  1   /* pips_forward: skip the encoder, the workspace already holds the maps */
+#define PIPS_FLAG_BF16_ENCODER 4  /* bf16 MFMA operands in the encoder's 3x3 / 1x1 convolutions (maps, statistics,
+                                     normalisation, resize and the 7x7 stem stay fp32) */
 #define PIPS_FLAG_BF16_MIXER  2   /* bf16 MFMA operands in the channel-mix and head Linear layers (BASELINE
                                      config 3); accumulation, norms, GELU, residual stream, gather stay fp32 */
 
@@ -114,6 +116,9 @@ size_t pips_pyramid_floats(int F, int H, int W, int stride);
 size_t pips_pyramid_offset(int F, int H, int W, int stride, int level);   /* in floats */
 int    pips_encoder_fwd(const void* arena, const float* rgbs, int F, int H, int W, int stride,
                         float* pyramid, void* workspace, size_t workspace_bytes, void* stream);
+
+int    pips_encoder_fwd_bf16(const void* arena, const float* rgbs, int F, int H, int W, int stride,
+                             float* pyramid, void* workspace, size_t workspace_bytes, void* stream);
 
 /* utils.samp.bilinear_sample2d (utils/samp.py:5-78): clamped-index point sample of frame
  * 0 of every clip.  xy (B,N,2) in map pixels -> out (B,N,128). */

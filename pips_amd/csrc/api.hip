@@ -68,6 +68,8 @@ static ArenaLayout build_layout() {
         A.h_w2[d] = take_h((size_t)4 * PIPS_DMIX * PIPS_DMIX);
     }
     A.h_head = take_h((size_t)PIPS_NOUT * PIPS_DMIX);
+    A.h_conv[0] = 0;                                   // the 7x7 stem stays fp32 (VALU kernel)
+    for (int i = 1; i < 22; ++i) A.h_conv[i] = take_h((size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
     A.total_h = hoff;
     return A;
 }
@@ -176,6 +178,8 @@ int pips_repack_weights(const void* const* params, int nparams, void* arena_v, v
         to_h(A.mix[d].w2, A.h_w2[d], (size_t)4 * PIPS_DMIX * PIPS_DMIX);
     }
     to_h(A.w_head, A.h_head, (size_t)PIPS_NOUT * PIPS_DMIX);
+    for (int i = 1; i < 22; ++i)
+        to_h(A.conv[i].w, A.h_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
     PIPS_CHECK_LAUNCH("pips_repack_weights");
     return pi == PIPS_NPARAMS ? PIPS_OK : PIPS_E_ARG;
 }
@@ -193,7 +197,7 @@ int pips_gemm_f32(const float* A, int lda, const float* W, const float* bias, fl
 }
 
 static int conv_nhwc(const float* in, int F, int H, int W, int Cin, const float* wgt, const float* bias, int Cout,
-                     int k, int s, int p, float* out, float* stats, int* tiles, hipStream_t st) {
+                     int k, int s, int p, float* out, float* stats, int* tiles, hipStream_t st, int bf16 = 0) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = in; g.W = wgt; g.bias = bias; g.C = out; g.stats = stats;
@@ -201,7 +205,7 @@ static int conv_nhwc(const float* in, int F, int H, int W, int Cin, const float*
     g.Ho = conv_out(H, k, s, p); g.Wo = conv_out(W, k, s, p);
     g.M = g.Ho * g.Wo; g.N = Cout; g.K = k * k * Cin; g.ldc = Cout; g.epi = EPI_BIAS;
     PIPS_CHECK_ARG(g.Ho > 0 && g.Wo > 0, "conv: empty output");
-    return launch_conv(g, F, tiles, st);
+    return bf16 ? launch_conv_bf16(g, F, tiles, st) : launch_conv(g, F, tiles, st);   // bf16: wgt points at bf16 data
 }
 
 int pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin, const float* wgt, const float* bias,
@@ -273,27 +277,36 @@ int check_geometry(int F, int H, int W, int stride) {
 #define RUN(x) do { int rc__ = (x); if (rc__ != PIPS_OK) return rc__; } while (0)
 
 // conv -> partial stats -> mean/rstd
-int conv_stats(const float* arena, const ConvW& c, const float* in, int F, int H, int W, float* out,
-               float* partial, float* mean_rstd, hipStream_t st) {
+// bf16 operands: the weight pointer is the conv's bf16 copy (ArenaLayout::h_conv), handed over as float*
+const float* conv_w(const float* arena, const ArenaLayout& A, int ci, int bf16) {
+    if (!bf16) return arena + A.conv[ci].w;
+    return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(arena + A.total) + A.h_conv[ci]);
+}
+
+int conv_stats(const float* arena, const ConvW& c, const float* wgt, const float* in, int F, int H, int W, float* out,
+               float* partial, float* mean_rstd, hipStream_t st, int bf16) {
     int tiles = 0;
-    RUN(conv_nhwc(in, F, H, W, c.cin, arena + c.w, arena + c.b, c.cout, c.k, c.stride, c.pad, out, partial, &tiles, st));
+    RUN(conv_nhwc(in, F, H, W, c.cin, wgt, arena + c.b, c.cout, c.k, c.stride, c.pad, out, partial, &tiles, st, bf16));
     const int Ho = conv_out(H, c.k, c.stride, c.pad), Wo = conv_out(W, c.k, c.stride, c.pad);
     return launch_inorm_finalize(partial, F, tiles, c.cout, Ho * Wo, mean_rstd, st);
 }
 
 // ResidualBlock.forward, nets/pips.py:173-181
 int res_block(const float* arena, const ArenaLayout& A, int& ci, bool down, const float* x, int F, int H, int W,
-              float* ws, const EncPlan& P, float* out, hipStream_t st) {
+              float* ws, const EncPlan& P, float* out, hipStream_t st, int bf16) {
+    const float* w1 = conv_w(arena, A, ci, bf16);
     const ConvW& c1 = A.conv[ci++];
+    const float* w2 = conv_w(arena, A, ci, bf16);
     const ConvW& c2 = A.conv[ci++];
     const int Ho = conv_out(H, 3, c1.stride, 1), Wo = conv_out(W, 3, c1.stride, 1);
     float* raw = ws + P.raw; float* mid = ws + P.mid;
-    RUN(conv_stats(arena, c1, x, F, H, W, raw, ws + P.partial, ws + P.st_a, st));
+    RUN(conv_stats(arena, c1, w1, x, F, H, W, raw, ws + P.partial, ws + P.st_a, st, bf16));
     RUN(launch_inorm_apply(raw, ws + P.st_a, nullptr, nullptr, mid, F, Ho * Wo, c1.cout, st));
-    RUN(conv_stats(arena, c2, mid, F, Ho, Wo, raw, ws + P.partial, ws + P.st_a, st));
+    RUN(conv_stats(arena, c2, w2, mid, F, Ho, Wo, raw, ws + P.partial, ws + P.st_a, st, bf16));
     if (down) {
+        const float* wd = conv_w(arena, A, ci, bf16);
         const ConvW& cd = A.conv[ci++];
-        RUN(conv_stats(arena, cd, x, F, H, W, ws + P.ds, ws + P.partial2, ws + P.st_b, st));
+        RUN(conv_stats(arena, cd, wd, x, F, H, W, ws + P.ds, ws + P.partial2, ws + P.st_b, st, bf16));
         RUN(launch_inorm_apply(raw, ws + P.st_a, ws + P.ds, ws + P.st_b, out, F, Ho * Wo, c2.cout, st));
     } else {
         RUN(launch_inorm_apply(raw, ws + P.st_a, x, nullptr, out, F, Ho * Wo, c2.cout, st));
@@ -324,8 +337,23 @@ size_t pips_pyramid_offset(int F, int H, int W, int stride, int level) {
     return n;
 }
 
+static int encoder_impl(const void* arena_v, const float* rgbs, int F, int H, int W, int stride, float* pyramid,
+                        void* workspace, size_t workspace_bytes, void* stream, int bf16);
+
 int pips_encoder_fwd(const void* arena_v, const float* rgbs, int F, int H, int W, int stride, float* pyramid,
                      void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_impl(arena_v, rgbs, F, H, W, stride, pyramid, workspace, workspace_bytes, stream, 0);
+}
+
+int pips_encoder_fwd_bf16(const void* arena_v, const float* rgbs, int F, int H, int W, int stride, float* pyramid,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_impl(arena_v, rgbs, F, H, W, stride, pyramid, workspace, workspace_bytes, stream, 1);
+}
+
+// bf16 != 0: bf16 MFMA operands in the 21 3x3 / 1x1 convolutions (maps stay fp32 in memory and are
+// rounded as they are staged; statistics, normalisation, resize and the 7x7 stem stay fp32)
+static int encoder_impl(const void* arena_v, const float* rgbs, int F, int H, int W, int stride, float* pyramid,
+                        void* workspace, size_t workspace_bytes, void* stream, int bf16) {
     PIPS_CHECK_ARG(arena_v && rgbs && pyramid && workspace, "encoder: null pointer");
     RUN(check_geometry(F, H, W, stride));
     const EncPlan P = plan_encoder(F, H, W, stride);
@@ -351,9 +379,9 @@ int pips_encoder_fwd(const void* arena_v, const float* rgbs, int F, int H, int W
     int Hc = P.Hs[0], Wc = P.Ws[0];
     for (int l = 0; l < 4; ++l) {
         const bool down = l > 0;
-        RUN(res_block(arena, A, ci, down, x, F, Hc, Wc, ws, P, ws + P.xb, st));
+        RUN(res_block(arena, A, ci, down, x, F, Hc, Wc, ws, P, ws + P.xb, st, bf16));
         Hc = P.Hs[l]; Wc = P.Ws[l];
-        RUN(res_block(arena, A, ci, false, ws + P.xb, F, Hc, Wc, ws, P, ws + P.outs[l], st));
+        RUN(res_block(arena, A, ci, false, ws + P.xb, F, Hc, Wc, ws, P, ws + P.outs[l], st, bf16));
         x = ws + P.outs[l];
     }
     // resize a,b,c,d to (H//stride, W//stride) and concatenate (:269-273)
@@ -362,11 +390,13 @@ int pips_encoder_fwd(const void* arena_v, const float* rgbs, int F, int H, int W
     for (int l = 0, coff = 0; l < 4; coff += ch[l], ++l)
         RUN(launch_resize_into(ws + P.outs[l], F, P.Hs[l], P.Ws[l], ch[l], ws + P.cat, H8, W8, 416, coff, st));
     // conv2 + norm2 + relu + conv3 (:273-276)
+    const float* wc2 = conv_w(arena, A, ci, bf16);
     const ConvW& c2 = A.conv[ci++];
+    const float* wc3 = conv_w(arena, A, ci, bf16);
     const ConvW& c3 = A.conv[ci++];
-    RUN(conv_stats(arena, c2, ws + P.cat, F, H8, W8, ws + P.raw, ws + P.partial, ws + P.st_a, st));
+    RUN(conv_stats(arena, c2, wc2, ws + P.cat, F, H8, W8, ws + P.raw, ws + P.partial, ws + P.st_a, st, bf16));
     RUN(launch_inorm_apply(ws + P.raw, ws + P.st_a, nullptr, nullptr, ws + P.mid, F, H8 * W8, 256, st));
-    RUN(conv_nhwc(ws + P.mid, F, H8, W8, 256, arena + c3.w, arena + c3.b, 128, 1, 1, 0, pyramid, nullptr, nullptr, st));
+    RUN(conv_nhwc(ws + P.mid, F, H8, W8, 256, wc3, arena + c3.b, 128, 1, 1, 0, pyramid, nullptr, nullptr, st, bf16));
     // CorrBlock.__init__ pyramid (:346-352)
     int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
     pyramid_dims(H, W, stride, lh, lw);
@@ -654,8 +684,9 @@ int pips_forward(const void* arena, const float* rgbs, const float* xys, const f
     float* ws = (float*)workspace;
     float* pyramid = ws + P.pyramid;
     if (!(flags & PIPS_FLAG_REUSE_MAPS))
-        RUN(pips_encoder_fwd(arena, rgbs, B * S, H, W, stride, pyramid, ws + P.enc,
-                             pips_encoder_workspace_bytes(B * S, H, W, stride), stream));
+        RUN(encoder_impl(arena, rgbs, B * S, H, W, stride, pyramid, ws + P.enc,
+                         pips_encoder_workspace_bytes(B * S, H, W, stride), stream,
+                         (flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0));
     return pips_track(arena, pyramid, B, S, H / stride, W / stride, xys, coords_init, feat_init, nullptr, times, N,
                       stride, iters, flags, ws + P.track, plan_track(B, N).total * sizeof(float), out_trajs, out_vis,
                       out_ffeat0, stream);

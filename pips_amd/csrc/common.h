@@ -79,6 +79,7 @@ int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
 int conv_tiles_m(int rows_per_frame, int Cout, int frames);  // tile count launch_conv will use
 // bf16-operand GEMM (gemm_bf16.hip): A fp32 or bf16, W bf16, C fp32 or bf16; pointers passed as float*
 int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
+int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
 
 // ---------------------------------------------------------------- weight arena
 // Offsets in floats into the packed arena (see api.hip: build_layout()).
@@ -93,7 +94,7 @@ struct ArenaLayout {
     size_t total;            // floats (fp32 section)
     // bf16 copies of the big Linear weights for the bf16-operand mixer, in ushort units from
     // the end of the fp32 section (arena + total)
-    size_t h_w1[PIPS_DEPTH], h_w2[PIPS_DEPTH], h_head, total_h;
+    size_t h_w1[PIPS_DEPTH], h_w2[PIPS_DEPTH], h_head, h_conv[22], total_h;
 };
 const ArenaLayout& arena_layout();
 

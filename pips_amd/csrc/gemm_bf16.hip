@@ -25,10 +25,15 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float4& lo, const float4& hi)
     return *reinterpret_cast<uint4*>(&b);
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool A_BF16, bool OUT_BF16>
+// CONV: implicit-GEMM convolution on an NHWC fp32 map (zero padding, per-frame m-tiling, the
+// instance-norm {sum,sumsq} partials from the fp32 accumulators) -- same contract as the fp32
+// conv of gemm.hip, with bf16 operands.  BKE = K elements per staged block per wave group: 64,
+// or 32 for Cin = 96 / 416 so that a block never straddles a filter tap.
+template <int BM, int BN, int WGM, int WGN, int KS, bool A_BF16, bool OUT_BF16, int BKE = 64, bool CONV = false>
 __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int NT = WGM * WGN * KS * 64;
-    constexpr int BKB = 64 * KS;                    // K elements staged per iteration
+    constexpr int BKB = BKE * KS;                   // K elements staged per iteration
+    static_assert(!CONV || (KS == 1 && !A_BF16 && !OUT_BF16), "conv: fp32 map in, fp32 out, no K split");
     constexpr int LDB = BKB * 2 + 16;               // LDS row stride in BYTES (16-byte pad)
     constexpr int TPR = BKB / 8;                    // loader threads per row (8 elements each)
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -50,14 +55,16 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs
     const int l31 = lane & 31, half = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int lrow = tid / TPR, cg = tid % TPR;
+    const int frame = blockIdx.z;
 
     const float* __restrict__ Af = p.A;                                          // A_BF16 == false
+    if (CONV) Af += (size_t)frame * p.H * p.Win * p.Cin;
     const unsigned short* __restrict__ Ab = reinterpret_cast<const unsigned short*>(p.A);   // A_BF16 == true
     const unsigned short* __restrict__ Wb = reinterpret_cast<const unsigned short*>(p.W);
 
 #define PIPS_PASSES(X) X(0) X(1) X(2) X(3)
 #define PIPS_DECL(i)                                                                     \
-    unsigned a_off##i = 0, b_off##i = 0;                                                 \
+    unsigned a_off##i = 0, b_off##i = 0; int a_hi##i = 0, a_wi##i = 0;                   \
     float4 ra##i##l = make_float4(0.f, 0.f, 0.f, 0.f), ra##i##h = ra##i##l;              \
     uint4 rq##i = make_uint4(0, 0, 0, 0), rb##i = rq##i;
     PIPS_PASSES(PIPS_DECL)
@@ -65,7 +72,13 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs
     if constexpr (i < PA) {                                                              \
         int m_ = m0 + lrow + i * ROWS_PER_PASS;                                          \
         m_ = m_ < p.M ? m_ : p.M - 1;                                                    \
-        a_off##i = (unsigned)m_ * (unsigned)p.lda + cg * 8;                              \
+        if (CONV) {                                                                      \
+            const int ho_ = m_ / p.Wo, wo_ = m_ - ho_ * p.Wo;                            \
+            a_hi##i = ho_ * p.cstride - p.pad;                                           \
+            a_wi##i = wo_ * p.cstride - p.pad;                                           \
+        } else {                                                                         \
+            a_off##i = (unsigned)m_ * (unsigned)p.lda + cg * 8;                          \
+        }                                                                                \
     }                                                                                    \
     if constexpr (i < PB) {                                                              \
         int n_ = n0 + lrow + i * ROWS_PER_PASS;                                          \
@@ -73,6 +86,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs
         b_off##i = (unsigned)n_ * (unsigned)p.K + cg * 8;                                \
     }
     PIPS_PASSES(PIPS_INIT)
+    (void)a_hi0; (void)a_wi0; (void)a_hi1; (void)a_wi1; (void)a_hi2; (void)a_wi2; (void)a_hi3; (void)a_wi3;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -85,13 +99,29 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs
 #define PIPS_LOAD(i)                                                                                 \
     if constexpr (i < PA) {                                                                          \
         if constexpr (A_BF16) rq##i = *reinterpret_cast<const uint4*>(Ab + a_off##i + k0_);          \
-        else {                                                                                       \
+        else if constexpr (CONV) {                                                                   \
+            const int hi_ = a_hi##i + kh_, wi_ = a_wi##i + kw_;                                      \
+            const bool ok_ = (unsigned)hi_ < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.Win;       \
+            const float* src_ = Af + ((size_t)(ok_ ? hi_ : 0) * p.Win + (ok_ ? wi_ : 0)) * p.Cin + c0_ + cg * 8; \
+            const float4 l_ = *reinterpret_cast<const float4*>(src_);                                \
+            const float4 h_ = *reinterpret_cast<const float4*>(src_ + 4);                            \
+            ra##i##l = ok_ ? l_ : make_float4(0.f, 0.f, 0.f, 0.f);                                   \
+            ra##i##h = ok_ ? h_ : make_float4(0.f, 0.f, 0.f, 0.f);                                   \
+        } else {                                                                                     \
             ra##i##l = *reinterpret_cast<const float4*>(Af + a_off##i + k0_);                        \
             ra##i##h = *reinterpret_cast<const float4*>(Af + a_off##i + k0_ + 4);                    \
         }                                                                                            \
     }                                                                                                \
     if constexpr (i < PB) rb##i = *reinterpret_cast<const uint4*>(Wb + b_off##i + k0_);
-#define PIPS_LOAD_TILES(kb_) { const int k0_ = (kb_) * BKB; PIPS_PASSES(PIPS_LOAD) }
+#define PIPS_LOAD_TILES(kb_)                                                                         \
+    {                                                                                                \
+        const int k0_ = (kb_) * BKB;                                                                 \
+        const int tap_ = CONV ? k0_ / p.Cin : 0;          /* Cin % BKE == 0: one tap per block */   \
+        const int c0_ = CONV ? k0_ - tap_ * p.Cin : 0;                                               \
+        const int kh_ = CONV ? tap_ / p.KW : 0, kw_ = CONV ? tap_ - kh_ * p.KW : 0;                  \
+        (void)c0_; (void)kh_; (void)kw_;                                                             \
+        PIPS_PASSES(PIPS_LOAD)                                                                       \
+    }
 #define PIPS_STORE(i)                                                                                \
     if constexpr (i < PA)                                                                            \
         *reinterpret_cast<uint4*>(As_ + (lrow + i * ROWS_PER_PASS) * LDB + cg * 16) =               \
@@ -101,9 +131,9 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs
 #define PIPS_STORE_TILES(buf_) { char* As_ = smem + (buf_) * STAGE; char* Bs_ = As_ + BM * LDB; PIPS_PASSES(PIPS_STORE) }
 #define PIPS_COMPUTE(buf_)                                                                           \
     {                                                                                                \
-        const char* a_frag = smem + (buf_) * STAGE + (wm * WTM + l31) * LDB + ks * 128 + half * 16;  \
-        const char* b_frag = smem + (buf_) * STAGE + BM * LDB + (wn * WTN + l31) * LDB + ks * 128 + half * 16; \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                           \
+        const char* a_frag = smem + (buf_) * STAGE + (wm * WTM + l31) * LDB + ks * (BKE * 2) + half * 16;  \
+        const char* b_frag = smem + (buf_) * STAGE + BM * LDB + (wn * WTN + l31) * LDB + ks * (BKE * 2) + half * 16; \
+        _Pragma("unroll") for (int kk = 0; kk < BKE / 16; ++kk) {                                    \
             uint4 fa[TM], fb[TN];                                                                    \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
                 fa[i] = *reinterpret_cast<const uint4*>(a_frag + i * 32 * LDB + kk * 32);            \
@@ -111,9 +141,12 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs
                 fb[j] = *reinterpret_cast<const uint4*>(b_frag + j * 32 * LDB + kk * 32);            \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                       \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                             \
-                        *reinterpret_cast<const bf16x8*>(&fb[j]), *reinterpret_cast<const bf16x8*>(&fa[i]), \
-                        acc[i][j], 0, 0, 0);                                                         \
+                    acc[i][j] = CONV ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(                      \
+                                           *reinterpret_cast<const bf16x8*>(&fa[i]),                 \
+                                           *reinterpret_cast<const bf16x8*>(&fb[j]), acc[i][j], 0, 0, 0) \
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(                      \
+                                           *reinterpret_cast<const bf16x8*>(&fb[j]),                 \
+                                           *reinterpret_cast<const bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0); \
         }                                                                                            \
     }
 
@@ -165,6 +198,58 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         acc[i][j][r] += red[(((g * (WGM * WGN) + wmn) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane];
+    }
+
+    if (CONV) {
+        // C orientation: col = lane&31, row = (r&3) + 8*(r>>2) + 4*half; fp32 output + column partials
+        float* __restrict__ Cc = p.C + (size_t)frame * p.M * p.ldc;
+        float csum[TN], csq[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            csum[j] = csq[j] = 0.f;
+            const int col = n0 + wn * WTN + j * 32 + l31;
+            const bool col_ok = col < p.N;
+            const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < p.M && col_ok) {
+                        const float v = acc[i][j][r] + bv;
+                        Cc[(size_t)row * p.ldc + col] = v;
+                        csum[j] += v;
+                        csq[j] += v * v;
+                    }
+                }
+        }
+        if (p.stats != nullptr) {
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);        // [WGM][BN][2]
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float s_ = csum[j] + __shfl_xor(csum[j], 32);
+                const float q_ = csq[j] + __shfl_xor(csq[j], 32);
+                if (half == 0) {
+                    const int c = wn * WTN + j * 32 + l31;
+                    red[(wm * BN + c) * 2 + 0] = s_;
+                    red[(wm * BN + c) * 2 + 1] = q_;
+                }
+            }
+            __syncthreads();
+            for (int c = tid; c < BN; c += NT) {
+                float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGM; ++w) { s_ += red[(w * BN + c) * 2 + 0]; q_ += red[(w * BN + c) * 2 + 1]; }
+                const int col = n0 + c;
+                if (col < p.N) {
+                    float* dst = p.stats + (((size_t)frame * gridDim.x + blockIdx.x) * p.N + col) * 2;
+                    dst[0] = s_;
+                    dst[1] = q_;
+                }
+            }
+        }
+        return;
     }
 
     // epilogue on C^T accumulators: MFMA row index = output column n, MFMA column = output row m
@@ -231,6 +316,34 @@ static int pick_tile(const GemmArgs& a, hipStream_t st) {
     if (b128 >= 400) return launch_bf16_tile<128, 128, 2, 2, 1, A_BF16, OUT_BF16>(a, st);
     if (b64 >= 800 || a.K % 128 != 0) return launch_bf16_tile<64, 64, 2, 2, 1, A_BF16, OUT_BF16>(a, st);
     return launch_bf16_tile<64, 64, 2, 2, 2, A_BF16, OUT_BF16>(a, st);
+}
+
+template <int BM, int BN, int BKE>
+static int launch_conv_tile(const GemmArgs& a, int frames, hipStream_t st) {
+    dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), frames);
+    const size_t lds = (size_t)2 * (BM + BN) * (BKE * 2 + 16);
+    auto kern = gemm_bf16_kernel<BM, BN, 2, 2, 1, false, false, BKE, true>;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    PIPS_CHECK_LAUNCH("gemm_bf16_kernel<conv>");
+    return PIPS_OK;
+}
+
+// bf16-operand convolution: NHWC fp32 map, weights bf16 [Cout][kh][kw][Cin]; raw fp32 output
+// + instance-norm partials exactly like launch_conv.  Cout = 96 rides a 128-wide tile (the
+// idle quarter costs nothing at the bf16 matrix rate).
+int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) {
+    PIPS_CHECK_ARG(a.Cin % 32 == 0 && a.K == a.KH * a.KW * a.Cin, "conv_bf16: Cin %% 32, K = kh*kw*Cin");
+    const bool k64 = a.Cin % 64 == 0;
+    const int bn = a.N <= 64 ? 64 : 128;
+    const long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.N, bn) * frames;
+    const int bm = blocks128 >= 512 ? 128 : 64;
+    if (tiles_m) *tiles_m = cdiv(a.M, bm);
+    if (bm == 128) {
+        if (bn == 128) return k64 ? launch_conv_tile<128, 128, 64>(a, frames, st) : launch_conv_tile<128, 128, 32>(a, frames, st);
+        return k64 ? launch_conv_tile<128, 64, 64>(a, frames, st) : launch_conv_tile<128, 64, 32>(a, frames, st);
+    }
+    if (bn == 128) return k64 ? launch_conv_tile<64, 128, 64>(a, frames, st) : launch_conv_tile<64, 128, 32>(a, frames, st);
+    return k64 ? launch_conv_tile<64, 64, 64>(a, frames, st) : launch_conv_tile<64, 64, 32>(a, frames, st);
 }
 
 // A: fp32 [M][lda] (a_bf16 = 0) or bf16 [M][lda]; W: bf16 [N][K]; C: fp32 or bf16 [M][ldc]

@@ -61,8 +61,8 @@ def pyramid_levels(pyr: torch.Tensor, F: int, H: int, W: int, stride: int):
     return out
 
 
-def encoder_fwd(arena, rgbs, stride):
-    """rgbs (F,3,H,W) 0..255 -> packed channel-last pyramid buffer."""
+def encoder_fwd(arena, rgbs, stride, bf16=False):
+    """rgbs (F,3,H,W) 0..255 -> packed channel-last pyramid buffer.  bf16: bf16 conv operands."""
     lib = _lib.load()
     rgbs = _f32(rgbs)
     F, _, H, W = rgbs.shape
@@ -70,8 +70,9 @@ def encoder_fwd(arena, rgbs, stride):
         pyr = torch.empty(lib.pips_pyramid_floats(F, H, W, stride), dtype=torch.float32, device=rgbs.device)
         nb = lib.pips_encoder_workspace_bytes(F, H, W, stride)
         ws = torch.empty(nb // 4, dtype=torch.float32, device=rgbs.device)
-        _lib.check(lib.pips_encoder_fwd(_lib.ptr(arena), _lib.ptr(rgbs), F, H, W, stride, _lib.ptr(pyr),
-                                        _lib.ptr(ws), nb, _stream()), "pips_encoder_fwd")
+        fn = lib.pips_encoder_fwd_bf16 if bf16 else lib.pips_encoder_fwd
+        _lib.check(fn(_lib.ptr(arena), _lib.ptr(rgbs), F, H, W, stride, _lib.ptr(pyr), _lib.ptr(ws), nb, _stream()),
+                   "pips_encoder_fwd")
     return pyr
 
 

@@ -69,6 +69,7 @@ class Pips(nn.Module):
         # GEMMs (BASELINE config 3).  Also switched on by an enclosing
         # ``torch.autocast("cuda", dtype=torch.bfloat16)``, the way the reference would be run in bf16.
         self.mixer_dtype = torch.float32
+        self.encoder_dtype = torch.float32          # same switch for the encoder's 3x3 / 1x1 convolutions
         self._names = list(param_table(S).keys())
         self._arena = None
         self._arena_key = None
@@ -85,9 +86,9 @@ class Pips(nn.Module):
         return self._arena
 
     def _flags(self):
-        bf16 = self.mixer_dtype == torch.bfloat16 or (
-            torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
-        return 2 if bf16 else 0                      # PIPS_FLAG_BF16_MIXER
+        ac = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        return (2 if ac or self.mixer_dtype == torch.bfloat16 else 0) | \
+               (4 if ac or self.encoder_dtype == torch.bfloat16 else 0)   # PIPS_FLAG_BF16_MIXER | _ENCODER
 
     def _workspace(self, lib, dims, device):
         k = (str(device),) + dims
@@ -166,14 +167,15 @@ class Pips(nn.Module):
         with torch.cuda.device(dev):
             arena = self._packed(dev)
             frames = rgbs.contiguous().to(torch.float32).reshape(F, 3, H, W)
+            eb = bool(self._flags() & 4)
             if F <= frames_per_pass:
-                pyr = ops.encoder_fwd(arena, frames, st)
+                pyr = ops.encoder_fwd(arena, frames, st, bf16=eb)
             else:
                 pyr = torch.empty(lib.pips_pyramid_floats(F, H, W, st), dtype=torch.float32, device=dev)
                 dst = ops.pyramid_levels(pyr, F, H, W, st)
                 for f0 in range(0, F, frames_per_pass):
                     f1 = min(F, f0 + frames_per_pass)
-                    part = ops.encoder_fwd(arena, frames[f0:f1], st)
+                    part = ops.encoder_fwd(arena, frames[f0:f1], st, bf16=eb)
                     for d, p in zip(dst, ops.pyramid_levels(part, f1 - f0, H, W, st)):
                         d[f0:f1].copy_(p)
         return FeatureCache(pyr, B, T, H, W, st)

@@ -139,7 +139,12 @@ def test_bf16_mixer_operands_config3_tolerance(weights_tamed):
     err = [float((a.cpu() - b).abs().max()) for a, b in zip(preds, ref_p)]
     print("bf16-operand mixer, per-iteration max |dtraj| px:", err)
     assert max(err) < 2e-2 and max(err) > 1e-5
-    m.mixer_dtype = torch.float32
+    m.encoder_dtype = torch.bfloat16                             # + bf16 conv operands
+    preds, _, vis, _, _ = _run(m, xys, rgbs, iters=6)
+    err = [float((a.cpu() - b).abs().max()) for a, b in zip(preds, ref_p)]
+    print("bf16-operand mixer + encoder, per-iteration max |dtraj| px:", err)
+    assert max(err) < 2e-2
+    m.mixer_dtype = m.encoder_dtype = torch.float32
     with torch.autocast("cuda", dtype=torch.bfloat16):          # the drop-in switch
         preds_ac = m(xys.to(DEV), rgbs.to(DEV), iters=6)[0]
     assert torch.equal(preds_ac[-1], preds[-1])

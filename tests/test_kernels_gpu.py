@@ -108,6 +108,22 @@ def test_encoder_pyramid(H, W, stride, weights_raw, arenas):
         assert err < 2e-4, f"level {l}: {err}"
 
 
+def test_encoder_bf16_operands(weights_raw, arenas):
+    """bf16 conv operands (config 3): maps within bf16-level error of the fp32 oracle."""
+    from pips_amd import ops
+    O = _oracle()
+    g = torch.Generator().manual_seed(3)
+    rgbs = torch.randint(0, 256, (8, 3, 128, 160), generator=g).float()
+    fm = O.encoder(weights_raw, 2 * (rgbs / 255.0) - 1.0, 8)
+    pyr = ops.encoder_fwd(arenas["raw"], rgbs.to(DEV), 8, bf16=True)
+    got = ops.pyramid_levels(pyr, 8, 128, 160, 8)[0].cpu()
+    ref = fm.permute(0, 2, 3, 1)
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    rms = float(((got - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+    print(f"bf16-operand encoder: max rel err {rel:.2e}, rms rel err {rms:.2e}")
+    assert 1e-5 < rel < 5e-2 and rms < 3e-2           # 21 convs x 2^-9 operand rounding: ~1.5 % rms
+
+
 # ----------------------------------------------------------------------------- tracker stages
 def _random_state(B, N, H8, W8, seed=5, spread=1.0):
     g = torch.Generator().manual_seed(seed)
