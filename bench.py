@@ -145,7 +145,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-profile", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3),
+                    help="2 (default, the headline: B=1/GPU fp32) or 3 (B=8/GPU, bf16 MFMA operands)")
     args = ap.parse_args()
+    global B_PER_GPU
+    if args.config == 3:
+        B_PER_GPU = 8
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,6 +165,8 @@ def main():
 
     from pips_amd import Pips, dist as pdist
     model = Pips(S=S, stride=STRIDE).to(device).eval()               # seeded random init (seed 0)
+    if args.config == 3:
+        model.mixer_dtype = model.encoder_dtype = torch.bfloat16     # BASELINE configs[2]
     xys, rgbs = make_inputs(rank, device)
 
     def step():
@@ -197,13 +204,15 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.config == 2 else "bf16 MFMA operands, fp32 accumulate/state",
         "data": "synthetic (uniform 0..255 frames, uniform in-bounds queries, seeded random-init weights)",
-        "config": {"workload": "BASELINE configs[1]: B=1/GPU S=8 368x496 N=256 I=6 fp32 stride 8, encoder included, "
-                               "inputs resident in HBM",
+        "config": {"workload": ("BASELINE configs[1]: B=1/GPU S=8 368x496 N=256 I=6 fp32 stride 8, encoder included, "
+                                "inputs resident in HBM") if args.config == 2 else
+                               ("BASELINE configs[2]: B=8/GPU S=8 368x496 N=256 I=6 bf16 operands stride 8, encoder "
+                                "included, inputs resident in HBM"),
                    "clips_per_gpu": B_PER_GPU, "parallelism": f"clip-sharded x{world}"},
     }
-    if rank == 0 and not args.no_stage_profile:
+    if rank == 0 and not args.no_stage_profile and args.config == 2:
         stages, kern, gather = stage_profile(model, xys, rgbs, device)
         dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
         # HBM-side bytes per launch of that kernel from the committed PMC passes (separate rocprofv3
@@ -226,7 +235,7 @@ def main():
         res["stages_ms"] = stages
         flop_per_update = 72.2e6
         res["forward_mfma_frac"] = res["value"] / world * flop_per_update / (PEAK_F32_MFMA_TF * 1e12)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(res), flush=True)
