@@ -103,6 +103,26 @@ def test_config2_against_oracle_tamed(weights_tamed):
         assert float((a.cpu() - b).abs().max()) < TOL_PX
 
 
+@pytest.mark.parametrize("B,N,H,W,stride,iters", [
+    (1, 16, 360, 640, 4, 2),      # BASELINE configs[0] geometry: demo.py frames, stride 4, 4x4 grid, I=2
+    (3, 1, 128, 168, 8, 2),       # a single particle per clip, odd batch
+    (1, 67, 135, 203, 8, 3),      # sizes that are multiples of nothing (floor everywhere)
+    (2, 130, 200, 328, 4, 2),     # stride 4, N not a multiple of 64
+])
+def test_shapes_against_oracle_tamed(B, N, H, W, stride, iters, weights_tamed):
+    from oracle import pips_oracle as O
+    xys, rgbs = _config2_inputs(B=B, N=N, H=H, W=W, seed=3)
+    if (B, N) == (1, 16):          # demo.py:32-36 grid
+        gy, gx = torch.meshgrid(torch.linspace(8, H - 8, 4), torch.linspace(8, W - 8, 4), indexing="ij")
+        xys = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1).unsqueeze(0)
+    ref_p, _, ref_vis, ref_ff = O.forward(weights_tamed, xys, rgbs, iters=iters, stride=stride)
+    preds, _, vis, ffeat, _ = _run(_model(weights_tamed, stride), xys, rgbs, iters=iters)
+    err = max(float((a.cpu() - b).abs().max()) for a, b in zip(preds, ref_p))
+    assert err < TOL_PX, err
+    assert float((vis.cpu() - ref_vis).abs().max()) < TOL_PX
+    assert float((ffeat.cpu() - ref_ff).abs().max()) < 2e-4
+
+
 def test_config2_properties(weights_raw):
     m = _model(weights_raw, 8)
     xys, rgbs = _config2_inputs()
