@@ -51,6 +51,8 @@ extern "C" {
 #define PIPS_FLAG_REUSE_MAPS  1   /* pips_forward: skip the encoder, the workspace already holds the maps */
 #define PIPS_FLAG_BF16_ENCODER 4  /* bf16 MFMA operands in the encoder's 3x3 / 1x1 convolutions (maps, statistics,
                                      normalisation, resize and the 7x7 stem stay fp32) */
+#define PIPS_FLAG_RGB_U8      8   /* rgbs points at uint8 (B,S,3,H,W) frames instead of float: same values, a
+                                     quarter of the input bytes (the decoded frames of demo.py:136-144) */
 #define PIPS_FLAG_BF16_MIXER  2   /* bf16 MFMA operands in the channel-mix and head Linear layers (BASELINE
                                      config 3); accumulation, norms, GELU, residual stream, gather stay fp32 */
 
@@ -119,6 +121,9 @@ int    pips_encoder_fwd(const void* arena, const float* rgbs, int F, int H, int 
 
 int    pips_encoder_fwd_bf16(const void* arena, const float* rgbs, int F, int H, int W, int stride,
                              float* pyramid, void* workspace, size_t workspace_bytes, void* stream);
+/* general form: flags = PIPS_FLAG_BF16_ENCODER | PIPS_FLAG_RGB_U8 */
+int    pips_encoder_fwd_ex(const void* arena, const void* rgbs, int F, int H, int W, int stride, int flags,
+                           float* pyramid, void* workspace, size_t workspace_bytes, void* stream);
 
 /* utils.samp.bilinear_sample2d (utils/samp.py:5-78): clamped-index point sample of frame
  * 0 of every clip.  xy (B,N,2) in map pixels -> out (B,N,128). */

@@ -337,8 +337,8 @@ size_t pips_pyramid_offset(int F, int H, int W, int stride, int level) {
     return n;
 }
 
-static int encoder_impl(const void* arena_v, const float* rgbs, int F, int H, int W, int stride, float* pyramid,
-                        void* workspace, size_t workspace_bytes, void* stream, int bf16);
+static int encoder_impl(const void* arena_v, const void* rgbs, int F, int H, int W, int stride, float* pyramid,
+                        void* workspace, size_t workspace_bytes, void* stream, int mode);
 
 int pips_encoder_fwd(const void* arena_v, const float* rgbs, int F, int H, int W, int stride, float* pyramid,
                      void* workspace, size_t workspace_bytes, void* stream) {
@@ -350,10 +350,18 @@ int pips_encoder_fwd_bf16(const void* arena_v, const float* rgbs, int F, int H, 
     return encoder_impl(arena_v, rgbs, F, H, W, stride, pyramid, workspace, workspace_bytes, stream, 1);
 }
 
-// bf16 != 0: bf16 MFMA operands in the 21 3x3 / 1x1 convolutions (maps stay fp32 in memory and are
-// rounded as they are staged; statistics, normalisation, resize and the 7x7 stem stay fp32)
-static int encoder_impl(const void* arena_v, const float* rgbs, int F, int H, int W, int stride, float* pyramid,
-                        void* workspace, size_t workspace_bytes, void* stream, int bf16) {
+int pips_encoder_fwd_ex(const void* arena_v, const void* rgbs, int F, int H, int W, int stride, int flags,
+                        float* pyramid, void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_impl(arena_v, rgbs, F, H, W, stride, pyramid, workspace, workspace_bytes, stream,
+                        ((flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0) | ((flags & PIPS_FLAG_RGB_U8) ? 2 : 0));
+}
+
+// mode bit0: bf16 MFMA operands in the 21 3x3 / 1x1 convolutions (maps stay fp32 in memory and are
+// rounded as they are staged; statistics, normalisation, resize and the 7x7 stem stay fp32);
+// mode bit1: rgbs is uint8 (B,S,3,H,W) instead of float
+static int encoder_impl(const void* arena_v, const void* rgbs, int F, int H, int W, int stride, float* pyramid,
+                        void* workspace, size_t workspace_bytes, void* stream, int mode) {
+    const int bf16 = mode & 1;
     PIPS_CHECK_ARG(arena_v && rgbs && pyramid && workspace, "encoder: null pointer");
     RUN(check_geometry(F, H, W, stride));
     const EncPlan P = plan_encoder(F, H, W, stride);
@@ -368,7 +376,7 @@ static int encoder_impl(const void* arena_v, const float* rgbs, int F, int H, in
 
     // stem: conv1 + norm1 + relu (nets/pips.py:251-253)
     int tiles = 0;
-    RUN(launch_stem(rgbs, arena + A.conv[0].w, arena + A.conv[0].b, ws + P.raw, ws + P.partial, F, H, W, P.Hs[0],
+    RUN(launch_stem(rgbs, (mode & 2) ? 1 : 0, arena + A.conv[0].w, arena + A.conv[0].b, ws + P.raw, ws + P.partial, F, H, W, P.Hs[0],
                     P.Ws[0], &tiles, st));
     RUN(launch_inorm_finalize(ws + P.partial, F, tiles, 64, P.Hs[0] * P.Ws[0], ws + P.st_a, st));
     RUN(launch_inorm_apply(ws + P.raw, ws + P.st_a, nullptr, nullptr, ws + P.xa, F, P.Hs[0] * P.Ws[0], 64, st));
@@ -686,7 +694,7 @@ int pips_forward(const void* arena, const float* rgbs, const float* xys, const f
     if (!(flags & PIPS_FLAG_REUSE_MAPS))
         RUN(encoder_impl(arena, rgbs, B * S, H, W, stride, pyramid, ws + P.enc,
                          pips_encoder_workspace_bytes(B * S, H, W, stride), stream,
-                         (flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0));
+                         ((flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0) | ((flags & PIPS_FLAG_RGB_U8) ? 2 : 0)));
     return pips_track(arena, pyramid, B, S, H / stride, W / stride, xys, coords_init, feat_init, nullptr, times, N,
                       stride, iters, flags, ws + P.track, plan_track(B, N).total * sizeof(float), out_trajs, out_vis,
                       out_ffeat0, stream);

@@ -102,7 +102,7 @@ const ArenaLayout& arena_layout();
 struct MapDims { int H, W; };
 inline int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
 
-int launch_stem(const float* rgbs, const float* w, const float* bias, float* out, float* stats,
+int launch_stem(const void* rgbs, int rgb_u8, const float* w, const float* bias, float* out, float* stats,
                 int F, int H, int W, int Ho, int Wo, int* tiles_m, hipStream_t st);
 int stem_tiles_m(int rows_per_frame);
 int launch_inorm_finalize(const float* partial, int F, int tiles, int C, int count, float* mean_rstd,

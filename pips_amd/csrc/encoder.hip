@@ -15,7 +15,10 @@ namespace pips {
 // every lane one pixel.  Also emits per-(frame, tile, channel) {sum, sumsq} partials.
 constexpr int STEM_TILE = 64;
 
-__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ rgbs,
+// RGB = float (0..255 values, what the reference's callers pass after .float()) or unsigned char
+// (the decoded frames themselves: a quarter of the bytes, bit-identical results).
+template <typename RGB>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const RGB* __restrict__ rgbs,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ out,
@@ -29,7 +32,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     const bool ok = m < M;
     const int ho = ok ? m / Wo : 0, wo = ok ? m - (m / Wo) * Wo : 0;
     const int hi0 = ho * 2 - 3, wi0 = wo * 2 - 3;
-    const float* src = rgbs + (size_t)frame * 3 * H * W;
+    const RGB* src = rgbs + (size_t)frame * 3 * H * W;
     const float* wv = w + wave * 16;
 
     float acc[16];
@@ -40,12 +43,12 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         for (int kh = 0; kh < 7; ++kh) {
             const int hi = hi0 + kh;
             const bool hok = ok && (unsigned)hi < (unsigned)H;
-            const float* row = src + ((size_t)ci * H + (hok ? hi : 0)) * W;
+            const RGB* row = src + ((size_t)ci * H + (hok ? hi : 0)) * W;
             // unconditional (clamped) loads of the 7 taps first, select the zero padding after:
             // a branch per tap would serialise the loads behind their own FMAs
             float xr[7];
 #pragma unroll
-            for (int kw = 0; kw < 7; ++kw) xr[kw] = row[min(max(wi0 + kw, 0), W - 1)];
+            for (int kw = 0; kw < 7; ++kw) xr[kw] = (float)row[min(max(wi0 + kw, 0), W - 1)];
 #pragma unroll
             for (int kw = 0; kw < 7; ++kw) {
                 const int wi = wi0 + kw;
@@ -89,12 +92,16 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 
 int stem_tiles_m(int rows_per_frame) { return cdiv(rows_per_frame, STEM_TILE); }
 
-int launch_stem(const float* rgbs, const float* w, const float* bias, float* out, float* stats,
+int launch_stem(const void* rgbs, int rgb_u8, const float* w, const float* bias, float* out, float* stats,
                 int F, int H, int W, int Ho, int Wo, int* tiles_m, hipStream_t st) {
     const int tiles = stem_tiles_m(Ho * Wo);
     if (tiles_m) *tiles_m = tiles;
-    hipLaunchKernelGGL(stem_conv_kernel, dim3(tiles, 1, F), dim3(256), 0, st, rgbs, w, bias, out, stats,
-                       H, W, Ho, Wo);
+    if (rgb_u8)
+        hipLaunchKernelGGL(stem_conv_kernel<unsigned char>, dim3(tiles, 1, F), dim3(256), 0, st,
+                           (const unsigned char*)rgbs, w, bias, out, stats, H, W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(stem_conv_kernel<float>, dim3(tiles, 1, F), dim3(256), 0, st, (const float*)rgbs, w, bias,
+                           out, stats, H, W, Ho, Wo);
     PIPS_CHECK_LAUNCH("stem_conv_kernel");
     return PIPS_OK;
 }

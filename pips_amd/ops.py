@@ -64,15 +64,16 @@ def pyramid_levels(pyr: torch.Tensor, F: int, H: int, W: int, stride: int):
 def encoder_fwd(arena, rgbs, stride, bf16=False):
     """rgbs (F,3,H,W) 0..255 -> packed channel-last pyramid buffer.  bf16: bf16 conv operands."""
     lib = _lib.load()
-    rgbs = _f32(rgbs)
+    u8 = rgbs.dtype == torch.uint8                    # decoded frames go in as they are
+    rgbs = rgbs.contiguous() if u8 else _f32(rgbs)
     F, _, H, W = rgbs.shape
     with torch.cuda.device(rgbs.device):
         pyr = torch.empty(lib.pips_pyramid_floats(F, H, W, stride), dtype=torch.float32, device=rgbs.device)
         nb = lib.pips_encoder_workspace_bytes(F, H, W, stride)
         ws = torch.empty(nb // 4, dtype=torch.float32, device=rgbs.device)
-        fn = lib.pips_encoder_fwd_bf16 if bf16 else lib.pips_encoder_fwd
-        _lib.check(fn(_lib.ptr(arena), _lib.ptr(rgbs), F, H, W, stride, _lib.ptr(pyr), _lib.ptr(ws), nb, _stream()),
-                   "pips_encoder_fwd")
+        flags = (4 if bf16 else 0) | (8 if u8 else 0)     # PIPS_FLAG_BF16_ENCODER | PIPS_FLAG_RGB_U8
+        _lib.check(lib.pips_encoder_fwd_ex(_lib.ptr(arena), _lib.ptr(rgbs), F, H, W, stride, flags, _lib.ptr(pyr),
+                                           _lib.ptr(ws), nb, _stream()), "pips_encoder_fwd_ex")
     return pyr
 
 

@@ -118,7 +118,8 @@ class Pips(nn.Module):
         lib = _lib.load()
         dev = rgbs.device
         f32 = torch.float32
-        rgbs_c = rgbs.contiguous().to(f32)
+        u8 = rgbs.dtype == torch.uint8               # decoded frames (demo.py:136-144) are read as they are
+        rgbs_c = rgbs.contiguous() if u8 else rgbs.contiguous().to(f32)
         xys_c = xys.to(dev).contiguous().to(f32)
         ci = None if coords_init is None else coords_init.to(dev).contiguous().to(f32)
         fi = None if feat_init is None else feat_init.to(dev).contiguous().to(f32)
@@ -135,7 +136,8 @@ class Pips(nn.Module):
             vis_e = torch.empty(B, S, N, dtype=f32, device=dev)
             ffeat = torch.empty(B, N, self.latent_dim, dtype=f32, device=dev)
             rc = lib.pips_forward(_lib.ptr(arena), _lib.ptr(rgbs_c), _lib.ptr(xys_c), _lib.ptr(ci), _lib.ptr(fi),
-                                  _lib.ptr(self._times), B, S, H, W, N, int(self.stride), int(iters), self._flags(),
+                                  _lib.ptr(self._times), B, S, H, W, N, int(self.stride), int(iters),
+                                  self._flags() | (8 if u8 else 0),
                                   _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "pips_forward")
@@ -166,7 +168,8 @@ class Pips(nn.Module):
         F = B * T
         with torch.cuda.device(dev):
             arena = self._packed(dev)
-            frames = rgbs.contiguous().to(torch.float32).reshape(F, 3, H, W)
+            frames = (rgbs.contiguous() if rgbs.dtype == torch.uint8 else rgbs.contiguous().to(torch.float32))
+            frames = frames.reshape(F, 3, H, W)
             eb = bool(self._flags() & 4)
             if F <= frames_per_pass:
                 pyr = ops.encoder_fwd(arena, frames, st, bf16=eb)

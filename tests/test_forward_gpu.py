@@ -170,6 +170,18 @@ def test_bf16_mixer_operands_config3_tolerance(weights_tamed):
     assert torch.equal(preds_ac[-1], preds[-1])
 
 
+def test_uint8_frames_are_bit_identical(weights_raw):
+    """Decoded frames can be handed over as uint8 (PIPS_FLAG_RGB_U8): same values, a quarter of the bytes."""
+    m = _model(weights_raw, 8)
+    xys, rgbs = _config2_inputs(B=2, N=9, H=128, W=160)
+    a = m(xys.to(DEV), rgbs.to(DEV), iters=2, return_feat=True)
+    b = m(xys.to(DEV), rgbs.to(torch.uint8).to(DEV), iters=2, return_feat=True)
+    for x, y in zip(a[0] + [a[2], a[3]], b[0] + [b[2], b[3]]):
+        assert torch.equal(x, y)
+    ca, cb = m.encode(rgbs.to(DEV)), m.encode(rgbs.to(torch.uint8).to(DEV))
+    assert torch.equal(ca.pyr, cb.pyr)
+
+
 def test_clips_are_independent(weights_tamed):
     """Batch sharding premise: a clip's result does not depend on its batch mates."""
     m = _model(weights_tamed, 8)
