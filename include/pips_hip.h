@@ -13,9 +13,10 @@
  *     last error of the calling thread is available from pips_last_error();
  *   - all pointers are DEVICE pointers unless the name ends in _host;
  *   - the caller owns every buffer (inputs, outputs, weight arena, workspace); the
- *     library never allocates, frees or synchronises, and keeps no mutable global state:
- *     calls are re-entrant, stream-ordered on `stream` (a hipStream_t passed as void*)
- *     and safe to capture in a hipGraph;
+ *     library never allocates, frees or synchronises (pips_mixer_fwd_timed excepted), and keeps
+ *     no mutable state between calls beyond idempotent one-time settings (kernel LDS-size
+ *     attributes, PIPS_* tuning environment variables read once): calls are re-entrant,
+ *     stream-ordered on `stream` (a hipStream_t passed as void*) and safe to capture in a hipGraph;
  *   - all tensors are dense fp32 unless stated; "frames" F = B*S; mixer rows are ordered
  *     m = (b*N + n)*S + s ("particle-major"), map levels are channel-last
  *     [F][H_l][W_l][128].

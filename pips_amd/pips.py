@@ -208,16 +208,18 @@ class Pips(nn.Module):
             if self._times is None or self._times.device != dev:
                 self._times = ops.times_table(dev)
             nb = lib.pips_track_workspace_bytes(B, N)
-            key = ("track", str(dev), B, N)
+            # ONE tracker workspace per device, grown on demand: chained tracking calls this with
+            # a different (shrinking) N at every hop
+            key = ("track", str(dev))
             ws = self._ws.get(key)
-            if ws is None:
+            if ws is None or ws.numel() * 4 < nb:
                 ws = self._ws[key] = torch.empty(nb // 4, dtype=f32, device=dev)
             trajs = torch.empty(iters + 1, B, S, N, 2, dtype=f32, device=dev)
             vis_e = torch.empty(B, S, N, dtype=f32, device=dev)
             ffeat = torch.empty(B, N, self.latent_dim, dtype=f32, device=dev)
             rc = lib.pips_track(_lib.ptr(arena), _lib.ptr(cache.pyr), B, cache.T, H8, W8, _lib.ptr(xys_c), _lib.ptr(ci),
                                 _lib.ptr(fi), _lib.ptr(ws_i), _lib.ptr(self._times), N, int(cache.stride), int(iters),
-                                self._flags(), _lib.ptr(ws), nb, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
+                                self._flags(), _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "pips_track")
         preds = [trajs[i + 1] for i in range(iters)]

@@ -33,13 +33,11 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_glds_kernel(Gem
     constexpr int NSTAGE = 3;
     constexpr int LPW = (BM + BN) / 8 / NWB;         // wave-instructions per wave per stage
     static_assert((BM + BN) % (8 * NWB) == 0 && BM % 8 == 0, "loader/tile mismatch");
-    static_assert(KS == 1 || (KS - 1) * BM * BN <= STAGE, "K-split reduction does not fit");
+    static_assert(KS == 1 || (KS - 1) * BM * BN <= NSTAGE * STAGE, "K-split reduction does not fit");
 
-    // one LDS object PER STAGE: hipcc tracks LDS-DMA per object (alias scopes), so fragment reads
-    // of stage kb do not wait for the DMA filling the other stages
-    __shared__ __attribute__((aligned(16))) float st0[STAGE];
-    __shared__ __attribute__((aligned(16))) float st1[STAGE];
-    __shared__ __attribute__((aligned(16))) float st2[STAGE];
+    // Fragment reads are issued from inline asm (ds_read_b128 + hand-counted lgkmcnt): hipcc then
+    // sees no LDS load that could alias an in-flight LDS-DMA and inserts no vmcnt(0) of its own.
+    extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,52 +80,61 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_glds_kernel(Gem
 #define PIPS_ISSUE1(q)                                                                           \
     if constexpr (q < LPW)                                                                       \
         __builtin_amdgcn_global_load_lds((gptr_t)(lsrc##q + koff_), (lptr_t)(ldsb_ + q * 256), 16, 0, 0);
-#define PIPS_ISSUE(kb_, stage_)                                                                  \
+#define PIPS_ISSUE(kb_, buf_)                                                                    \
     {                                                                                            \
         const size_t koff_ = (size_t)(kb_) * (32 * KS);                                          \
-        float* ldsb_ = stage_ + ldst;                                                            \
+        float* ldsb_ = smem + (buf_) * STAGE + ldst;                                             \
         PIPS_Q(PIPS_ISSUE1)                                                                      \
     }
 
-    // fragment addresses: row = tile row + l31, logical slot 2*kk + half, swizzled
+    // fragment byte addresses inside a stage: row = tile row + l31, logical slot 2*kk + half, swizzled
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int sw = (l31 >> 1) & 7;
-    const int a_off = ks * HALF + (wm * WTM + l31) * 32;
-    const int b_off = ks * HALF + BM * 32 + (wn * WTN + l31) * 32;
-
-#define PIPS_STEP(kb_, cur_, nxt2_)                                                              \
-    if ((kb_) < nk) {                                                                            \
-        if ((kb_) + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");           \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
-        __builtin_amdgcn_s_barrier();                                                            \
-        if ((kb_) + 2 < nk) PIPS_ISSUE((kb_) + 2, nxt2_)                                         \
-        const float* ab = cur_ + a_off;                                                          \
-        const float* bb = cur_ + b_off;                                                          \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                       \
-            float4 fa[TM], fb[TN];                                                               \
-            const int off = (((kk * 2 + half) ^ sw) * 4);                                        \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
-                fa[i] = *reinterpret_cast<const float4*>(ab + i * 32 * 32 + off);                \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                       \
-                fb[j] = *reinterpret_cast<const float4*>(bb + j * 32 * 32 + off);                \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                 \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0); \
-                }                                                                                \
-        }                                                                                        \
-    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const unsigned a_byte = lds0 + (ks * HALF + (wm * WTM + l31) * 32) * 4;
+    const unsigned b_byte = lds0 + (ks * HALF + BM * 32 + (wn * WTN + l31) * 32) * 4;
+    unsigned koffb[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koffb[kk] = ((kk * 2 + half) ^ sw) * 16;
 
     const int nk = p.K / (32 * KS);
-    PIPS_ISSUE(0, st0)
-    if (nk > 1) PIPS_ISSUE(1, st1)
-    for (int kb = 0; kb < nk; kb += 3) {
-        PIPS_STEP(kb, st0, st2)
-        PIPS_STEP(kb + 1, st1, st0)
-        PIPS_STEP(kb + 2, st2, st1)
+    PIPS_ISSUE(0, 0)
+    if (nk > 1) PIPS_ISSUE(1, 1)
+    int buf = 0;
+    for (int kb = 0; kb < nk; ++kb) {
+        if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kb + 2 < nk) {
+            const int nb = buf >= 1 ? buf - 1 : NSTAGE - 1;          // buffer of stage kb-1 == (kb+2) % 3
+            PIPS_ISSUE(kb + 2, nb)
+        }
+        const unsigned ab = a_byte + buf * (STAGE * 4), bb = b_byte + buf * (STAGE * 4);
+        f32x4 fa[4][TM], fb[4][TN];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[kk][i]) : "v"(ab + koffb[kk]), "n"(i * 32 * 32 * 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[kk][j]) : "v"(bb + koffb[kk]), "n"(j * 32 * 32 * 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kk][j].x, fa[kk][i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kk][j].y, fa[kk][i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kk][j].z, fa[kk][i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kk][j].w, fa[kk][i].w, acc[i][j], 0, 0, 0);
+                }
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
     }
-#undef PIPS_STEP
 #undef PIPS_ISSUE
 #undef PIPS_ISSUE1
 #undef PIPS_LSRC
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_glds_kernel(Gem
 
     if (KS > 1) {
         __syncthreads();
-        float* red = st0;
+        float* red = smem;
         if (ks > 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -201,8 +208,7 @@ static int launch_glds_tile(const GemmArgs& a, hipStream_t st) {
             raised = true;
         }
     }
-    (void)lds;
-    hipLaunchKernelGGL(kern, grid, block, 0, st, a);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     PIPS_CHECK_LAUNCH("igemm_f32_glds_kernel");
     return PIPS_OK;
 }
