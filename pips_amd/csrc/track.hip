@@ -286,100 +286,144 @@ __device__ __forceinline__ void ln_stats(const float (&x0)[S], const float (&x1)
     for (int t = 0; t < S; ++t) rstd[t] = 1.0f / sqrtf(a[t] * (1.0f / PIPS_DMIX) + 1e-5f);
 }
 
-// LayerNorm statistics of 8 rows x 512 channels held one channel per thread by a 512-thread
-// block: ONE reduction with the parallel (Chan) mean/M2 merge instead of two passes --
-// numerically equivalent to the two-pass form, half the barriers.  Equal counts at every
-// merge: mean = (ma+mb)/2, M2 = M2a + M2b + (mb-ma)^2 * c/2.
-__device__ __forceinline__ void ln_stats512(const float (&x)[S], float (&mean)[S], float (&rstd)[S],
-                                            float (*red)[S][2]) {
-    float m[S], q[S];
-#pragma unroll
-    for (int t = 0; t < S; ++t) { m[t] = x[t]; q[t] = 0.f; }
-#define PIPS_WELFORD_STEP(O, HALF_C)                                              \
-    _Pragma("unroll") for (int t = 0; t < S; ++t) {                               \
-        const float om = __shfl_xor(m[t], (O)), oq = __shfl_xor(q[t], (O));      \
-        const float d = om - m[t];                                                \
-        m[t] = 0.5f * (m[t] + om);                                                \
-        q[t] = (q[t] + oq) + d * d * (HALF_C);                                    \
-    }
-    PIPS_WELFORD_STEP(1, 0.5f) PIPS_WELFORD_STEP(2, 1.0f) PIPS_WELFORD_STEP(4, 2.0f)
-    PIPS_WELFORD_STEP(8, 4.0f) PIPS_WELFORD_STEP(16, 8.0f) PIPS_WELFORD_STEP(32, 16.0f)
-#undef PIPS_WELFORD_STEP
+// The kernel is instruction-bound (PMC: 3.2k VALU instructions per wave in the previous
+// one-channel-per-thread version), so everything is done to cut instruction count: two
+// channels per thread in packed float2 arithmetic (v_pk_fma_f32), wave reductions with DPP
+// row shifts/broadcasts instead of ds_bpermute, cross-wave combination through 32 floats of LDS.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_add(float acc, float src) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false);
+    return acc + __int_as_float(t);
+}
+// sum over the 64 lanes, returned wave-uniform (row_shr 1,2,3 | 4 | 8 | row_bcast15 | row_bcast31 -> lane 63)
+__device__ __forceinline__ float wave_sum(float x) {
+    float s = x;
+    s = dpp_add<0x111, 0xf, 0xf>(s, x);
+    s = dpp_add<0x112, 0xf, 0xf>(s, x);
+    s = dpp_add<0x113, 0xf, 0xf>(s, x);
+    s = dpp_add<0x114, 0xf, 0xe>(s, s);
+    s = dpp_add<0x118, 0xf, 0xc>(s, s);
+    s = dpp_add<0x142, 0xa, 0xf>(s, s);
+    s = dpp_add<0x143, 0xc, 0xf>(s, s);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+}
+
+// sums of 8 per-token values over the 256 threads of the block; red is [S][4 waves]
+__device__ __forceinline__ void block_sum8_dpp(float (&v)[S], float (*red)[4]) {
     const int wave = threadIdx.x >> 6;
+    float w[S];
+#pragma unroll
+    for (int t = 0; t < S; ++t) w[t] = wave_sum(v[t]);
     __syncthreads();                                   // previous readers of red are done
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
-        for (int t = 0; t < S; ++t) { red[wave][t][0] = m[t]; red[wave][t][1] = q[t]; }
+        for (int t = 0; t < S; ++t) red[t][wave] = w[t];
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < S; ++t) {
-        float pm[8], pq[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) { pm[w] = red[w][t][0]; pq[w] = red[w][t][1]; }
-        // 8 -> 4 -> 2 -> 1 groups of 64, 128, 256 channels (written out: keeps pm/pq in registers)
-#define PIPS_MERGE(dst, a_, b_, HALF_C)                                   \
-        { const float d = pm[b_] - pm[a_];                                 \
-          pq[dst] = (pq[a_] + pq[b_]) + d * d * (HALF_C);                  \
-          pm[dst] = 0.5f * (pm[a_] + pm[b_]); }
-        PIPS_MERGE(0, 0, 1, 32.0f) PIPS_MERGE(1, 2, 3, 32.0f) PIPS_MERGE(2, 4, 5, 32.0f) PIPS_MERGE(3, 6, 7, 32.0f)
-        PIPS_MERGE(0, 0, 1, 64.0f) PIPS_MERGE(1, 2, 3, 64.0f)
-        PIPS_MERGE(0, 0, 1, 128.0f)
-#undef PIPS_MERGE
-        mean[t] = pm[0];
-        rstd[t] = 1.0f / sqrtf(pq[0] * (1.0f / PIPS_DMIX) + 1e-5f);
+        const float4 r = *reinterpret_cast<const float4*>(red[t]);
+        v[t] = (r.x + r.y) + (r.z + r.w);
     }
 }
 
-__global__ __launch_bounds__(512) void token_mix_kernel(const float* __restrict__ arena, MixLayerW L,
+// two-pass LayerNorm statistics (mean, then centred squares) of 8 tokens x 512 channels, 2 channels per thread
+__device__ __forceinline__ void ln_stats2(const f2 (&x)[S], float (&mean)[S], float (&rstd)[S], float (*red)[4]) {
+    float a[S];
+#pragma unroll
+    for (int t = 0; t < S; ++t) a[t] = x[t].x + x[t].y;
+    block_sum8_dpp(a, red);
+#pragma unroll
+    for (int t = 0; t < S; ++t) mean[t] = a[t] * (1.0f / PIPS_DMIX);
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        const f2 d = x[t] - mean[t];
+        a[t] = d.x * d.x + d.y * d.y;
+    }
+    block_sum8_dpp(a, red);
+#pragma unroll
+    for (int t = 0; t < S; ++t) rstd[t] = 1.0f / sqrtf(a[t] * (1.0f / PIPS_DMIX) + 1e-5f);
+}
+
+// fast_erf / gelu_exact (common.h) on two values at once: the polynomials run as packed FMAs
+__device__ __forceinline__ f2 gelu_exact2(f2 v) {
+    const f2 x = v * 0.70710678118654752440f;
+    const f2 ax = __builtin_elementwise_abs(x);
+    const f2 t = __builtin_elementwise_min(ax, (f2){4.0f, 4.0f});
+    const f2 u = x * x;
+    f2 p = (f2){-6.218503113e-04f, -6.218503113e-04f};
+    p = p * u + 5.035122391e-03f;
+    p = p * u + -2.679345198e-02f;
+    p = p * u + 1.128251031e-01f;
+    p = p * u + -3.761255443e-01f;
+    p = p * u + 1.128379107e+00f;
+    f2 q = (f2){-8.686167803e-07f, -8.686167803e-07f};
+    q = q * t + 3.125615694e-05f;
+    q = q * t + -4.758332507e-04f;
+    q = q * t + 4.213109612e-03f;
+    q = q * t + -2.493269742e-02f;
+    q = q * t + 1.075836346e-01f;
+    q = q * t + 6.343385577e-01f;
+    q = q * t + 1.128848195e+00f;
+    const f2 e = q * t;
+    f2 erf;
+    erf.x = t.x > 0.875f ? copysignf(1.0f - __expf(-e.x), x.x) : x.x * p.x;
+    erf.y = t.y > 0.875f ? copysignf(1.0f - __expf(-e.y), x.y) : x.y * p.y;
+    return (v * 0.5f) * (erf + 1.0f);
+}
+
+__global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict__ arena, MixLayerW L,
                                                         float* __restrict__ x, float* __restrict__ xn) {
-    __shared__ float red[8][S][2];
+    __shared__ __attribute__((aligned(16))) float red[S][4];
     __shared__ float wsm[32 * 8 + 32 + 8 * 32 + 8];
     const int tid = threadIdx.x;
     // stage the tiny token-MLP weights: w0[32][8], b0[32], w3[8][32], b3[8]
-    if (tid < 256) wsm[tid] = arena[L.tw0 + tid];
-    else wsm[288 + (tid - 256)] = arena[L.tw3 + (tid - 256)];
+    wsm[tid] = arena[L.tw0 + tid];
+    wsm[288 + tid] = arena[L.tw3 + tid];
     if (tid < 32) wsm[256 + tid] = arena[L.tb0 + tid];
     if (tid >= 64 && tid < 72) wsm[544 + (tid - 64)] = arena[L.tb3 + (tid - 64)];
 
-    float* xp = x + (size_t)blockIdx.x * S * PIPS_DMIX;
-    float* xnp = xn + (size_t)blockIdx.x * S * PIPS_DMIX;
-    const int c = tid;
-    float xv[S], mean[S], rstd[S];
+    // thread -> channels 2*tid, 2*tid+1 (one 8-byte access per token row)
+    float* xp = x + (size_t)blockIdx.x * S * PIPS_DMIX + 2 * tid;
+    float* xnp = xn + (size_t)blockIdx.x * S * PIPS_DMIX + 2 * tid;
+    f2 xv[S];
+    float mean[S], rstd[S];
 #pragma unroll
-    for (int t = 0; t < S; ++t) xv[t] = xp[t * PIPS_DMIX + c];
-    const float g1 = arena[L.ln1g + c], be1 = arena[L.ln1b + c];
-    const float g2 = arena[L.ln2g + c], be2 = arena[L.ln2b + c];
-    ln_stats512(xv, mean, rstd, red);        // (its barriers also publish wsm)
+    for (int t = 0; t < S; ++t) xv[t] = *reinterpret_cast<const f2*>(xp + t * PIPS_DMIX);
+    const f2 g1 = *reinterpret_cast<const f2*>(arena + L.ln1g + 2 * tid), be1 = *reinterpret_cast<const f2*>(arena + L.ln1b + 2 * tid);
+    const f2 g2 = *reinterpret_cast<const f2*>(arena + L.ln2g + 2 * tid), be2 = *reinterpret_cast<const f2*>(arena + L.ln2b + 2 * tid);
+    ln_stats2(xv, mean, rstd, red);          // (its barriers also publish wsm)
 
-    float h[S], y[S];
+    f2 h[S], y[S];
 #pragma unroll
     for (int t = 0; t < S; ++t) {
         h[t] = (xv[t] - mean[t]) * rstd[t] * g1 + be1;
-        y[t] = wsm[544 + t];
+        y[t] = (f2){wsm[544 + t], wsm[544 + t]};
     }
-#pragma unroll 8
+#pragma unroll 4
     for (int j = 0; j < 32; ++j) {
-        float u = wsm[256 + j];
+        f2 u = (f2){wsm[256 + j], wsm[256 + j]};
 #pragma unroll
-        for (int t = 0; t < S; ++t) u = fmaf(wsm[j * 8 + t], h[t], u);
-        u = gelu_exact(u);
+        for (int t = 0; t < S; ++t) u = h[t] * wsm[j * 8 + t] + u;
+        u = gelu_exact2(u);
 #pragma unroll
-        for (int t = 0; t < S; ++t) y[t] = fmaf(wsm[288 + t * 32 + j], u, y[t]);
+        for (int t = 0; t < S; ++t) y[t] = u * wsm[288 + t * 32 + j] + y[t];
     }
 #pragma unroll
     for (int t = 0; t < S; ++t) y[t] += xv[t];
 
-    ln_stats512(y, mean, rstd, red);
+    ln_stats2(y, mean, rstd, red);
 #pragma unroll
     for (int t = 0; t < S; ++t) {
-        xp[t * PIPS_DMIX + c] = y[t];
-        xnp[t * PIPS_DMIX + c] = (y[t] - mean[t]) * rstd[t] * g2 + be2;
+        *reinterpret_cast<f2*>(xp + t * PIPS_DMIX) = y[t];
+        *reinterpret_cast<f2*>(xnp + t * PIPS_DMIX) = (y[t] - mean[t]) * rstd[t] * g2 + be2;
     }
 }
 
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
                      hipStream_t st) {
-    hipLaunchKernelGGL(token_mix_kernel, dim3(particles), dim3(512), 0, st, arena, L, x, xn);
+    hipLaunchKernelGGL(token_mix_kernel, dim3(particles), dim3(256), 0, st, arena, L, x, xn);
     PIPS_CHECK_LAUNCH("token_mix_kernel");
     return PIPS_OK;
 }
