@@ -425,6 +425,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         case 4: if (k64) return launch_tile<128, 128, 2, 2, 2, false>(a, 1, st); break;
         case 5: if (k64) return launch_tile<64, 64, 2, 2, 2, false>(a, 1, st); break;
         case 6: if (k64) return launch_tile<128, 64, 2, 2, 2, false>(a, 1, st); break;
+        case 7: return launch_tile<32, 64, 1, 2, 1, false>(a, 1, st);     // measured at M=2048: 57 TF
+        case 8: return launch_tile<64, 32, 2, 1, 1, false>(a, 1, st);     // 56 TF
         default: break;
     }
     // Measured on MI355X (tools/gemm_bench.py): with >= ~2 blocks per CU of 128x128 the big
