@@ -109,17 +109,19 @@ int launch_stem(const void* rgbs, int rgb_u8, const float* w, const float* bias,
 // ------------------------------------------------------------------ instance-norm stats
 // partial [F][tiles][C][2] fp32 -> mean_rstd [F][C][2]; accumulation in fp64.
 // InstanceNorm2d(affine=False, eps=1e-5), biased variance (nets/pips.py:153-157,199-201).
-__global__ __launch_bounds__(256) void inorm_finalize_kernel(const float* __restrict__ partial,
-                                                             int tiles, int C, int count,
-                                                             float* __restrict__ mean_rstd) {
-    __shared__ double red[2][8][32];
+// (a handful of blocks per launch: 32 channels x 32 tile-subsets per block keep the serial
+// part of the tile loop short)
+__global__ __launch_bounds__(1024) void inorm_finalize_kernel(const float* __restrict__ partial,
+                                                              int tiles, int C, int count,
+                                                              float* __restrict__ mean_rstd) {
+    __shared__ double red[2][32][32];
     const int f = blockIdx.y;
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
     const int sub = threadIdx.x >> 5;
     double s = 0.0, q = 0.0;
     if (c < C) {
         const float* p = partial + ((size_t)f * tiles * C + c) * 2;
-        for (int t = sub; t < tiles; t += 8) {
+        for (int t = sub; t < tiles; t += 32) {
             const float2 v = *reinterpret_cast<const float2*>(p + (size_t)t * C * 2);
             s += (double)v.x;
             q += (double)v.y;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void inorm_finalize_kernel(const float* __rest
     if (threadIdx.x < 32 && c < C) {
         s = 0.0; q = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { s += red[0][i][threadIdx.x]; q += red[1][i][threadIdx.x]; }
+        for (int i = 0; i < 32; ++i) { s += red[0][i][threadIdx.x]; q += red[1][i][threadIdx.x]; }
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void inorm_finalize_kernel(const float* __rest
 
 int launch_inorm_finalize(const float* partial, int F, int tiles, int C, int count, float* mean_rstd,
                           hipStream_t st) {
-    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(cdiv(C, 32), F), dim3(256), 0, st, partial, tiles, C,
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(cdiv(C, 32), F), dim3(1024), 0, st, partial, tiles, C,
                        count, mean_rstd);
     PIPS_CHECK_LAUNCH("inorm_finalize_kernel");
     return PIPS_OK;
