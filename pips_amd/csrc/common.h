@@ -53,6 +53,42 @@ __device__ __forceinline__ float gelu_exact(float x) {
     return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+// fast_erf / gelu_exact (common.h) on two values at once: the polynomials run as packed FMAs
+__device__ __forceinline__ f2 gelu_exact2(f2 v) {
+    const f2 x = v * 0.70710678118654752440f;
+    const f2 ax = __builtin_elementwise_abs(x);
+    const f2 t = __builtin_elementwise_min(ax, (f2){4.0f, 4.0f});
+    const f2 u = x * x;
+    f2 p = (f2){-6.218503113e-04f, -6.218503113e-04f};
+    p = p * u + 5.035122391e-03f;
+    p = p * u + -2.679345198e-02f;
+    p = p * u + 1.128251031e-01f;
+    p = p * u + -3.761255443e-01f;
+    p = p * u + 1.128379107e+00f;
+    f2 q = (f2){-8.686167803e-07f, -8.686167803e-07f};
+    q = q * t + 3.125615694e-05f;
+    q = q * t + -4.758332507e-04f;
+    q = q * t + 4.213109612e-03f;
+    q = q * t + -2.493269742e-02f;
+    q = q * t + 1.075836346e-01f;
+    q = q * t + 6.343385577e-01f;
+    q = q * t + 1.128848195e+00f;
+    // branch-free like fast_erf: both arms are evaluated, then selected (hipcc turns a ?: around
+    // the exp into exec-mask branches per element otherwise)
+    const f2 a = (q * t) * -1.44269504088896340736f;             // exp(-q t) = exp2(-q t log2 e)
+    const f2 ex = (f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f2 om = 1.0f - ex;
+    const f2 big = (f2){copysignf(om.x, x.x), copysignf(om.y, x.y)};
+    const f2 sm = x * p;
+    f2 erf;
+    erf.x = t.x > 0.875f ? big.x : sm.x;
+    erf.y = t.y > 0.875f ? big.y : sm.y;
+    return (v * 0.5f) * (erf + 1.0f);
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -74,9 +110,61 @@ struct GemmArgs {
     int H, Win, Cin, Ho, Wo, KH, KW, cstride, pad;
 };
 
+// Epilogue of a plain-GEMM tile that lies wholly inside C (the common case): straight-line code,
+// every bias / residual load issued before the first use, GELU on packed pairs (shared by the
+// fp32 and bf16-operand kernels; OUT_BF16 stores the tile as bf16).  The lane holds
+// C^T: acc[i][j][4g..4g+3] = C[row = i*32 + l31][col = j*32 + 8g + 4*half + 0..3].
+template <int E, bool OUT_BF16, int TM, int TN>
+__device__ __forceinline__ void epilogue_full_tile(const f32x16 (&acc)[TM][TN], const float* __restrict__ bias,
+                                                   const float* __restrict__ R, int ldr, void* __restrict__ Cv,
+                                                   int ldc, int row0, int col0) {
+    float4 b4[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            b4[j][g] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + col0 + j * 32 + 8 * g)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const size_t row = (size_t)(row0 + i * 32);
+        float4 r4[TN][4];
+        if (E == EPI_RESIDUAL) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    r4[j][g] = *reinterpret_cast<const float4*>(R + row * ldr + col0 + j * 32 + 8 * g);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f2 lo = (f2){acc[i][j][4 * g] + b4[j][g].x, acc[i][j][4 * g + 1] + b4[j][g].y};
+                f2 hi = (f2){acc[i][j][4 * g + 2] + b4[j][g].z, acc[i][j][4 * g + 3] + b4[j][g].w};
+                if (E == EPI_GELU) {
+                    lo = gelu_exact2(lo);
+                    hi = gelu_exact2(hi);
+                } else if (E == EPI_RESIDUAL) {
+                    lo += (f2){r4[j][g].x, r4[j][g].y};
+                    hi += (f2){r4[j][g].z, r4[j][g].w};
+                }
+                const size_t o = row * ldc + col0 + j * 32 + 8 * g;
+                if (OUT_BF16) {
+                    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+                    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                    const f32x4_ t = {lo.x, lo.y, hi.x, hi.y};
+                    bf16x4_ ob = __builtin_convertvector(t, bf16x4_);              // hardware RNE
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(Cv) + o) = *reinterpret_cast<uint2*>(&ob);
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + o) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
+    }
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t st);          // plain GEMM, picks a tile
 int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
-int conv_tiles_m(int rows_per_frame, int Cout, int frames);  // tile count launch_conv will use
 // bf16-operand GEMM (gemm_bf16.hip): A fp32 or bf16, W bf16, C fp32 or bf16; pointers passed as float*
 int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
 int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
@@ -99,7 +187,6 @@ struct ArenaLayout {
 const ArenaLayout& arena_layout();
 
 // ---------------------------------------------------------------- encoder pieces (encoder.hip)
-struct MapDims { int H, W; };
 inline int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
 
 int launch_stem(const void* rgbs, int rgb_u8, const float* w, const float* bias, float* out, float* stats,

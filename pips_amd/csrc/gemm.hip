@@ -23,7 +23,6 @@
 
 namespace pips {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 template <int BM, int BN, int WGM, int WGN, int KS, bool CONV>
@@ -65,6 +64,22 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
     }
     const int m0 = bx * BM, n0 = by * BN;
     const int frame = blockIdx.z;
+#ifdef PIPS_GEMM_TRACE
+    // tools/gemm_trace.py: per-block phase timestamps (100 MHz constant clock) for plain GEMMs
+    unsigned long long* tr_ = reinterpret_cast<unsigned long long*>(p.stats) +
+                              8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
+#define PIPS_T(slot) if (!CONV && p.stats != nullptr && tid == 0) tr_[slot] = wall_clock64();
+    if (!CONV && p.stats != nullptr && tid == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tr_[5] = hw; tr_[6] = xcc;
+    }
+#else
+#define PIPS_T(slot)
+#endif
+    PIPS_T(0)
 
     const float* __restrict__ Abase = p.A;
     float* __restrict__ Cbase = p.C;
@@ -194,6 +209,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
     PIPS_LOAD_TILES(0);
     PIPS_STORE_TILES(0);
     __syncthreads();
+    PIPS_T(1)
     int buf = 0;
 #ifdef PIPS_GEMM_ABLATE
     const bool ab_ld = !(p.epi & 0x100), ab_st = !(p.epi & 0x200), ab_bar = !(p.epi & 0x400);
@@ -221,6 +237,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
     }
 #endif
     PIPS_COMPUTE(buf);
+    PIPS_T(2)
 #undef PIPS_LOAD_TILES
 #undef PIPS_STORE_TILES
 #undef PIPS_PASSES_A
@@ -266,6 +283,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
                         acc[i][j][r] += red[(((g * (WGM * WGN) + wmn) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane];
     }
 
+    PIPS_T(3)
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float csum[TN], csq[TN];
 #pragma unroll
@@ -275,6 +293,14 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
     if (!CONV) {
         // transposed accumulators: MFMA row index = output column n, MFMA column = output row m
         const bool vec_ok = (p.ldc & 3) == 0 && (epi != EPI_RESIDUAL || (p.ldr & 3) == 0);
+        if (vec_ok && m0 + BM <= p.M && n0 + BN <= p.N) {
+            const int row0 = m0 + wm * WTM + l31, col0 = n0 + wn * WTN + 4 * half;
+            if (epi == EPI_GELU) epilogue_full_tile<EPI_GELU, false, TM, TN>(acc, p.bias, p.R, p.ldr, Cbase, p.ldc, row0, col0);
+            else if (epi == EPI_RESIDUAL) epilogue_full_tile<EPI_RESIDUAL, false, TM, TN>(acc, p.bias, p.R, p.ldr, Cbase, p.ldc, row0, col0);
+            else epilogue_full_tile<EPI_BIAS, false, TM, TN>(acc, p.bias, p.R, p.ldr, Cbase, p.ldc, row0, col0);
+            PIPS_T(4)
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = m0 + wm * WTM + i * 32 + l31;
@@ -313,24 +339,42 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
                 }
             }
         }
+        PIPS_T(4)
         return;
     }
 
+    // Bias is added to every accumulator BEFORE the (predicated) stores: a bias load first used
+    // inside a predicated block makes hipcc put s_waitcnt vmcnt(0) in front of each store, which
+    // also waits for the previous store's acknowledgement (16 serialized round trips per tile).
+    const bool full_tile = m0 + BM <= p.M && n0 + BN <= p.N;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * WTN + j * 32 + l31;
         const bool col_ok = col < p.N;
-        const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+        const float bv = p.bias != nullptr ? p.bias[col_ok ? col : p.N - 1] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < p.M && col_ok) {
-                    const float v = acc[i][j][r] + bv;
-                    Cbase[(size_t)row * p.ldc + col] = v;
-                    csum[j] += v;
-                    csq[j] += v * v;
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+            const int rbase = m0 + wm * WTM + i * 32 + 4 * half;
+            float* cp = Cbase + (size_t)rbase * p.ldc + col;
+            if (full_tile) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
+                    csum[j] += v[r];
+                    csq[j] += v[r] * v[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M && col_ok) {
+                        cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
+                        csum[j] += v[r];
+                        csq[j] += v[r] * v[r];
+                    }
                 }
             }
         }
@@ -369,6 +413,17 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs
     }
 }
 
+#ifdef PIPS_GEMM_TRACE
+static float* trace_buffer() {
+    static void* buf = nullptr;
+    if (!buf) { (void)hipMalloc(&buf, 8u << 20); (void)hipMemset(buf, 0, 8u << 20); }
+    return reinterpret_cast<float*>(buf);
+}
+extern "C" int pips_trace_read(void* host, size_t bytes) {
+    return (int)hipMemcpy(host, trace_buffer(), bytes, hipMemcpyDeviceToHost);
+}
+#endif
+
 static int swizzle_on() {
     static int v = -1;
     if (v < 0) {
@@ -394,6 +449,9 @@ static int launch_tile(const GemmArgs& a_in, int frames, hipStream_t st) {
             raised = true;
         }
     }
+#ifdef PIPS_GEMM_TRACE
+    if (!CONV) a.stats = trace_buffer();
+#endif
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     PIPS_CHECK_LAUNCH("igemm_f32_kernel");
     return PIPS_OK;
@@ -427,6 +485,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         case 6: if (k64) return launch_tile<128, 64, 2, 2, 2, false>(a, 1, st); break;
         case 7: return launch_tile<32, 64, 1, 2, 1, false>(a, 1, st);     // measured at M=2048: 57 TF
         case 8: return launch_tile<64, 32, 2, 1, 1, false>(a, 1, st);     // 56 TF
+        case 9: if (a.K % 128 == 0) return launch_tile<64, 64, 2, 2, 4, false>(a, 1, st); break;   // down-proj: within 0.5 % of KS=2
         default: break;
     }
     // Measured on MI355X (tools/gemm_bench.py): with >= ~2 blocks per CU of 128x128 the big
@@ -440,7 +499,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     return launch_tile<64, 64, 2, 2, 2, false>(a, 1, st);
 }
 
-// tile choice of launch_conv, shared with the stats consumer
+// tile choice of launch_conv (the caller learns the M-tile count through *tiles_m)
 static void conv_tile(int rows, int cout, int frames, int* bm, int* bn) {
     int n = (cout % 128 == 0) ? 128 : (cout % 96 == 0 ? 96 : 64);
     long blocks128 = (long)cdiv(rows, 128) * (cout / n) * frames;
@@ -452,12 +511,6 @@ static void conv_tile(int rows, int cout, int frames, int* bm, int* bn) {
     static int force_bm = -1;                  // tuning hook: PIPS_CONV_BM=64|128
     if (force_bm < 0) { const char* e = getenv("PIPS_CONV_BM"); force_bm = e ? atoi(e) : 0; }
     if (force_bm == 64 || force_bm == 128) *bm = force_bm;
-}
-
-int conv_tiles_m(int rows_per_frame, int Cout, int frames) {
-    int bm, bn;
-    conv_tile(rows_per_frame, Cout, frames, &bm, &bn);
-    return cdiv(rows_per_frame, bm);
 }
 
 int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) {

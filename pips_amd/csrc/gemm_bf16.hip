@@ -14,7 +14,6 @@
 
 namespace pips {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -204,24 +203,40 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs
         // C orientation: col = lane&31, row = (r&3) + 8*(r>>2) + 4*half; fp32 output + column partials
         float* __restrict__ Cc = p.C + (size_t)frame * p.M * p.ldc;
         float csum[TN], csq[TN];
+        // bias added before the predicated stores, full tiles unpredicated (see gemm.hip)
+        const bool full_tile = m0 + BM <= p.M && n0 + BN <= p.N;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             csum[j] = csq[j] = 0.f;
             const int col = n0 + wn * WTN + j * 32 + l31;
             const bool col_ok = col < p.N;
-            const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+            const float bv = p.bias != nullptr ? p.bias[col_ok ? col : p.N - 1] : 0.f;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < p.M && col_ok) {
-                        const float v = acc[i][j][r] + bv;
-                        Cc[(size_t)row * p.ldc + col] = v;
-                        csum[j] += v;
-                        csq[j] += v * v;
+                for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+                const int rbase = m0 + wm * WTM + i * 32 + 4 * half;
+                float* cp = Cc + (size_t)rbase * p.ldc + col;
+                if (full_tile) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
+                        csum[j] += v[r];
+                        csq[j] += v[r] * v[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < p.M && col_ok) {
+                            cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
+                            csum[j] += v[r];
+                            csq[j] += v[r] * v[r];
+                        }
                     }
                 }
+            }
         }
         if (p.stats != nullptr) {
             __syncthreads();
@@ -256,6 +271,13 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs
     const int epi = p.epi & 0xff;
     float* __restrict__ Cf = p.C;
     unsigned short* __restrict__ Cb = reinterpret_cast<unsigned short*>(p.C);
+    if (m0 + BM <= p.M && n0 + BN <= p.N && (epi != EPI_RESIDUAL || (p.ldr & 3) == 0)) {
+        const int row0 = m0 + wm * WTM + l31, col0 = n0 + wn * WTN + 4 * half;
+        if (epi == EPI_GELU) epilogue_full_tile<EPI_GELU, OUT_BF16, TM, TN>(acc, p.bias, p.R, p.ldr, p.C, p.ldc, row0, col0);
+        else if (epi == EPI_RESIDUAL) epilogue_full_tile<EPI_RESIDUAL, OUT_BF16, TM, TN>(acc, p.bias, p.R, p.ldr, p.C, p.ldc, row0, col0);
+        else epilogue_full_tile<EPI_BIAS, OUT_BF16, TM, TN>(acc, p.bias, p.R, p.ldr, p.C, p.ldc, row0, col0);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = m0 + wm * WTM + i * 32 + l31;

@@ -290,7 +290,6 @@ __device__ __forceinline__ void ln_stats(const float (&x0)[S], const float (&x1)
 // one-channel-per-thread version), so everything is done to cut instruction count: two
 // channels per thread in packed float2 arithmetic (v_pk_fma_f32), wave reductions with DPP
 // row shifts/broadcasts instead of ds_bpermute, cross-wave combination through 32 floats of LDS.
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float dpp_add(float acc, float src) {
@@ -344,33 +343,6 @@ __device__ __forceinline__ void ln_stats2(const f2 (&x)[S], float (&mean)[S], fl
     block_sum8_dpp(a, red);
 #pragma unroll
     for (int t = 0; t < S; ++t) rstd[t] = 1.0f / sqrtf(a[t] * (1.0f / PIPS_DMIX) + 1e-5f);
-}
-
-// fast_erf / gelu_exact (common.h) on two values at once: the polynomials run as packed FMAs
-__device__ __forceinline__ f2 gelu_exact2(f2 v) {
-    const f2 x = v * 0.70710678118654752440f;
-    const f2 ax = __builtin_elementwise_abs(x);
-    const f2 t = __builtin_elementwise_min(ax, (f2){4.0f, 4.0f});
-    const f2 u = x * x;
-    f2 p = (f2){-6.218503113e-04f, -6.218503113e-04f};
-    p = p * u + 5.035122391e-03f;
-    p = p * u + -2.679345198e-02f;
-    p = p * u + 1.128251031e-01f;
-    p = p * u + -3.761255443e-01f;
-    p = p * u + 1.128379107e+00f;
-    f2 q = (f2){-8.686167803e-07f, -8.686167803e-07f};
-    q = q * t + 3.125615694e-05f;
-    q = q * t + -4.758332507e-04f;
-    q = q * t + 4.213109612e-03f;
-    q = q * t + -2.493269742e-02f;
-    q = q * t + 1.075836346e-01f;
-    q = q * t + 6.343385577e-01f;
-    q = q * t + 1.128848195e+00f;
-    const f2 e = q * t;
-    f2 erf;
-    erf.x = t.x > 0.875f ? copysignf(1.0f - __expf(-e.x), x.x) : x.x * p.x;
-    erf.y = t.y > 0.875f ? copysignf(1.0f - __expf(-e.y), x.y) : x.y * p.y;
-    return (v * 0.5f) * (erf + 1.0f);
 }
 
 __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict__ arena, MixLayerW L,
