@@ -26,7 +26,8 @@ namespace pips {
 
 
 template <int BM, int BN, int WGM, int WGN, int KS, bool CONV>
-__global__ __launch_bounds__(WGM * WGN * KS * 64) void igemm_f32_kernel(GemmArgs p) {
+// 128x128 tiles (64 accumulators per lane) must keep two blocks per CU: cap them at 256 registers
+__global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM * WGN * KS == 4) ? 2 : 1) void igemm_f32_kernel(GemmArgs p) {
     constexpr int NT = WGM * WGN * KS * 64;
     constexpr int BKB = 32 * KS;                    // K values staged per iteration
     constexpr int LD = BKB + 4;                     // LDS row stride (floats)

@@ -29,7 +29,8 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float4& lo, const float4& hi)
 // conv of gemm.hip, with bf16 operands.  BKE = K elements per staged block per wave group: 64,
 // or 32 for Cin = 96 / 416 so that a block never straddles a filter tap.
 template <int BM, int BN, int WGM, int WGN, int KS, bool A_BF16, bool OUT_BF16, int BKE = 64, bool CONV = false>
-__global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_bf16_kernel(GemmArgs p) {
+// 128x128 tiles (64 accumulators per lane) must keep two blocks per CU: cap them at 256 registers
+__global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM * WGN * KS == 4) ? 2 : 1) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int NT = WGM * WGN * KS * 64;
     constexpr int BKB = BKE * KS;                   // K elements staged per iteration
     static_assert(!CONV || (KS == 1 && !A_BF16 && !OUT_BF16), "conv: fp32 map in, fp32 out, no K split");
