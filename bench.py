@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--no-stage-profile", action="store_true")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3),
                     help="2 (default, the headline: B=1/GPU fp32) or 3 (B=8/GPU, bf16 MFMA operands)")
+    ap.add_argument("--matmul", default="exact", choices=("exact", "split"),
+                    help="config 2 only: exact-fp32 MFMA (default, the headline) or the fp32-grade split-bf16 path")
     args = ap.parse_args()
     global B_PER_GPU
     if args.config == 3:
@@ -174,6 +176,7 @@ def main():
     model = Pips(S=S, stride=STRIDE).to(device).eval()               # seeded random init (seed 0)
     if args.config == 3:
         model.mixer_dtype = model.encoder_dtype = torch.bfloat16     # BASELINE configs[2]
+    model.matmul = args.matmul
     xys, rgbs = make_inputs(rank, device)
 
     def step():
@@ -211,7 +214,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.config == 2 else "bf16 MFMA operands, fp32 accumulate/state",
+        "dtype": ("f32" if args.matmul == "exact" else
+                  "f32-grade: split-bf16 (3 exact bf16 terms per fp32 operand, 6 bf16 MFMA products, fp32 accumulate)")
+        if args.config == 2 else "bf16 MFMA operands, fp32 accumulate/state",
         "data": "synthetic (uniform 0..255 frames, uniform in-bounds queries, seeded random-init weights)",
         "config": {"workload": ("BASELINE configs[1]: B=1/GPU S=8 368x496 N=256 I=6 fp32 stride 8, encoder included, "
                                 "inputs resident in HBM") if args.config == 2 else
@@ -219,7 +224,23 @@ def main():
                                 "included, inputs resident in HBM"),
                    "clips_per_gpu": B_PER_GPU, "parallelism": f"clip-sharded x{world}"},
     }
-    if rank == 0 and not args.no_stage_profile and args.config == 2:
+    if rank == 0 and world == 1 and args.config == 2 and args.matmul == "exact" and not args.no_stage_profile:
+        # the same workload on the fp32-grade split-bf16 matrix path (Pips.matmul = "split"; passes the
+        # same fp32 parity gates, tests/test_forward_gpu.py) -- reported beside the exact-fp32 headline
+        model.matmul = "split"
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t1
+        model.matmul = "exact"
+        res["split_bf16"] = {"value": updates / dts, "unit": "particle-updates/s", "ms_per_step": dts / args.steps * 1e3,
+                             "note": "Pips.matmul='split' (PIPS_FLAG_SPLIT_BF16): mixer GEMMs + 64/128-channel convs as "
+                                     "6 exact bf16 MFMA products per fp32 product; same parity gates as fp32"}
+    if rank == 0 and not args.no_stage_profile and args.config == 2 and args.matmul == "exact":
         stages, kern, gather = stage_profile(model, xys, rgbs, device)
         dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
         # HBM-side bytes per launch of that kernel from the committed PMC passes (separate rocprofv3

@@ -57,6 +57,12 @@ extern "C" {
 #define PIPS_FLAG_BF16_MIXER  2   /* bf16 MFMA operands in the channel-mix and head Linear layers (BASELINE
                                      config 3); accumulation, norms, GELU, residual stream, gather stay fp32 */
 
+#define PIPS_FLAG_SPLIT_BF16  16  /* fp32-grade "split-bf16" matrix path: every fp32 operand is split exactly into
+                                     three bf16 terms, six exact bf16 products per fp32 product, fp32 accumulation
+                                     (pips_gemm_f32x3) -- all mixer Linear layers and the convolutions where it is
+                                     faster; same accuracy class as the exact-fp32 MFMA path, not bitwise equal to
+                                     it; takes precedence over the two BF16 flags */
+
 const char* pips_last_error(void);
 int         pips_abi_version(void);
 
@@ -158,6 +164,9 @@ int    pips_mixer_fwd(const void* arena, const float* X, int M, float* delta,
  * activations rounded to bf16 (RNE) as they are staged, fp32 accumulation and epilogues. */
 int    pips_mixer_fwd_bf16(const void* arena, const float* X, int M, float* delta,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* Same with every GEMM on the split-bf16 (bf16x3) path: fp32-grade results, see pips_gemm_f32x3. */
+int    pips_mixer_fwd_x3(const void* arena, const float* X, int M, float* delta,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Profiling variant (the ONLY entry point that creates events and synchronises): same work as
  * pips_mixer_fwd with a hipEvent pair around every GEMM launch on `stream`; ms_host[5] receives
@@ -186,6 +195,19 @@ int    pips_gemm_f32(const float* A, int lda, const float* W, const float* bias,
 int    pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin,
                           const float* wgt, const float* bias, int Cout, int ksize, int cstride, int pad,
                           float* out, float* stats, int* tiles_m_host, void* stream);
+
+/* Split-bf16 ("bf16x3") building blocks: fp32-grade results from the bf16 matrix cores.  Every
+ * fp32 operand is split exactly into three bf16 terms and each product is formed from six exact
+ * bf16 products accumulated in fp32 (same F.linear / F.conv2d contracts as the two calls above).
+ * pips_split_bf16x3: src fp32 [n] (n even) -> dst bf16 planes [3][n] (6n bytes).
+ * pips_gemm_f32x3 / pips_conv_nhwc_f32x3: W3 / wgt3 are the split planes of the fp32 weights. */
+int    pips_split_bf16x3(const float* src, size_t n, void* dst3, void* stream);
+int    pips_gemm_f32x3(const float* A, int lda, const void* W3, const float* bias,
+                       float* C, int ldc, int M, int N, int K, int epi,
+                       const float* R, int ldr, void* stream);
+int    pips_conv_nhwc_f32x3(const float* in, int F, int H, int W, int Cin,
+                            const void* wgt3, const float* bias, int Cout, int ksize, int cstride, int pad,
+                            float* out, float* stats, int* tiles_m_host, void* stream);
 
 #ifdef __cplusplus
 }

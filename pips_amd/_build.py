@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpips_hip.so")
-SOURCES = ["gemm.hip", "encoder.hip", "track.hip", "gather_tiled.hip", "gemm_bf16.hip", "api.hip"]
+SOURCES = ["gemm.hip", "encoder.hip", "track.hip", "gather_tiled.hip", "gemm_bf16.hip", "gemm_x3.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -30,7 +30,8 @@ def _stale(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "pips_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tail.h"),
+               os.path.join(HERE, "..", "include", "pips_hip.h")]
     objs = []
     procs = []
     for src in SOURCES:

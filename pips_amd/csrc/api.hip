@@ -71,6 +71,17 @@ static ArenaLayout build_layout() {
     A.h_conv[0] = 0;                                   // the 7x7 stem stays fp32 (VALU kernel)
     for (int i = 1; i < 22; ++i) A.h_conv[i] = take_h((size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
     A.total_h = hoff;
+    size_t toff = 0;
+    auto take_t = [&](size_t n) { size_t o = toff; toff += (3 * n + 127) / 128 * 128; return o; };
+    A.t_in = take_t((size_t)PIPS_DMIX * PIPS_KIN_PAD);
+    for (int d = 0; d < PIPS_DEPTH; ++d) {
+        A.t_w1[d] = take_t((size_t)4 * PIPS_DMIX * PIPS_DMIX);
+        A.t_w2[d] = take_t((size_t)4 * PIPS_DMIX * PIPS_DMIX);
+    }
+    A.t_head = take_t((size_t)PIPS_NOUT * PIPS_DMIX);
+    A.t_conv[0] = 0;
+    for (int i = 1; i < 22; ++i) A.t_conv[i] = take_t((size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
+    A.total_t = toff;
     return A;
 }
 
@@ -122,7 +133,8 @@ const char* pips_last_error(void) { return g_err; }
 int pips_abi_version(void) { return 1; }
 
 size_t pips_weight_arena_bytes(void) {
-    return arena_layout().total * sizeof(float) + arena_layout().total_h * sizeof(unsigned short);
+    return arena_layout().total * sizeof(float) +
+           (arena_layout().total_h + arena_layout().total_t) * sizeof(unsigned short);
 }
 
 int pips_repack_weights(const void* const* params, int nparams, void* arena_v, void* stream) {
@@ -180,6 +192,19 @@ int pips_repack_weights(const void* const* params, int nparams, void* arena_v, v
     to_h(A.w_head, A.h_head, (size_t)PIPS_NOUT * PIPS_DMIX);
     for (int i = 1; i < 22; ++i)
         to_h(A.conv[i].w, A.h_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
+    // split-bf16 planes of the same weights (fp32-grade matrix path on the bf16 cores)
+    unsigned short* tb = reinterpret_cast<unsigned short*>(arena + A.total) + A.total_h;
+    auto to_t = [&](size_t src_off, size_t dst_off, size_t n) {
+        (void)launch_split_bf16x3(arena + src_off, n, tb + dst_off, st);
+    };
+    to_t(A.w_in, A.t_in, (size_t)PIPS_DMIX * PIPS_KIN_PAD);
+    for (int d = 0; d < PIPS_DEPTH; ++d) {
+        to_t(A.mix[d].w1, A.t_w1[d], (size_t)4 * PIPS_DMIX * PIPS_DMIX);
+        to_t(A.mix[d].w2, A.t_w2[d], (size_t)4 * PIPS_DMIX * PIPS_DMIX);
+    }
+    to_t(A.w_head, A.t_head, (size_t)PIPS_NOUT * PIPS_DMIX);
+    for (int i = 1; i < 22; ++i)
+        to_t(A.conv[i].w, A.t_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
     PIPS_CHECK_LAUNCH("pips_repack_weights");
     return pi == PIPS_NPARAMS ? PIPS_OK : PIPS_E_ARG;
 }
@@ -196,6 +221,23 @@ int pips_gemm_f32(const float* A, int lda, const float* W, const float* bias, fl
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+int pips_split_bf16x3(const float* src, size_t n, void* dst3, void* stream) {
+    PIPS_CHECK_ARG(src && dst3, "split_bf16x3: null pointer");
+    return launch_split_bf16x3(src, n, dst3, (hipStream_t)stream);
+}
+
+int pips_gemm_f32x3(const float* A, int lda, const void* W3, const float* bias, float* C, int ldc, int M, int N,
+                    int K, int epi, const float* R, int ldr, void* stream) {
+    PIPS_CHECK_ARG(A && W3 && C, "gemm_x3: null pointer");
+    PIPS_CHECK_ARG((epi & 0xff) <= 2 && ((epi & 0xff) != EPI_RESIDUAL || R != nullptr), "gemm_x3: bad epilogue");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.W = (const float*)W3; g.bias = bias; g.C = C; g.R = R;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.epi = epi;
+    return launch_gemm_x3(g, (hipStream_t)stream);
+}
+
+// mm: 0 exact-fp32 MFMA, 1 bf16 operands (RNE), 2 split-bf16 (wgt points at the matching weight form)
 static int conv_nhwc(const float* in, int F, int H, int W, int Cin, const float* wgt, const float* bias, int Cout,
                      int k, int s, int p, float* out, float* stats, int* tiles, hipStream_t st, int bf16 = 0) {
     GemmArgs g;
@@ -205,7 +247,16 @@ static int conv_nhwc(const float* in, int F, int H, int W, int Cin, const float*
     g.Ho = conv_out(H, k, s, p); g.Wo = conv_out(W, k, s, p);
     g.M = g.Ho * g.Wo; g.N = Cout; g.K = k * k * Cin; g.ldc = Cout; g.epi = EPI_BIAS;
     PIPS_CHECK_ARG(g.Ho > 0 && g.Wo > 0, "conv: empty output");
+    if (bf16 == 2) return launch_conv_x3(g, F, tiles, st);
     return bf16 ? launch_conv_bf16(g, F, tiles, st) : launch_conv(g, F, tiles, st);   // bf16: wgt points at bf16 data
+}
+
+int pips_conv_nhwc_f32x3(const float* in, int F, int H, int W, int Cin, const void* wgt3, const float* bias,
+                         int Cout, int ksize, int cstride, int pad, float* out, float* stats, int* tiles_m_host,
+                         void* stream) {
+    PIPS_CHECK_ARG(in && wgt3 && out, "conv_x3: null pointer");
+    return conv_nhwc(in, F, H, W, Cin, (const float*)wgt3, bias, Cout, ksize, cstride, pad, out, stats, tiles_m_host,
+                     (hipStream_t)stream, 2);
 }
 
 int pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin, const float* wgt, const float* bias,
@@ -276,17 +327,30 @@ int check_geometry(int F, int H, int W, int stride) {
 
 #define RUN(x) do { int rc__ = (x); if (rc__ != PIPS_OK) return rc__; } while (0)
 
-// conv -> partial stats -> mean/rstd
-// bf16 operands: the weight pointer is the conv's bf16 copy (ArenaLayout::h_conv), handed over as float*
-const float* conv_w(const float* arena, const ArenaLayout& A, int ci, int bf16) {
-    if (!bf16) return arena + A.conv[ci].w;
-    return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(arena + A.total) + A.h_conv[ci]);
+// Matrix mode of one convolution.  mm: 0 exact-fp32 MFMA, 1 bf16 operands, 2 split-bf16.  The
+// split path is used where it measured faster than the exact kernel (tools/x3_check.py): Cout 64 /
+// 128 on maps of >= 8000 output pixels; Cout = 96 (a 128-wide tile three quarters full), the small
+// 23x31 maps and the 416->256 layer stay on the exact kernel.
+int layer_mm(const ConvW& c, int F, int H, int W, int mm) {
+    if (mm != 2) return mm;
+    const long rows = (long)F * conv_out(H, c.k, c.stride, c.pad) * conv_out(W, c.k, c.stride, c.pad);
+    return ((c.cout == 64 || c.cout == 128) && rows >= 8000) ? 2 : 0;
+}
+// weight pointer for that mode, handed over as float* (bf16 copy / split planes live behind the fp32 arena)
+const float* conv_w(const float* arena, const ArenaLayout& A, int ci, int mm) {
+    if (mm == 0) return arena + A.conv[ci].w;
+    const unsigned short* hb = reinterpret_cast<const unsigned short*>(arena + A.total);
+    return reinterpret_cast<const float*>(mm == 1 ? hb + A.h_conv[ci] : hb + A.total_h + A.t_conv[ci]);
 }
 
-int conv_stats(const float* arena, const ConvW& c, const float* wgt, const float* in, int F, int H, int W, float* out,
-               float* partial, float* mean_rstd, hipStream_t st, int bf16) {
+// conv -> partial stats -> mean/rstd
+int conv_stats(const float* arena, const ArenaLayout& A, int ci, const float* in, int F, int H, int W, float* out,
+               float* partial, float* mean_rstd, hipStream_t st, int mm) {
+    const ConvW& c = A.conv[ci];
+    const int lm = layer_mm(c, F, H, W, mm);
     int tiles = 0;
-    RUN(conv_nhwc(in, F, H, W, c.cin, wgt, arena + c.b, c.cout, c.k, c.stride, c.pad, out, partial, &tiles, st, bf16));
+    RUN(conv_nhwc(in, F, H, W, c.cin, conv_w(arena, A, ci, lm), arena + c.b, c.cout, c.k, c.stride, c.pad, out, partial,
+                  &tiles, st, lm));
     const int Ho = conv_out(H, c.k, c.stride, c.pad), Wo = conv_out(W, c.k, c.stride, c.pad);
     return launch_inorm_finalize(partial, F, tiles, c.cout, Ho * Wo, mean_rstd, st);
 }
@@ -294,19 +358,17 @@ int conv_stats(const float* arena, const ConvW& c, const float* wgt, const float
 // ResidualBlock.forward, nets/pips.py:173-181
 int res_block(const float* arena, const ArenaLayout& A, int& ci, bool down, const float* x, int F, int H, int W,
               float* ws, const EncPlan& P, float* out, hipStream_t st, int bf16) {
-    const float* w1 = conv_w(arena, A, ci, bf16);
-    const ConvW& c1 = A.conv[ci++];
-    const float* w2 = conv_w(arena, A, ci, bf16);
-    const ConvW& c2 = A.conv[ci++];
+    const int i1 = ci++, i2 = ci++;
+    const ConvW& c1 = A.conv[i1];
+    const ConvW& c2 = A.conv[i2];
     const int Ho = conv_out(H, 3, c1.stride, 1), Wo = conv_out(W, 3, c1.stride, 1);
     float* raw = ws + P.raw; float* mid = ws + P.mid;
-    RUN(conv_stats(arena, c1, w1, x, F, H, W, raw, ws + P.partial, ws + P.st_a, st, bf16));
+    RUN(conv_stats(arena, A, i1, x, F, H, W, raw, ws + P.partial, ws + P.st_a, st, bf16));
     RUN(launch_inorm_apply(raw, ws + P.st_a, nullptr, nullptr, mid, F, Ho * Wo, c1.cout, st));
-    RUN(conv_stats(arena, c2, w2, mid, F, Ho, Wo, raw, ws + P.partial, ws + P.st_a, st, bf16));
+    RUN(conv_stats(arena, A, i2, mid, F, Ho, Wo, raw, ws + P.partial, ws + P.st_a, st, bf16));
     if (down) {
-        const float* wd = conv_w(arena, A, ci, bf16);
-        const ConvW& cd = A.conv[ci++];
-        RUN(conv_stats(arena, cd, wd, x, F, H, W, ws + P.ds, ws + P.partial2, ws + P.st_b, st, bf16));
+        const int id = ci++;
+        RUN(conv_stats(arena, A, id, x, F, H, W, ws + P.ds, ws + P.partial2, ws + P.st_b, st, bf16));
         RUN(launch_inorm_apply(raw, ws + P.st_a, ws + P.ds, ws + P.st_b, out, F, Ho * Wo, c2.cout, st));
     } else {
         RUN(launch_inorm_apply(raw, ws + P.st_a, x, nullptr, out, F, Ho * Wo, c2.cout, st));
@@ -353,15 +415,17 @@ int pips_encoder_fwd_bf16(const void* arena_v, const float* rgbs, int F, int H, 
 int pips_encoder_fwd_ex(const void* arena_v, const void* rgbs, int F, int H, int W, int stride, int flags,
                         float* pyramid, void* workspace, size_t workspace_bytes, void* stream) {
     return encoder_impl(arena_v, rgbs, F, H, W, stride, pyramid, workspace, workspace_bytes, stream,
-                        ((flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0) | ((flags & PIPS_FLAG_RGB_U8) ? 2 : 0));
+                        ((flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0) | ((flags & PIPS_FLAG_RGB_U8) ? 2 : 0) |
+                            ((flags & PIPS_FLAG_SPLIT_BF16) ? 4 : 0));
 }
 
 // mode bit0: bf16 MFMA operands in the 21 3x3 / 1x1 convolutions (maps stay fp32 in memory and are
 // rounded as they are staged; statistics, normalisation, resize and the 7x7 stem stay fp32);
-// mode bit1: rgbs is uint8 (B,S,3,H,W) instead of float
+// mode bit1: rgbs is uint8 (B,S,3,H,W) instead of float;
+// mode bit2: split-bf16 (fp32-grade) convolutions where layer_mm() picks them; wins over bit0
 static int encoder_impl(const void* arena_v, const void* rgbs, int F, int H, int W, int stride, float* pyramid,
                         void* workspace, size_t workspace_bytes, void* stream, int mode) {
-    const int bf16 = mode & 1;
+    const int bf16 = (mode & 4) ? 2 : (mode & 1);      // matrix mode handed to the convolutions
     PIPS_CHECK_ARG(arena_v && rgbs && pyramid && workspace, "encoder: null pointer");
     RUN(check_geometry(F, H, W, stride));
     const EncPlan P = plan_encoder(F, H, W, stride);
@@ -398,13 +462,13 @@ static int encoder_impl(const void* arena_v, const void* rgbs, int F, int H, int
     for (int l = 0, coff = 0; l < 4; coff += ch[l], ++l)
         RUN(launch_resize_into(ws + P.outs[l], F, P.Hs[l], P.Ws[l], ch[l], ws + P.cat, H8, W8, 416, coff, st));
     // conv2 + norm2 + relu + conv3 (:273-276)
-    const float* wc2 = conv_w(arena, A, ci, bf16);
-    const ConvW& c2 = A.conv[ci++];
-    const float* wc3 = conv_w(arena, A, ci, bf16);
-    const ConvW& c3 = A.conv[ci++];
-    RUN(conv_stats(arena, c2, wc2, ws + P.cat, F, H8, W8, ws + P.raw, ws + P.partial, ws + P.st_a, st, bf16));
+    const int i2 = ci++, i3 = ci++;
+    const ConvW& c3 = A.conv[i3];
+    RUN(conv_stats(arena, A, i2, ws + P.cat, F, H8, W8, ws + P.raw, ws + P.partial, ws + P.st_a, st, bf16));
     RUN(launch_inorm_apply(ws + P.raw, ws + P.st_a, nullptr, nullptr, ws + P.mid, F, H8 * W8, 256, st));
-    RUN(conv_nhwc(ws + P.mid, F, H8, W8, 256, wc3, arena + c3.b, 128, 1, 1, 0, pyramid, nullptr, nullptr, st, bf16));
+    const int m3 = layer_mm(c3, F, H8, W8, bf16);
+    RUN(conv_nhwc(ws + P.mid, F, H8, W8, 256, conv_w(arena, A, i3, m3), arena + c3.b, 128, 1, 1, 0, pyramid, nullptr,
+                  nullptr, st, m3));
     // CorrBlock.__init__ pyramid (:346-352)
     int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
     pyramid_dims(H, W, stride, lh, lw);
@@ -514,6 +578,23 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
         ++g;                                                               \
     } while (0)
 
+    const unsigned short* tw = reinterpret_cast<const unsigned short*>(arena + A.total) + A.total_h;
+    if (bf16 == 2) {                                   // split-bf16: every GEMM of the mixer
+        TIMED(pips_gemm_f32x3(X, PIPS_KIN_PAD, tw + A.t_in, arena + A.b_in, x, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
+                              EPI_BIAS, nullptr, 0, stream));
+        for (int d = 0; d < PIPS_DEPTH; ++d) {
+            const MixLayerW& L = A.mix[d];
+            RUN(launch_token_mix(arena, L, x, xn, P, st));
+            TIMED(pips_gemm_f32x3(xn, PIPS_DMIX, tw + A.t_w1[d], arena + L.b1, h, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX,
+                                  PIPS_DMIX, EPI_GELU, nullptr, 0, stream));
+            TIMED(pips_gemm_f32x3(h, 4 * PIPS_DMIX, tw + A.t_w2[d], arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX,
+                                  4 * PIPS_DMIX, EPI_RESIDUAL, x, PIPS_DMIX, stream));
+        }
+        RUN(launch_ln_mean(x, arena + A.lnf_g, arena + A.lnf_b, pooled, P, st));
+        TIMED(pips_gemm_f32x3(pooled, PIPS_DMIX, tw + A.t_head, arena + A.b_head, delta, PIPS_NOUT, P, PIPS_NOUT,
+                              PIPS_DMIX, EPI_BIAS, nullptr, 0, stream));
+        return PIPS_OK;
+    }
     TIMED(pips_gemm_f32(X, PIPS_KIN_PAD, arena + A.w_in, arena + A.b_in, x, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
                         EPI_BIAS, nullptr, 0, stream));
     for (int d = 0; d < PIPS_DEPTH; ++d) {
@@ -553,6 +634,11 @@ int pips_mixer_fwd(const void* arena_v, const float* X, int M, float* delta, voi
 int pips_mixer_fwd_bf16(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                         size_t workspace_bytes, void* stream) {
     return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 1);
+}
+
+int pips_mixer_fwd_x3(const void* arena_v, const float* X, int M, float* delta, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 2);
 }
 
 int pips_mixer_fwd_timed(const void* arena_v, const float* X, int M, float* delta, void* workspace,
@@ -662,7 +748,7 @@ int pips_track(const void* arena, const float* pyramid, int B, int T, int H8, in
         RUN(mixer_input(pyramid, B, T, H8, W8, ffeats, coords, times, N, win_start, ws + P.X, st, ws + P.mixer,
                         pips_mixer_workspace_bytes(M)));
         RUN(mixer_impl(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes(M), stream, nullptr,
-                       (flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0));
+                       (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0)));
         RUN(launch_state_update((const float*)arena, ws + P.delta, ffeats, coords, coords0, B, N, (float)stride,
                                 out_trajs + (size_t)(it + 1) * traj_sz, it + 1 == iters ? out_vis : nullptr, st));
     }
@@ -694,7 +780,8 @@ int pips_forward(const void* arena, const float* rgbs, const float* xys, const f
     if (!(flags & PIPS_FLAG_REUSE_MAPS))
         RUN(encoder_impl(arena, rgbs, B * S, H, W, stride, pyramid, ws + P.enc,
                          pips_encoder_workspace_bytes(B * S, H, W, stride), stream,
-                         ((flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0) | ((flags & PIPS_FLAG_RGB_U8) ? 2 : 0)));
+                         ((flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0) | ((flags & PIPS_FLAG_RGB_U8) ? 2 : 0) |
+                             ((flags & PIPS_FLAG_SPLIT_BF16) ? 4 : 0)));
     return pips_track(arena, pyramid, B, S, H / stride, W / stride, xys, coords_init, feat_init, nullptr, times, N,
                       stride, iters, flags, ws + P.track, plan_track(B, N).total * sizeof(float), out_trajs, out_vis,
                       out_ffeat0, stream);

@@ -89,6 +89,9 @@ struct GemmArgs {
     int swz;             // XCD-aware tile order (set by the launcher)
     // implicit-GEMM geometry (conv only); M = Ho*Wo rows per frame, gridDim.z = frames
     int H, Win, Cin, Ho, Wo, KH, KW, cstride, pad;
+#ifdef PIPS_GEMM_TRACE
+    unsigned long long* trace;   // tools/gemm_trace.py: per-block phase timestamps
+#endif
 };
 
 // Epilogue of a plain-GEMM tile that lies wholly inside C (the common case): straight-line code,
@@ -149,6 +152,10 @@ int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
 // bf16-operand GEMM (gemm_bf16.hip): A fp32 or bf16, W bf16, C fp32 or bf16; pointers passed as float*
 int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
 int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
+// split-bf16 (bf16x3) fp32-grade GEMM / conv (gemm_x3.hip): A fp32, W = three bf16 planes [3][N][K]
+int launch_split_bf16x3(const float* src, size_t n, void* dst, hipStream_t st);
+int launch_gemm_x3(const GemmArgs& a, hipStream_t st);
+int launch_conv_x3(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
 
 // ---------------------------------------------------------------- weight arena
 // Offsets in floats into the packed arena (see api.hip: build_layout()).
@@ -164,6 +171,9 @@ struct ArenaLayout {
     // bf16 copies of the big Linear weights for the bf16-operand mixer, in ushort units from
     // the end of the fp32 section (arena + total)
     size_t h_w1[PIPS_DEPTH], h_w2[PIPS_DEPTH], h_head, h_conv[22], total_h;
+    // split-bf16 planes [3][N][K] of every matrix-core weight (gemm_x3.hip), in ushort units from
+    // the end of the bf16 section
+    size_t t_in, t_w1[PIPS_DEPTH], t_w2[PIPS_DEPTH], t_head, t_conv[22], total_t;
 };
 const ArenaLayout& arena_layout();
 

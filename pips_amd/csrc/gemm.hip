@@ -67,10 +67,9 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
     const int frame = blockIdx.z;
 #ifdef PIPS_GEMM_TRACE
     // tools/gemm_trace.py: per-block phase timestamps (100 MHz constant clock) for plain GEMMs
-    unsigned long long* tr_ = reinterpret_cast<unsigned long long*>(p.stats) +
-                              8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
-#define PIPS_T(slot) if (!CONV && p.stats != nullptr && tid == 0) tr_[slot] = wall_clock64();
-    if (!CONV && p.stats != nullptr && tid == 0) {
+    unsigned long long* tr_ = p.trace + 8 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+#define PIPS_T(slot) if (tid == 0) tr_[slot] = wall_clock64();
+    if (tid == 0) {
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc;
@@ -211,6 +210,9 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
     PIPS_STORE_TILES(0);
     __syncthreads();
     PIPS_T(1)
+#ifdef PIPS_GEMM_TRACE
+    const long long cyc0_ = clock64();
+#endif
     int buf = 0;
 #ifdef PIPS_GEMM_ABLATE
     const bool ab_ld = !(p.epi & 0x100), ab_st = !(p.epi & 0x200), ab_bar = !(p.epi & 0x400);
@@ -239,6 +241,9 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
 #endif
     PIPS_COMPUTE(buf);
     PIPS_T(2)
+#ifdef PIPS_GEMM_TRACE
+    if (tid == 0) tr_[7] = (unsigned long long)(clock64() - cyc0_);
+#endif
 #undef PIPS_LOAD_TILES
 #undef PIPS_STORE_TILES
 #undef PIPS_PASSES_A
@@ -412,13 +417,14 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
             }
         }
     }
+    PIPS_T(4)
 }
 
 #ifdef PIPS_GEMM_TRACE
-static float* trace_buffer() {
+static unsigned long long* trace_buffer() {
     static void* buf = nullptr;
     if (!buf) { (void)hipMalloc(&buf, 8u << 20); (void)hipMemset(buf, 0, 8u << 20); }
-    return reinterpret_cast<float*>(buf);
+    return reinterpret_cast<unsigned long long*>(buf);
 }
 extern "C" int pips_trace_read(void* host, size_t bytes) {
     return (int)hipMemcpy(host, trace_buffer(), bytes, hipMemcpyDeviceToHost);
@@ -451,21 +457,31 @@ static int launch_tile(const GemmArgs& a_in, int frames, hipStream_t st) {
         }
     }
 #ifdef PIPS_GEMM_TRACE
-    if (!CONV) a.stats = trace_buffer();
+    a.trace = trace_buffer();
 #endif
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     PIPS_CHECK_LAUNCH("igemm_f32_kernel");
     return PIPS_OK;
 }
 
-// Debug/tuning hook: PIPS_GEMM_TILE=<id> forces one tile configuration for plain GEMMs.
-static int forced_tile() {
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("PIPS_GEMM_TILE");
-        v = e ? atoi(e) : -1;
+// Debug/tuning hooks: PIPS_GEMM_TILE=<id> forces one tile configuration for plain GEMMs;
+// PIPS_GEMM_TILE_UP / PIPS_GEMM_TILE_DOWN do so only for N > K / N < K (the mixer's up- and
+// down-projections), for in-situ A/B runs of tools/mixer_bench.py.
+static int env_int(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : -1;
+}
+static int forced_tile(const GemmArgs& a) {
+    static int all = -2, up = -2, down = -2;
+    if (all == -2) {
+        all = env_int("PIPS_GEMM_TILE");
+        up = env_int("PIPS_GEMM_TILE_UP");
+        down = env_int("PIPS_GEMM_TILE_DOWN");
     }
-    return v;
+    if (all >= 0) return all;
+    if (a.N > a.K && up >= 0) return up;
+    if (a.N < a.K && down >= 0) return down;
+    return -1;
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
@@ -476,7 +492,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
                        (unsigned long long)a.N * (unsigned long long)a.K < (1ull << 32),
                    "gemm: operand exceeds 2^32 elements");
     const bool k64 = a.K % 64 == 0;
-    switch (forced_tile()) {
+    switch (forced_tile(a)) {
         case 0: return launch_tile<128, 128, 2, 2, 1, false>(a, 1, st);
         case 1: return launch_tile<128, 64, 2, 2, 1, false>(a, 1, st);
         case 2: return launch_tile<64, 128, 2, 2, 1, false>(a, 1, st);

@@ -61,8 +61,9 @@ def pyramid_levels(pyr: torch.Tensor, F: int, H: int, W: int, stride: int):
     return out
 
 
-def encoder_fwd(arena, rgbs, stride, bf16=False):
-    """rgbs (F,3,H,W) 0..255 -> packed channel-last pyramid buffer.  bf16: bf16 conv operands."""
+def encoder_fwd(arena, rgbs, stride, bf16=False, split=False):
+    """rgbs (F,3,H,W) 0..255 -> packed channel-last pyramid buffer.  bf16: bf16 conv operands;
+    split: fp32-grade split-bf16 convolutions."""
     lib = _lib.load()
     u8 = rgbs.dtype == torch.uint8                    # decoded frames go in as they are
     rgbs = rgbs.contiguous() if u8 else _f32(rgbs)
@@ -71,7 +72,7 @@ def encoder_fwd(arena, rgbs, stride, bf16=False):
         pyr = torch.empty(lib.pips_pyramid_floats(F, H, W, stride), dtype=torch.float32, device=rgbs.device)
         nb = lib.pips_encoder_workspace_bytes(F, H, W, stride)
         ws = torch.empty(nb // 4, dtype=torch.float32, device=rgbs.device)
-        flags = (4 if bf16 else 0) | (8 if u8 else 0)     # PIPS_FLAG_BF16_ENCODER | PIPS_FLAG_RGB_U8
+        flags = (4 if bf16 else 0) | (8 if u8 else 0) | (16 if split else 0)   # PIPS_FLAG_BF16_ENCODER | RGB_U8 | SPLIT_BF16
         _lib.check(lib.pips_encoder_fwd_ex(_lib.ptr(arena), _lib.ptr(rgbs), F, H, W, stride, flags, _lib.ptr(pyr),
                                            _lib.ptr(ws), nb, _stream()), "pips_encoder_fwd_ex")
     return pyr
@@ -121,8 +122,9 @@ def mixer_input_build_tiled(pyr, B, H8, W8, ffeats, coords):
     return X
 
 
-def mixer_fwd(arena, X, bf16=False):
-    """X (M,544) -> delta (M/8, 1040).  bf16: bf16 MFMA operands in the channel-mix/head GEMMs."""
+def mixer_fwd(arena, X, bf16=False, split=False):
+    """X (M,544) -> delta (M/8, 1040).  bf16: bf16 MFMA operands in the channel-mix/head GEMMs;
+    split: every GEMM on the fp32-grade split-bf16 path."""
     lib = _lib.load()
     X = _f32(X)
     M = X.shape[0]
@@ -130,7 +132,7 @@ def mixer_fwd(arena, X, bf16=False):
     nb = lib.pips_mixer_workspace_bytes(M)
     ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
-        fn = lib.pips_mixer_fwd_bf16 if bf16 else lib.pips_mixer_fwd
+        fn = lib.pips_mixer_fwd_x3 if split else (lib.pips_mixer_fwd_bf16 if bf16 else lib.pips_mixer_fwd)
         _lib.check(fn(_lib.ptr(arena), _lib.ptr(X), M, _lib.ptr(delta), _lib.ptr(ws), nb, _stream()), "pips_mixer_fwd")
     return delta
 
@@ -176,6 +178,29 @@ def gemm(A, W, bias=None, epi=0, R=None):
     return Cm
 
 
+def split_bf16x3(w):
+    """fp32 tensor -> its three bf16 planes, int16 tensor of shape (3, *w.shape) (exact truncation split)."""
+    lib = _lib.load()
+    w = _f32(w)
+    out = torch.empty((3,) + tuple(w.shape), dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.pips_split_bf16x3(_lib.ptr(w), w.numel(), _lib.ptr(out), _stream()), "pips_split_bf16x3")
+    return out
+
+
+def gemm_x3(A, W3, bias=None, epi=0, R=None):
+    """gemm() on the split-bf16 path; W3 = split_bf16x3(W) with W of shape (N, K)."""
+    lib = _lib.load()
+    A = _f32(A)
+    M, K = A.shape
+    N = W3.shape[1]
+    Cm = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        _lib.check(lib.pips_gemm_f32x3(_lib.ptr(A), K, _lib.ptr(W3), _lib.ptr(bias), _lib.ptr(Cm), N, M, N, K, epi,
+                                       _lib.ptr(R), N if R is not None else 0, _stream()), "pips_gemm_f32x3")
+    return Cm
+
+
 def conv_nhwc(x, w_packed, bias, ksize, stride, pad, want_stats=False):
     """x (F,H,W,Cin) NHWC, w_packed (Cout, k, k, Cin) -> (F,Ho,Wo,Cout) [+ partial stats]."""
     lib = _lib.load()
@@ -193,6 +218,28 @@ def conv_nhwc(x, w_packed, bias, ksize, stride, pad, want_stats=False):
         _lib.check(lib.pips_conv_nhwc_f32(_lib.ptr(x), F, H, W, Cin, _lib.ptr(w_packed), _lib.ptr(bias), Cout, ksize,
                                           stride, pad, _lib.ptr(out), _lib.ptr(stats), C.byref(tiles), _stream()),
                    "pips_conv_nhwc_f32")
+    if want_stats:
+        return out, stats.view(-1)[: F * tiles.value * Cout * 2].view(F, tiles.value, Cout, 2)
+    return out
+
+
+def conv_nhwc_x3(x, w3, bias, ksize, stride, pad, want_stats=False):
+    """conv_nhwc() on the split-bf16 path; w3 = split_bf16x3(w_packed)."""
+    lib = _lib.load()
+    x = _f32(x)
+    F, H, W, Cin = x.shape
+    Cout = w3.shape[1]
+    Ho = (H + 2 * pad - ksize) // stride + 1
+    Wo = (W + 2 * pad - ksize) // stride + 1
+    out = torch.empty(F, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats:
+        stats = torch.zeros(F, (Ho * Wo + 63) // 64, Cout, 2, dtype=torch.float32, device=x.device)
+    tiles = C.c_int(0)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pips_conv_nhwc_f32x3(_lib.ptr(x), F, H, W, Cin, _lib.ptr(w3), _lib.ptr(bias), Cout, ksize,
+                                            stride, pad, _lib.ptr(out), _lib.ptr(stats), C.byref(tiles), _stream()),
+                   "pips_conv_nhwc_f32x3")
     if want_stats:
         return out, stats.view(-1)[: F * tiles.value * Cout * 2].view(F, tiles.value, Cout, 2)
     return out

@@ -70,6 +70,10 @@ class Pips(nn.Module):
         # ``torch.autocast("cuda", dtype=torch.bfloat16)``, the way the reference would be run in bf16.
         self.mixer_dtype = torch.float32
         self.encoder_dtype = torch.float32          # same switch for the encoder's 3x3 / 1x1 convolutions
+        # "exact": fp32 MFMA (products and sums bitwise an fmaf chain).  "split": the fp32-grade
+        # split-bf16 matrix path (PIPS_FLAG_SPLIT_BF16: three exact bf16 terms per fp32 operand, six
+        # bf16 products per fp32 product, fp32 accumulation) -- same accuracy class, ~1.2x faster.
+        self.matmul = "exact"
         self._names = list(param_table(S).keys())
         self._arena = None
         self._arena_key = None
@@ -87,8 +91,11 @@ class Pips(nn.Module):
 
     def _flags(self):
         ac = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
-        return (2 if ac or self.mixer_dtype == torch.bfloat16 else 0) | \
-               (4 if ac or self.encoder_dtype == torch.bfloat16 else 0)   # PIPS_FLAG_BF16_MIXER | _ENCODER
+        if self.matmul not in ("exact", "split"):
+            raise ValueError(f"Pips.matmul must be 'exact' or 'split', not {self.matmul!r}")
+        bf = (2 if ac or self.mixer_dtype == torch.bfloat16 else 0) | \
+             (4 if ac or self.encoder_dtype == torch.bfloat16 else 0)     # PIPS_FLAG_BF16_MIXER | _ENCODER
+        return bf if bf or self.matmul == "exact" else 16                 # PIPS_FLAG_SPLIT_BF16
 
     def _workspace(self, lib, dims, device):
         k = (str(device),) + dims
@@ -171,14 +178,15 @@ class Pips(nn.Module):
             frames = (rgbs.contiguous() if rgbs.dtype == torch.uint8 else rgbs.contiguous().to(torch.float32))
             frames = frames.reshape(F, 3, H, W)
             eb = bool(self._flags() & 4)
+            sp = bool(self._flags() & 16)
             if F <= frames_per_pass:
-                pyr = ops.encoder_fwd(arena, frames, st, bf16=eb)
+                pyr = ops.encoder_fwd(arena, frames, st, bf16=eb, split=sp)
             else:
                 pyr = torch.empty(lib.pips_pyramid_floats(F, H, W, st), dtype=torch.float32, device=dev)
                 dst = ops.pyramid_levels(pyr, F, H, W, st)
                 for f0 in range(0, F, frames_per_pass):
                     f1 = min(F, f0 + frames_per_pass)
-                    part = ops.encoder_fwd(arena, frames[f0:f1], st, bf16=eb)
+                    part = ops.encoder_fwd(arena, frames[f0:f1], st, bf16=eb, split=sp)
                     for d, p in zip(dst, ops.pyramid_levels(part, f1 - f0, H, W, st)):
                         d[f0:f1].copy_(p)
         return FeatureCache(pyr, B, T, H, W, st)

@@ -22,11 +22,15 @@ TOL_PX = 1e-3
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _model(sd, stride):
+MATMUL = ["exact", "split"]      # fp32 MFMA / fp32-grade split-bf16 matrix path: one set of tolerances
+
+
+def _model(sd, stride, matmul="exact"):
     from pips_amd import Pips
     m = Pips(S=8, stride=stride)
     missing = m.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
+    m.matmul = matmul
     return m.to(DEV).eval()
 
 
@@ -37,18 +41,19 @@ def _run(m, xys, rgbs, ci=None, fi=None, iters=6):
     return out
 
 
+@pytest.mark.parametrize("matmul", MATMUL)
 @pytest.mark.parametrize("name", list(G.CASES))
-def test_golden_reference_outputs(name, weights_raw, weights_tamed):
+def test_golden_reference_outputs(name, matmul, weights_raw, weights_tamed):
     case = G.CASES[name]
     gold = np.load(os.path.join(GOLD, name + ".npz"))
     sd = weights_tamed if case["tamed"] else weights_raw
     xys, rgbs, ci, fi = G.make_inputs(case)
-    preds, preds2, vis, ffeat, losses = _run(_model(sd, case["stride"]), xys, rgbs, ci, fi, case["iters"])
+    preds, preds2, vis, ffeat, losses = _run(_model(sd, case["stride"], matmul), xys, rgbs, ci, fi, case["iters"])
     assert losses is None and len(preds) == case["iters"] and len(preds2) == case["iters"] + 4
     trajs = torch.stack(preds).cpu().numpy()
     assert trajs.shape == gold["trajs"].shape
     err = np.abs(trajs - gold["trajs"]).reshape(case["iters"], -1).max(axis=1)
-    print(name, "per-iteration max |dtraj| px:", err)
+    print(name, matmul, "per-iteration max |dtraj| px:", err)
     assert np.abs(preds2[0].cpu().numpy() - gold["traj0"]).max() < 1e-5
     assert np.abs(ffeat.cpu().numpy() - gold["ffeat"]).max() < 2e-4
     if case["tamed"]:
@@ -60,7 +65,8 @@ def test_golden_reference_outputs(name, weights_raw, weights_tamed):
             assert err[1] < 5e-2, err            # second: floor 1.8e-3 px (chaotic regime beyond)
 
 
-def test_teacher_forced_iterations_raw_weights(weights_raw, arenas):
+@pytest.mark.parametrize("matmul", MATMUL)
+def test_teacher_forced_iterations_raw_weights(matmul, weights_raw, arenas):
     """Each iteration recomputed by the HIP stages from the ORACLE's input state."""
     from pips_amd import ops
     from oracle import pips_oracle as O
@@ -69,17 +75,18 @@ def test_teacher_forced_iterations_raw_weights(weights_raw, arenas):
     taps = {}
     O.forward(weights_raw, xys, rgbs, iters=case["iters"], stride=8, taps=taps)
     B, N, H8, W8 = 1, case["N"], 16, 20
-    pyr = ops.encoder_fwd(arenas["raw"], rgbs.reshape(8, 3, 128, 160).to(DEV), 8)
+    split = matmul == "split"
+    pyr = ops.encoder_fwd(arenas["raw"], rgbs.reshape(8, 3, 128, 160).to(DEV), 8, split=split)
     pm = lambda t: t.permute(0, 2, 1, 3).reshape(B * N * 8, -1).contiguous().to(DEV)
     coords0 = pm(taps["iters"][0]["coords_in"])
     for i, it in enumerate(taps["iters"]):
         ff, co = pm(it["ffeats_in"]), pm(it["coords_in"])
         X = ops.mixer_input_build(pyr, B, H8, W8, ff, co)
-        delta = ops.mixer_fwd(arenas["raw"], X)
+        delta = ops.mixer_fwd(arenas["raw"], X, split=split)
         traj, _ = ops.state_update(arenas["raw"], delta, ff, co, coords0, B, N, 8.0)
         err = float((traj.cpu() - it["coords_out"] * 8.0).abs().max())
         ferr = float((ff.cpu() - pm(it["ffeats_out"]).cpu()).abs().max())
-        print(f"teacher-forced iteration {i + 1}: max |dtraj| = {err:.2e} px, max |dffeat| = {ferr:.2e}")
+        print(f"teacher-forced ({matmul}) iteration {i + 1}: max |dtraj| = {err:.2e} px, max |dffeat| = {ferr:.2e}")
         assert err < TOL_PX
         assert ferr < 1e-3
 
@@ -89,13 +96,19 @@ def _config2_inputs(B=1, N=256, H=368, W=496, seed=1):
     return G.make_inputs(dict(B=B, N=N, H=H, W=W), seed=seed)[:2]
 
 
-def test_config2_against_oracle_tamed(weights_tamed):
+@pytest.fixture(scope="module")
+def config2_oracle(weights_tamed):
     from oracle import pips_oracle as O
     xys, rgbs = _config2_inputs()
-    ref_p, ref_p2, ref_vis, ref_ff = O.forward(weights_tamed, xys, rgbs, iters=6, stride=8)
-    preds, preds2, vis, ffeat, _ = _run(_model(weights_tamed, 8), xys, rgbs, iters=6)
+    return xys, rgbs, O.forward(weights_tamed, xys, rgbs, iters=6, stride=8)
+
+
+@pytest.mark.parametrize("matmul", MATMUL)
+def test_config2_against_oracle_tamed(matmul, weights_tamed, config2_oracle):
+    xys, rgbs, (ref_p, ref_p2, ref_vis, ref_ff) = config2_oracle
+    preds, preds2, vis, ffeat, _ = _run(_model(weights_tamed, 8, matmul), xys, rgbs, iters=6)
     err = [float((a.cpu() - b).abs().max()) for a, b in zip(preds, ref_p)]
-    print("config 2 (tamed) per-iteration max |dtraj| px:", err)
+    print(f"config 2 (tamed, {matmul}) per-iteration max |dtraj| px:", err)
     assert max(err) < TOL_PX
     assert float((vis.cpu() - ref_vis).abs().max()) < TOL_PX
     assert float((ffeat.cpu() - ref_ff).abs().max()) < 2e-4

@@ -60,6 +60,65 @@ def test_gemm_identity_asymmetric():
     assert torch.equal(out, W.t().contiguous())
 
 
+# ----------------------------------------------------------------------------- split-bf16 path
+def test_split_bf16x3_is_exact():
+    """x = h + m + l exactly, each term a bf16 (top / middle / low 8 significant bits).  (Below
+    ~2^-110 the remainders are fp32 subnormals and flush to zero: h alone, 8 bits, is kept.)"""
+    from pips_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.randn(4096, generator=g), torch.randn(4096, generator=g) * 1e-6,
+                   torch.randn(4096, generator=g) * 1e6, torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-30, 65504.0])])
+    x = x[: x.numel() // 2 * 2].contiguous()
+    planes = ops.split_bf16x3(x.to(DEV)).cpu()                        # int16 (3, n)
+    terms = (planes.to(torch.int32) << 16).view(torch.float32)        # bf16 bits -> fp32 values
+    assert torch.equal(terms.double().sum(dim=0).float(), x)
+    assert torch.equal(terms[0], (x.view(torch.int32) & -65536).view(torch.float32))   # h = truncation of x
+
+
+@pytest.mark.parametrize("M,N,K,epi", [
+    (2048, 2048, 512, 1), (2048, 512, 2048, 2), (2048, 512, 544, 0), (256, 1040, 512, 0),
+    (77, 132, 96, 2), (8, 32, 32, 1), (16384, 2048, 512, 1),
+])
+def test_gemm_split_bf16(M, N, K, epi):
+    """Same reference and the SAME tolerance as test_gemm_f32: the split path is fp32-grade."""
+    from pips_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g) if epi == 2 else None
+    ref = A.double() @ W.double().t() + b.double()
+    if epi == 1:
+        ref = F.gelu(ref)
+    elif epi == 2:
+        ref = ref + R.double()
+    W3 = ops.split_bf16x3(W.to(DEV))
+    out = ops.gemm_x3(A.to(DEV), W3, b.to(DEV), epi, None if R is None else R.to(DEV)).cpu()
+    assert _rel_err(out.double(), ref) < 2e-6
+    exact = ops.gemm(A.to(DEV), W.to(DEV), b.to(DEV), epi, None if R is None else R.to(DEV)).cpu()
+    # no further from fp64 than the exact-fp32 MFMA kernel (up to 20 % slack on the max norm)
+    assert float((out.double() - ref).abs().max()) <= 1.2 * float((exact.double() - ref).abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("F_,H,W,Cin,Cout,k,s,p", [
+    (2, 46, 62, 64, 64, 3, 1, 1), (2, 46, 62, 64, 96, 3, 2, 1), (2, 23, 31, 96, 128, 1, 2, 0),
+    (1, 16, 20, 416, 256, 3, 1, 1), (8, 92, 124, 64, 64, 3, 1, 1), (8, 46, 62, 128, 128, 3, 1, 1),
+])
+def test_conv_split_bf16(F_, H, W, Cin, Cout, k, s, p):
+    from pips_amd import ops
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = torch.randn(F_, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p).permute(0, 2, 3, 1)
+    w3 = ops.split_bf16x3(w.permute(0, 2, 3, 1).contiguous().to(DEV))
+    out, stats = ops.conv_nhwc_x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), w3, b.to(DEV), k, s, p, want_stats=True)
+    assert _rel_err(out.cpu().double(), ref) < 2e-6
+    st = stats.cpu().double().sum(dim=1)
+    assert _rel_err(st[..., 0], ref.sum(dim=(1, 2))) < 1e-5
+    assert _rel_err(st[..., 1], (ref * ref).sum(dim=(1, 2))) < 1e-5
+
+
 # ----------------------------------------------------------------------------- conv
 @pytest.mark.parametrize("F_,H,W,Cin,Cout,k,s,p", [
     (2, 46, 62, 64, 64, 3, 1, 1),
@@ -88,8 +147,9 @@ def test_conv_nhwc(F_, H, W, Cin, Cout, k, s, p):
 
 
 # ----------------------------------------------------------------------------- encoder
-@pytest.mark.parametrize("H,W,stride", [(128, 160, 8), (96, 128, 4), (136, 200, 8)])
-def test_encoder_pyramid(H, W, stride, weights_raw, arenas):
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("H,W,stride", [(128, 160, 8), (96, 128, 4), (136, 200, 8), (368, 496, 8)])
+def test_encoder_pyramid(H, W, stride, split, weights_raw, arenas):
     from pips_amd import ops
     O = _oracle()
     g = torch.Generator().manual_seed(3)
@@ -97,7 +157,7 @@ def test_encoder_pyramid(H, W, stride, weights_raw, arenas):
     taps = {}
     fm = O.encoder(weights_raw, 2 * (rgbs / 255.0) - 1.0, stride, taps)
     pyr_ref = O.build_pyramid(fm.unsqueeze(0))
-    pyr = ops.encoder_fwd(arenas["raw"], rgbs.to(DEV), stride)
+    pyr = ops.encoder_fwd(arenas["raw"], rgbs.to(DEV), stride, split=split)   # one tolerance for both matrix paths
     torch.cuda.synchronize()
     levels = ops.pyramid_levels(pyr, 8, H, W, stride)
     for l, (got, ref) in enumerate(zip(levels, pyr_ref)):
@@ -219,8 +279,9 @@ def test_mixer_input_build_tiled(B, N, H8, W8, spread):
     assert torch.equal(X[..., 324:], Xd[..., 324:])                       # embedding: same instructions
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("P", [4, 32, 256])
-def test_mixer(P, weights_raw, arenas):
+def test_mixer(P, split, weights_raw, arenas):
     from pips_amd import ops
     O = _oracle()
     g = torch.Generator().manual_seed(P)
@@ -228,7 +289,7 @@ def test_mixer(P, weights_raw, arenas):
     ref = O.mixer(weights_raw, x)
     X = torch.zeros(P * 8, 544)
     X[:, :519] = x.reshape(P * 8, 519)
-    out = ops.mixer_fwd(arenas["raw"], X.to(DEV)).cpu()
+    out = ops.mixer_fwd(arenas["raw"], X.to(DEV), split=split).cpu()
     # 12 residual blocks of fp32 GEMMs with K up to 2048; outputs O(1)
     assert float((out - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
 
