@@ -34,6 +34,7 @@ import torch.distributed as dist   # noqa: E402
 
 B_PER_GPU, S, H, W, NPTS, ITERS, STRIDE = 1, 8, 368, 496, 256, 6, 8
 PEAK_F32_MFMA_TF = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TF = 2500.0         # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (16x the fp32 MFMA rate)
 PEAK_HBM_GBS = 8000.0              # spec; 6290 measured-achievable
 
 
@@ -99,6 +100,24 @@ def stage_profile(model, xys, rgbs, device):
         "up_proj(M=%d,N=2048,K=512)" % M: {"ms": t_up, "tflops": flops / t_up / 1e9},
         "down_proj(M=%d,N=512,K=2048)" % M: {"ms": t_down, "tflops": flops / t_down / 1e9},
     }
+    # the same two launches on the split-bf16 path (gemm_x3_kernel): fp32-equivalent rate, and the bf16
+    # MFMA work actually issued (6 products per fp32 product) against the dense bf16 peak
+    ups, downs, ovh = [], [], []
+    for _ in range(5):
+        _, t = ops.mixer_fwd_timed(arena, X, flags=16)
+        ups.append(t["up_proj"])
+        downs.append(t["down_proj"])
+        ovh.append(t["event_overhead"])
+    s_ovh = sum(ovh) / len(ovh)
+    s_up, s_down = sum(ups) / len(ups) - s_ovh, sum(downs) / len(downs) - s_ovh
+    split = {
+        "up_proj_ms": s_up, "down_proj_ms": s_down,
+        "fp32_equiv_tflops": {"up_proj": flops / s_up / 1e9, "down_proj": flops / s_down / 1e9},
+        "bf16_mfma_tflops_issued": 6 * flops / max(s_up, s_down) / 1e9,
+        "frac_of_bf16_peak": 6 * flops / max(s_up, s_down) / 1e9 / PEAK_BF16_MFMA_TF,
+        "mixer_ms": ev_time_ms(lambda: ops.mixer_fwd(arena, X, split=True), 5) * ITERS,
+        "encoder_ms": min(ev_time_ms(lambda: ops.encoder_fwd(arena, frames, STRIDE, split=True), 3) for _ in range(3)),
+    }
     # gather: compulsory bytes per launch: pyramid + ffeats + coords + fcorrs
     lv = sum((H8 >> l) * (W8 >> l) for l in range(4))
     comp_bytes = B_PER_GPU * S * (lv * 128 * 4 + NPTS * 128 * 4 + NPTS * 8 + NPTS * 196 * 4)
@@ -111,7 +130,7 @@ def stage_profile(model, xys, rgbs, device):
         "frac_of_hbm_peak": comp_bytes / t_gather / 1e6 / PEAK_HBM_GBS,
         "note": "config 2's 18 MB footprint is L2/MALL-resident; HBM fraction is meaningful at config 4",
     }
-    return out, kern, gather
+    return out, kern, gather, split
 
 
 def cpu_baseline():
@@ -241,7 +260,9 @@ def main():
                              "note": "Pips.matmul='split' (PIPS_FLAG_SPLIT_BF16): mixer GEMMs + 64/128-channel convs as "
                                      "6 exact bf16 MFMA products per fp32 product; same parity gates as fp32"}
     if rank == 0 and not args.no_stage_profile and args.config == 2 and args.matmul == "exact":
-        stages, kern, gather = stage_profile(model, xys, rgbs, device)
+        stages, kern, gather, split = stage_profile(model, xys, rgbs, device)
+        if "split_bf16" in res:
+            res["split_bf16"].update(split)
         dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
         # HBM-side bytes per launch of that kernel from the committed PMC passes (separate rocprofv3
         # --pmc FETCH_SIZE / WRITE_SIZE runs of this command; profiles/r1_pmc_traffic.json)

@@ -175,6 +175,9 @@ int    pips_mixer_fwd_x3(const void* arena, const float* X, int M, float* delta,
  * first four RAW (not overhead-corrected).  Used by bench.py for the roofline object. */
 int    pips_mixer_fwd_timed(const void* arena, const float* X, int M, float* delta,
                             void* workspace, size_t workspace_bytes, void* stream, float* ms_host);
+/* Same for the matrix mode selected by flags (0, PIPS_FLAG_BF16_MIXER or PIPS_FLAG_SPLIT_BF16). */
+int    pips_mixer_fwd_timed_ex(const void* arena, const float* X, int M, int flags, float* delta,
+                               void* workspace, size_t workspace_bytes, void* stream, float* ms_host);
 
 /* State update nets/pips.py:525-539 (+ vis head :559 when out_vis != NULL).
  * delta (B*N,1040); ffeats/coords updated in place; coords0 = locked frame-0 coords;

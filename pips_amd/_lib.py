@@ -44,6 +44,8 @@ SIGNATURES = {
     "pips_mixer_fwd_bf16": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_x3": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_timed": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p, C.POINTER(c_float)]),
+    "pips_mixer_fwd_timed_ex": (c_int, [c_void_p, fp, c_int, c_int, fp, c_void_p, c_size_t, c_void_p,
+                                        C.POINTER(c_float)]),
     "pips_state_update": (c_int, [c_void_p, fp, fp, fp, fp, c_int, c_int, c_float, fp, fp, c_void_p]),
     "pips_gemm_f32": (c_int, [fp, c_int, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, c_int, c_void_p]),
     "pips_conv_nhwc_f32": (c_int, [fp, c_int, c_int, c_int, c_int, fp, fp, c_int, c_int, c_int, c_int, fp, fp,

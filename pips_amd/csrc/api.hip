@@ -643,7 +643,13 @@ int pips_mixer_fwd_x3(const void* arena_v, const float* X, int M, float* delta, 
 
 int pips_mixer_fwd_timed(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                          size_t workspace_bytes, void* stream, float* ms_host) {
+    return pips_mixer_fwd_timed_ex(arena_v, X, M, 0, delta, workspace, workspace_bytes, stream, ms_host);
+}
+
+int pips_mixer_fwd_timed_ex(const void* arena_v, const float* X, int M, int flags, float* delta, void* workspace,
+                            size_t workspace_bytes, void* stream, float* ms_host) {
     PIPS_CHECK_ARG(ms_host != nullptr, "mixer_timed: null output");
+    const int mm = (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0);
     constexpr int NG = 2 * PIPS_DEPTH + 2;
     constexpr int NCAL = 8;                      // empty event pairs: the marker-to-marker overhead
     hipEvent_t ev[2 * NG], cal[2 * NCAL];
@@ -652,7 +658,7 @@ int pips_mixer_fwd_timed(const void* arena_v, const float* X, int M, float* delt
     for (int i = 0; i < 2 * NCAL; ++i)
         if (hipEventCreate(&cal[i]) != hipSuccess) { set_error("hipEventCreate failed"); return PIPS_E_LAUNCH; }
     hipStream_t st = (hipStream_t)stream;
-    int rc = mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, ev);
+    int rc = mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, ev, mm);
     for (int i = 0; i < 2 * NCAL; ++i) (void)hipEventRecord(cal[i], st);
     if (rc == PIPS_OK && hipEventSynchronize(cal[2 * NCAL - 1]) != hipSuccess) rc = PIPS_E_LAUNCH;
     if (rc == PIPS_OK) {

@@ -137,8 +137,9 @@ def mixer_fwd(arena, X, bf16=False, split=False):
     return delta
 
 
-def mixer_fwd_timed(arena, X):
+def mixer_fwd_timed(arena, X, flags=0):
     """Profiling: one mixer pass with HIP events around every GEMM launch.
+    flags: 0 exact fp32, 2 bf16 operands, 16 split-bf16 (PIPS_FLAG_*).
     Returns (delta, {in_proj, up_proj, down_proj, head} milliseconds per launch)."""
     lib = _lib.load()
     X = _f32(X)
@@ -148,8 +149,8 @@ def mixer_fwd_timed(arena, X):
     ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
     ms = (C.c_float * 5)()
     with torch.cuda.device(X.device):
-        _lib.check(lib.pips_mixer_fwd_timed(_lib.ptr(arena), _lib.ptr(X), M, _lib.ptr(delta), _lib.ptr(ws), nb,
-                                            _stream(), ms), "pips_mixer_fwd_timed")
+        _lib.check(lib.pips_mixer_fwd_timed_ex(_lib.ptr(arena), _lib.ptr(X), M, flags, _lib.ptr(delta), _lib.ptr(ws), nb,
+                                               _stream(), ms), "pips_mixer_fwd_timed_ex")
     return delta, {"in_proj": ms[0], "up_proj": ms[1], "down_proj": ms[2], "head": ms[3], "event_overhead": ms[4]}
 
 
