@@ -1,6 +1,6 @@
 #!/bin/sh
 # Timing-only ablations of the split-bf16 main loop: builds tools/libpips_x3abl<mask>.so for
-# mask in "$@" (1 no split VALU, 2 no global loads, 4 no ds_write, 8 no barrier; results invalid).
+# mask in "$@" (1 no split VALU, 2 no global loads, 4 no ds_write, 8 no barrier, 16 every load re-reads K block 0; results invalid).
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$ROOT/pips_amd/csrc"
