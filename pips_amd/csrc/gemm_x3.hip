@@ -284,6 +284,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64 * (WS ? 2 : 1)) void gemm_x3_ke
             __syncthreads();
             int kb = 0;                                  // iteration kb: store block kb+1, load block kb+3
             for (; kb + 3 < nk; kb += 3) {
+                if (PIPS_X3_ABL & 32) { __syncthreads(); __syncthreads(); __syncthreads(); continue; }   // idle loaders
                 PIPS_WS_LOAD(0, kb + 3) PIPS_WS_STORE(1, (kb + 1) & 1) __syncthreads();
                 PIPS_WS_LOAD(1, kb + 4) PIPS_WS_STORE(2, (kb + 2) & 1) __syncthreads();
                 PIPS_WS_LOAD(2, kb + 5) PIPS_WS_STORE(0, (kb + 3) & 1) __syncthreads();
