@@ -19,6 +19,7 @@ else:
     xys = torch.rand(B, N, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])
 xys = xys.to(dev)
 m = Pips(stride=stride).to(dev).eval()
+m.matmul = os.environ.get("PIPS_MATMUL", "exact")       # exact | split
 def ev(fn, reps):
     fn(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -27,7 +28,7 @@ def ev(fn, reps):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / reps
 t = ev(lambda: m(xys, rgbs, iters=iters), 3)
-print(f"B={B} {H}x{W} N={N} {mode} I={iters}: forward {t:.2f} ms -> {B*S*N*iters/t*1e3:.3e} particle-updates/s", flush=True)
+print(f"[{m.matmul}] B={B} {H}x{W} N={N} {mode} I={iters}: forward {t:.2f} ms -> {B*S*N*iters/t*1e3:.3e} particle-updates/s", flush=True)
 arena = m._packed(dev)
 H8, W8 = H // stride, W // stride
 F = B * S
