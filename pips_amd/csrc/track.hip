@@ -288,37 +288,50 @@ __device__ __forceinline__ void ln_stats(const float (&x0)[S], const float (&x1)
 
 // The kernel is instruction-bound (PMC: 3.2k VALU instructions per wave in the previous
 // one-channel-per-thread version), so everything is done to cut instruction count: two
-// channels per thread in packed float2 arithmetic (v_pk_fma_f32), wave reductions with DPP
-// row shifts/broadcasts instead of ds_bpermute, cross-wave combination through 32 floats of LDS.
+// channels per thread in packed float2 arithmetic (v_pk_fma_f32), the eight per-token wave sums of
+// every LayerNorm pass in one transpose-reduce, cross-wave combination through 32 floats of LDS.
 
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ float dpp_add(float acc, float src) {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false);
-    return acc + __int_as_float(t);
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, BANK_MASK, false));
 }
-// sum over the 64 lanes, returned wave-uniform (row_shr 1,2,3 | 4 | 8 | row_bcast15 | row_bcast31 -> lane 63)
-__device__ __forceinline__ float wave_sum(float x) {
-    float s = x;
-    s = dpp_add<0x111, 0xf, 0xf>(s, x);
-    s = dpp_add<0x112, 0xf, 0xf>(s, x);
-    s = dpp_add<0x113, 0xf, 0xf>(s, x);
-    s = dpp_add<0x114, 0xf, 0xe>(s, s);
-    s = dpp_add<0x118, 0xf, 0xc>(s, s);
-    s = dpp_add<0x142, 0xa, 0xf>(s, s);
-    s = dpp_add<0x143, 0xc, 0xf>(s, s);
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+// Eight wave sums at once by transpose-reduce: three exchange steps (lane^1, ^2, ^4) in which a lane
+// keeps the half of its values that matches its lane bit and adds the partner's copy of it -- 8 -> 4
+// -> 2 -> 1 value per lane -- then three plain steps (^8, ^16, ^32).  Lane l returns the sum over the
+// wave of v[l & 7]: 26 instructions against ~200 for eight separate wave reductions.  DPP quad_perm /
+// row_shl / row_shr / row_ror within rows, ds_swizzle across rows, one bpermute across the halves.
+// (Neutral at B=1, where one block per CU leaves the kernel latency-bound; -20 % at 2048+ particles,
+// where it is VALU-issue bound.)
+__device__ __forceinline__ float wave_sum8(const float (&v)[S]) {
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float w[4], x[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
+        w[i] = keep + dpp_mov<0xB1, 0xf>(0.f, send);                   // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = b1 ? w[2 * j + 1] : w[2 * j], send = b1 ? w[2 * j] : w[2 * j + 1];
+        x[j] = keep + dpp_mov<0x4E, 0xf>(0.f, send);                   // quad_perm [2,3,0,1]
+    }
+    const float keep = b2 ? x[1] : x[0], send = b2 ? x[0] : x[1];
+    float recv = dpp_mov<0x104, 0x5>(0.f, send);                       // row_shl:4 into lanes 0-3, 8-11
+    recv = dpp_mov<0x114, 0xa>(recv, send);                            // row_shr:4 into lanes 4-7, 12-15
+    float y = keep + recv;
+    y += dpp_mov<0x128, 0xf>(0.f, y);                                  // row_ror:8  (lane ^ 8)
+    y += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(y), 0x401F));   // lane ^ 16
+    y += __shfl_xor(y, 32);
+    return y;
 }
 
 // sums of 8 per-token values over the 256 threads of the block; red is [S][4 waves]
 __device__ __forceinline__ void block_sum8_dpp(float (&v)[S], float (*red)[4]) {
-    const int wave = threadIdx.x >> 6;
-    float w[S];
-#pragma unroll
-    for (int t = 0; t < S; ++t) w[t] = wave_sum(v[t]);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float w = wave_sum8(v);
     __syncthreads();                                   // previous readers of red are done
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int t = 0; t < S; ++t) red[t][wave] = w[t];
+    if (lane < S) red[lane][wave] = w;
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < S; ++t) {
