@@ -13,8 +13,10 @@
 // stays fp32 in memory and is split while it is staged into LDS (5 VALU ops per value).  Block
 // structure follows gemm.hip: two LDS stages, one barrier per K block (32 K values per wave
 // group), K-split wave groups reduced through LDS, C^T accumulators for plain GEMMs.  The LDS
-// image holds six planes per stage, unpadded XOR-swizzled rows (reads and writes conflict-free).  The
-// kernel is LDS-read bound unless a wave owns a 64x64 tile (12 fragment reads per 24 MFMAs).
+// image holds six planes per stage, unpadded XOR-swizzled rows (reads and writes conflict-free).  A
+// wave should own a 64x64 tile (12 fragment reads per 24 MFMAs; smaller wave tiles are LDS-read
+// bound).  Measured (PMC): the bf16 matrix pipe is ~30 % busy -- the global -> VGPR -> LDS staging
+// does not hide behind the MFMAs of a wave that is alone on its SIMD.
 #include "gemm_tail.h"
 
 #include <cstdlib>
