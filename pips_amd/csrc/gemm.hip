@@ -502,7 +502,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         case 6: if (k64) return launch_tile<128, 64, 2, 2, 2, false>(a, 1, st); break;
         case 7: return launch_tile<32, 64, 1, 2, 1, false>(a, 1, st);     // measured at M=2048: 57 TF
         case 8: return launch_tile<64, 32, 2, 1, 1, false>(a, 1, st);     // 56 TF
-        case 9: if (a.K % 128 == 0) return launch_tile<64, 64, 2, 2, 4, false>(a, 1, st); break;   // down-proj: within 0.5 % of KS=2
+        case 9: if (a.K % 128 == 0) return launch_tile<64, 64, 2, 2, 4, false>(a, 1, st); break;
+        case 10: return launch_tile<256, 128, 4, 2, 1, false>(a, 1, st);   // down-proj: within 0.5 % of KS=2
         default: break;
     }
     // Measured on MI355X (tools/gemm_bench.py): with >= ~2 blocks per CU of 128x128 the big

@@ -12,6 +12,8 @@
 // supplies 8 consecutive K values.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace pips {
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -336,6 +338,9 @@ template <bool A_BF16, bool OUT_BF16>
 static int pick_tile(const GemmArgs& a, hipStream_t st) {
     const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const long b64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
+    static int big = -1;                        // tuning hook: PIPS_BF16_BIG=0 disables the 256x128 tile
+    if (big < 0) { const char* e = getenv("PIPS_BF16_BIG"); big = e ? atoi(e) : 1; }
+    if (big && (long)cdiv(a.M, 256) * cdiv(a.N, 128) >= 256) return launch_bf16_tile<256, 128, 4, 2, 1, A_BF16, OUT_BF16>(a, st);
     if (b128 >= 400) return launch_bf16_tile<128, 128, 2, 2, 1, A_BF16, OUT_BF16>(a, st);
     if (b64 >= 800 || a.K % 128 != 0) return launch_bf16_tile<64, 64, 2, 2, 1, A_BF16, OUT_BF16>(a, st);
     return launch_bf16_tile<64, 64, 2, 2, 2, A_BF16, OUT_BF16>(a, st);
