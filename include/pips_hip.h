@@ -58,7 +58,7 @@ extern "C" {
                                      config 3); accumulation, norms, GELU, residual stream, gather stay fp32 */
 
 #define PIPS_FLAG_SPLIT_BF16  16  /* fp32-grade "split-bf16" matrix path: every fp32 operand is split exactly into
-                                     three bf16 terms, six exact bf16 products per fp32 product, fp32 accumulation
+                                     three bf16 terms (round-to-nearest at each step), six exact bf16 products per fp32 product, fp32 accumulation
                                      (pips_gemm_f32x3) -- all mixer Linear layers and the convolutions where it is
                                      faster; same accuracy class as the exact-fp32 MFMA path, not bitwise equal to
                                      it; takes precedence over the two BF16 flags */

@@ -1,7 +1,7 @@
 // fp32-grade GEMM / implicit-GEMM convolution on the bf16 matrix cores ("split-bf16", bf16x3).
 //
-// Every fp32 operand is split EXACTLY into three bf16 terms by truncation,
-//     x = h + m + l,   h = top 8 significant bits, m = next 8, l = last 8,
+// Every fp32 operand is split EXACTLY into three bf16 terms (round-to-nearest at each step),
+//     x = h + m + l,   h = bf16(x), m = bf16(x - h), l = x - h - m,
 // and a product a*b is formed as six exact bf16 products accumulated in fp32,
 //     a*b ~= al*bh + ah*bl + am*bm + am*bh + ah*bm + ah*bh        (smallest first),
 // dropping am*bl + al*bm + al*bl <= 2^-23 |a b|.  Measured against fp64 (tools/x3_check.py) the
@@ -10,7 +10,7 @@
 // time (v_mfma_f32_32x32x16_bf16 runs 16x the fp32 MFMA rate on CDNA4).
 //
 // W is split once at weight-pack time into three planes [3][N][K]; A (activations / NHWC maps)
-// stays fp32 in memory and is split while it is staged into LDS (5 VALU ops per value).  Block
+// stays fp32 in memory and is split while it is staged into LDS (6 VALU ops per value).  Block
 // structure follows gemm.hip: two LDS stages, one barrier per K block (32 K values per wave
 // group), K-split wave groups reduced through LDS, C^T accumulators for plain GEMMs.  The LDS
 // image holds six planes per stage, unpadded XOR-swizzled rows (reads and writes conflict-free).  A
@@ -29,16 +29,24 @@ namespace pips {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// exact split of two values; the three results hold the bf16 pairs (x0 in the low half).
+// Exact split of two values into bf16 terms by round-to-nearest-even (hardware v_cvt_pk_bf16_f32):
+// h = bf16(x), m = bf16(x - h), l = x - h - m (8 significant bits or fewer are left: exact).  The
+// three results hold the pairs (x0 in the low half).  Rounding rather than truncating keeps the
+// dropped cross terms zero-mean, so their sum over K grows like sqrt(K), not K.
 // (Remainders that are fp32 subnormals -- |x| below ~2^-110 -- flush to zero: h is kept.)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    const bf16x2_ r = __builtin_convertvector(v, bf16x2_);
+    return *reinterpret_cast<const unsigned*>(&r);
+}
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);          // {u1.hi16, u0.hi16}
-    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);   // <= 8 bits left: exact
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
 }
 __device__ __forceinline__ void split3_x8(const float4& a, const float4& b, uint4& h, uint4& m, uint4& l) {
     split3_pair(a.x, a.y, h.x, m.x, l.x);

@@ -62,7 +62,7 @@ def test_gemm_identity_asymmetric():
 
 # ----------------------------------------------------------------------------- split-bf16 path
 def test_split_bf16x3_is_exact():
-    """x = h + m + l exactly, each term a bf16 (top / middle / low 8 significant bits).  (Below
+    """x = h + m + l exactly, each term a bf16: h = bf16(x), m = bf16(x - h), l the rest.  (Below
     ~2^-110 the remainders are fp32 subnormals and flush to zero: h alone, 8 bits, is kept.)"""
     from pips_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -72,7 +72,7 @@ def test_split_bf16x3_is_exact():
     planes = ops.split_bf16x3(x.to(DEV)).cpu()                        # int16 (3, n)
     terms = (planes.to(torch.int32) << 16).view(torch.float32)        # bf16 bits -> fp32 values
     assert torch.equal(terms.double().sum(dim=0).float(), x)
-    assert torch.equal(terms[0], (x.view(torch.int32) & -65536).view(torch.float32))   # h = truncation of x
+    assert torch.equal(terms[0], x.bfloat16().float())                                 # h = round-to-nearest-even bf16
 
 
 @pytest.mark.parametrize("M,N,K,epi", [
