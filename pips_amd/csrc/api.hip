@@ -328,13 +328,12 @@ int check_geometry(int F, int H, int W, int stride) {
 #define RUN(x) do { int rc__ = (x); if (rc__ != PIPS_OK) return rc__; } while (0)
 
 // Matrix mode of one convolution.  mm: 0 exact-fp32 MFMA, 1 bf16 operands, 2 split-bf16.  The
-// split path is used where it measured faster than the exact kernel (tools/x3_check.py): Cout 64 /
-// 128 on maps of >= 8000 output pixels; Cout = 96 (a 128-wide tile three quarters full), the small
-// 23x31 maps and the 416->256 layer stay on the exact kernel.
+// split path is used where it measured faster than the exact kernel (tools/x3_check.py): every
+// layer with >= 8000 output pixels over the batch (at config 2: all but the 23x31 maps).
 int layer_mm(const ConvW& c, int F, int H, int W, int mm) {
     if (mm != 2) return mm;
     const long rows = (long)F * conv_out(H, c.k, c.stride, c.pad) * conv_out(W, c.k, c.stride, c.pad);
-    return ((c.cout == 64 || c.cout == 128) && rows >= 8000) ? 2 : 0;
+    return rows >= 8000 ? 2 : 0;
 }
 // weight pointer for that mode, handed over as float* (bf16 copy / split planes live behind the fp32 arena)
 const float* conv_w(const float* arena, const ArenaLayout& A, int ci, int mm) {

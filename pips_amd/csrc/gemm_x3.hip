@@ -396,9 +396,16 @@ int launch_gemm_x3(const GemmArgs& a, hipStream_t st) {
 int launch_conv_x3(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) {
     PIPS_CHECK_ARG(a.Cin % 32 == 0 && a.K == a.KH * a.KW * a.Cin, "conv_x3: Cin %% 32, K = kh*kw*Cin");
     const int bn = a.N <= 64 ? 64 : 128;            // Cout = 96 rides a 128-wide tile
-    const long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.N, bn) * frames;
-    const int bm = blocks128 >= 256 ? 128 : 64;
+    static int force_bm = -1;                       // tuning hook: PIPS_X3_CONV_BM=64|128|256
+    if (force_bm < 0) { const char* e = getenv("PIPS_X3_CONV_BM"); force_bm = e ? atoi(e) : 0; }
+    int bm = (long)cdiv(a.M, 128) * cdiv(a.N, bn) * frames >= 256 ? 128 : 64;
+    // 256-row tiles (8 waves of 64x64, a quarter fewer staged bytes per MFMA) once they fill 5/8 of the
+    // CUs: measured 96->96 164 -> 150 us, 64->96/s2 118 -> 103 us, 416->256 (192 tiles) 435 -> 304 us;
+    // the 96-tile layers (46x62, Cout 128) lose with them (69 -> 91 us)
+    if (bn == 128 && (long)cdiv(a.M, 256) * cdiv(a.N, 128) * frames >= 160) bm = 256;
+    if (force_bm == 64 || force_bm == 128 || (force_bm == 256 && bn == 128)) bm = force_bm;
     if (tiles_m) *tiles_m = cdiv(a.M, bm);
+    if (bm == 256) return launch_x3_tile<256, 128, 4, 2, 1, true>(a, frames, st);
     if (bm == 128) {
         if (bn == 128) return launch_x3_tile<128, 128, 2, 2, 1, true>(a, frames, st);
         return launch_x3_tile<128, 64, 2, 2, 1, true>(a, frames, st);
