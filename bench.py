@@ -257,7 +257,7 @@ def main():
         dts = time.perf_counter() - t1
         model.matmul = "exact"
         res["split_bf16"] = {"value": updates / dts, "unit": "particle-updates/s", "ms_per_step": dts / args.steps * 1e3,
-                             "note": "Pips.matmul='split' (PIPS_FLAG_SPLIT_BF16): mixer GEMMs + 64/128-channel convs as "
+                             "note": "Pips.matmul='split' (PIPS_FLAG_SPLIT_BF16): mixer GEMMs + the larger convs as "
                                      "6 exact bf16 MFMA products per fp32 product; same parity gates as fp32"}
     if rank == 0 and not args.no_stage_profile and args.config == 2 and args.matmul == "exact":
         stages, kern, gather, split = stage_profile(model, xys, rgbs, device)
