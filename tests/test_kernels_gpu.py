@@ -78,6 +78,7 @@ def test_split_bf16x3_is_exact():
 @pytest.mark.parametrize("M,N,K,epi", [
     (2048, 2048, 512, 1), (2048, 512, 2048, 2), (2048, 512, 544, 0), (256, 1040, 512, 0),
     (77, 132, 96, 2), (8, 32, 32, 1), (16384, 2048, 512, 1),
+    (16500, 1040, 512, 0),      # 256x128 tiles with ragged M and N edges
 ])
 def test_gemm_split_bf16(M, N, K, epi):
     """Same reference and the SAME tolerance as test_gemm_f32: the split path is fp32-grade."""
@@ -117,6 +118,26 @@ def test_conv_split_bf16(F_, H, W, Cin, Cout, k, s, p):
     st = stats.cpu().double().sum(dim=1)
     assert _rel_err(st[..., 0], ref.sum(dim=(1, 2))) < 1e-5
     assert _rel_err(st[..., 1], (ref * ref).sum(dim=(1, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("F_,H,W,Cin,Cout,k,s,p", [
+    (8, 92, 124, 96, 96, 3, 1, 1),       # 360 tiles of 256x128: the 8-wave conv tile, Cout = 96 in a 128-wide tile
+    (8, 46, 62, 416, 256, 3, 1, 1),      # 192 tiles, K = 3744
+    (8, 184, 248, 64, 96, 3, 2, 1),      # stride 2, ragged last m-tile (11408 = 44 * 256 + 144)
+])
+def test_conv_split_bf16_256_row_tile(F_, H, W, Cin, Cout, k, s, p):
+    """Config-2 layer shapes that take the 256-row split tile, against the exact-fp32 MFMA conv
+    (itself checked against fp64 above): outputs and instance-norm partial sums."""
+    from pips_amd import ops
+    g = torch.Generator().manual_seed(Cin * 3 + Cout)
+    x = torch.randn(F_, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / math.sqrt(Cin * k * k)).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    ref, rst = ops.conv_nhwc(x, w, b, k, s, p, want_stats=True)
+    out, st = ops.conv_nhwc_x3(x, ops.split_bf16x3(w), b, k, s, p, want_stats=True)
+    assert st.shape[1] == (ref.shape[1] * ref.shape[2] + 255) // 256          # the 256-row tile was taken
+    assert _rel_err(out.double(), ref.double()) < 4e-6
+    assert _rel_err(st.double().sum(dim=1), rst.double().sum(dim=1)) < 1e-5
 
 
 # ----------------------------------------------------------------------------- conv
