@@ -1,45 +1,58 @@
-// LDS-tiled variant of the fused correlation gather (CorrBlock.corr + CorrBlock.sample,
-// nets/pips.py:384-398, 355-382) for DENSE query sets (BASELINE config 4: N=4096 on a grid).
+// LDS-tiled fused correlation gather (CorrBlock.corr + CorrBlock.sample, nets/pips.py:384-398,
+// 355-382) for DENSE query sets (BASELINE config 4: N=4096 on a grid over 720x1280).
 //
-// The direct kernel (track.hip: mixer_input_kernel) reads every particle's 8x8x128 window from
-// L2: 132 KB per particle-update, 17 GB per launch at config 4, i.e. it runs at the L2 roof
-// while the compulsory HBM traffic is only the pyramid itself.  Dense queries overlap: a
-// 16x16-pixel tile of the level-0 map holds ~68 particles whose windows cover 26x26 pixels, so
-// staging that region ONCE per tile in LDS cuts the L2 traffic ~6x and moves the gather from
-// the L2 roof towards the HBM roof.
+// The direct kernel (track.hip: mixer_input_kernel) reads every particle's 4 x (8x8 px x 128 ch)
+// windows through the vector L1: 132 KB per particle-update, 17 GB per launch at config 4 -- it runs
+// at the L1/L2 roof although the compulsory HBM traffic is only the pyramid itself (0.31 GB).  Dense
+// queries overlap, so here each 16x16-pixel tile of the level-0 map (with its halo, at all four levels)
+// is staged in LDS ONCE and serves every particle that lives in it (~68 at config 4).
 //
-//   bin_particles_kernel   one block per frame (b,s): counting sort of the N particles by the
-//                          16x16 level-0 tile of their current coordinate -> sorted order +
-//                          a work list of (tile, first, count<=64) items.  No global atomics:
-//                          the order inside a tile does not influence any output value.
-//   gather_tiled_kernel    one block (8 waves) per work item.  For each pyramid level and each
-//                          16-channel chunk: the tile's halo region is copied into LDS
-//                          (channel-last, 80-byte pixel stride = conflict-free ds_read_b128, two
-//                          stages so chunk c+1 is fetched while chunk c is consumed), then every
-//                          wave takes particles of the item with LANE = WINDOW PIXEL (64 lanes =
-//                          8x8 window): 4 ds_read_b128 + 16 FMAs per chunk against the particle's
-//                          feature chunk, staged in LDS once per item and read as a broadcast.  No
-//                          cross-lane reduction is needed; the 2x2 blend fetches its four neighbours
-//                          with ds_bpermute.  Particles whose coordinate lies outside the map are
-//                          binned apart and served straight from global memory by the same kernel.
-// Output is identical in meaning to mixer_input_kernel (same taps, same transposed order,
-// zeros outside the map); the dot products are summed in a different order (fp32 round-off).
+//   bin_particles_kernel   one block per frame (b,s): counting sort of the N particles by the tile of
+//                          floor(ix), floor(iy) (the level-0 window anchor, computed with the reference's
+//                          own un-normalisation arithmetic so the tile test is exact) -> sorted order + a
+//                          work list of (tile, first, count <= GMAX) items.  Particles whose anchor is
+//                          outside the map form one extra bin served straight from global memory.
+//   embed_rows_kernel      feature copy + sin/cos embedding + raw flow + zero pad of every mixer row
+//                          (get_3d_embedding, utils/misc.py:44-69; DeltaBlock concat, nets/pips.py:304-308).
+//   gather_tiled_kernel    one block (8 waves) per work item, two blocks per CU.  20 phases =
+//                          (level 0: 8 chunks of 16 channels; levels 1-3: 4 chunks of 32 channels).  The
+//                          tile's region of a (level, chunk) is copied global -> LDS by the waves' own
+//                          LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging, no ds_write), double
+//                          buffered: chunk p+1 lands while chunk p is consumed, one barrier per phase.
+//                          Consumer: LANE = WINDOW PIXEL (64 lanes = the 8x8 integer window of one
+//                          particle-level), the particle's feature chunk comes through the scalar cache
+//                          into SGPRs (wave-uniform), so a phase costs a lane Q `ds_read_b128` + 4Q FMAs
+//                          and no cross-lane reduction.  The LDS image is dense (DMA writes 1 KiB linear
+//                          pieces) and XOR-swizzled on the GLOBAL side -- the lane that fetches LDS quad
+//                          position j of pixel (rx,ry) reads channel quad j ^ key(rx,ry) -- which makes
+//                          the lane=pixel `ds_read_b128` conflict-free for its true 16-lane service groups.
+//                          Particles are Morton-sorted inside the item, so consecutive slots of a wave
+//                          often share the same window anchor at the coarse levels and re-use the
+//                          fragment registers instead of re-reading LDS.  The 2x2 blend of the 8x8
+//                          correlations to the 49 taps uses ds_bpermute; the 196 taps of a row are
+//                          written together at the end.
+// Output is identical in meaning to mixer_input_kernel (same taps, same transposed order, zeros outside
+// the map); the dot products are summed in channel order (fp32 round-off differs from the tree sum).
 #include "common.h"
 
 #include <cstdlib>
+
+#ifndef PIPS_TILED_REUSE
+#define PIPS_TILED_REUSE 1     // re-use the fragment registers between consecutive slots with the same window anchor
+#endif
 
 namespace pips {
 
 constexpr int S = PIPS_S;
 constexpr int C = PIPS_C;
 constexpr int TS = 16;                    // level-0 tile edge in map pixels
-constexpr int GMAX = 64;                  // particles per work item
-constexpr int HALO_LO = 4, HALO_HI = 5;   // window reach (3 / 4) + 1 px slack for the rounded coordinate
-constexpr int RMAX = TS + HALO_LO + HALO_HI;        // 25: largest region edge (level 0)
-constexpr int CH = 16;                    // channels per staged chunk
-constexpr int PIX_LD = CH + 4;            // floats per staged pixel (16-byte pad)
+constexpr int GMAX = 88;                  // particles per work item
 constexpr int NW = 8;                     // waves per block
-constexpr int SLOTS = GMAX / NW;          // particles per wave per item
+constexpr int SLOTS = GMAX / NW;          // particle slots per wave
+constexpr int SLOT_BYTES = 37 * 1024;     // one stage: >= 17*17 px * 128 B (level 1), whole 1 KiB DMA pieces
+constexpr int MAXPIECES = 5;              // DMA pieces per wave per phase: ceil(37 / 8)
+constexpr int LDS_MISC = 2048;            // sort keys / sorted particle table
+constexpr int LDS_BYTES = 2 * SLOT_BYTES + LDS_MISC;
 
 struct TiledLevels {
     size_t off[PIPS_LEVELS];
@@ -62,13 +75,20 @@ __device__ __forceinline__ void corr_window(float cxm, float cym, int lvl, int H
     by = (int)fminf(fmaxf(fy0, -1.0e6f), 1.0e6f) - PIPS_RADIUS;
 }
 
+// staged region of tile coordinate t at level lvl along one axis (inclusive, clipped to [0, n-1]).
+// Level 0: the anchor floor(ix) of a binned particle lies in [16t, 16t+15] exactly, its window reaches
+// -3..+4.  Coarser levels: floor(ix_l) lies in [T-1, T+(16>>l)] with T = (16t)>>l (one pixel of slack
+// each side for the independently rounded coordinate), same reach.
+__device__ __forceinline__ void region_axis(int t, int lvl, int n, int& lo, int& hi) {
+    const int T = (t * TS) >> lvl, w = TS >> lvl;
+    lo = max(lvl == 0 ? T - 3 : T - 4, 0);
+    hi = min(lvl == 0 ? T + w + 3 : T + w + 4, n - 1);
+}
+
 // ---------------------------------------------------------------------------- binning
 // order  [F][N]        particle indices n of frame f sorted by tile
 // items  [F][max_items] int4 {tile, first, count, kind}   kind 0: staged, 1: direct
 // nitems [F]
-// A particle whose level-0 coordinate lies inside the map has, at every level, all in-map
-// pixels of its window inside its tile's halo region (HALO includes 1 px of slack for the
-// rounded coordinate).  Particles outside the map go to one extra bin served without staging.
 __global__ __launch_bounds__(256) void bin_particles_kernel(const float* __restrict__ coords, int N, int H0, int W0,
                                                             int tiles_x, int tiles_y, int max_items,
                                                             int* __restrict__ order, int4* __restrict__ items,
@@ -83,9 +103,12 @@ __global__ __launch_bounds__(256) void bin_particles_kernel(const float* __restr
     __syncthreads();
     auto tile_of = [&](int n) {
         const size_t m = ((size_t)b * N + n) * S + s;
-        const float x = coords[m * 2 + 0], y = coords[m * 2 + 1];
-        if (!(x >= 0.f && x <= (float)(W0 - 1) && y >= 0.f && y <= (float)(H0 - 1))) return ntiles;   // also NaN
-        return min((int)y / TS, tiles_y - 1) * tiles_x + min((int)x / TS, tiles_x - 1);
+        int bx, by; float wx, wy;
+        corr_window(coords[m * 2 + 0], coords[m * 2 + 1], 0, H0, W0, bx, by, wx, wy);
+        const int ax = bx + PIPS_RADIUS, ay = by + PIPS_RADIUS;                    // floor(ix), floor(iy)
+        if (!((unsigned)ax < (unsigned)W0 && (unsigned)ay < (unsigned)H0) || !(wx == wx) || !(wy == wy))
+            return ntiles;                                                         // outside the map / NaN
+        return (ay / TS) * tiles_x + ax / TS;
     };
     for (int n = threadIdx.x; n < N; n += blockDim.x) atomicAdd(&hist[tile_of(n)], 1);
     __syncthreads();
@@ -110,8 +133,9 @@ __global__ __launch_bounds__(256) void bin_particles_kernel(const float* __restr
     }
 }
 
-// blend of one particle-level: lane holds the correlation of window pixel (row lane>>3, col lane&7)
-__device__ __forceinline__ void blend_store(float dval, float wx, float wy, int lane, float* __restrict__ dst) {
+// blend of one particle-level: lane holds the correlation of window pixel (row lane>>3, col lane&7);
+// returns the tap k = ix*7 + iy of lanes < 49
+__device__ __forceinline__ float blend_taps(float dval, float wx, float wy, int lane) {
     const int t = lane < 49 ? lane : 0;
     const int ti = t / 7, tj = t - ti * 7;
     const int src = tj * 8 + ti;                                // lane holding D[row tj][col ti]
@@ -122,17 +146,29 @@ __device__ __forceinline__ void blend_store(float dval, float wx, float wy, int 
     o += ne * (so * wx);
     o += sw * (wy * e);
     o += se * (wy * wx);
-    if (lane < 49) dst[lane] = o;                               // k = ix*7 + iy
+    return o;
 }
 
-// feature copy, sin/cos embedding of (dx, dy, t), raw flow, zero pad of one mixer row (one wave)
-__device__ __forceinline__ void embed_row(const float* __restrict__ ff, float dx, float dy, float tt, int lane,
-                                          float* __restrict__ xrow) {
+// ---------------------------------------------------------------------------- embedding rows
+// One wave per mixer row m: X[m] = [ffeat 128 | (corr 196: not touched) | sin/cos 192 | dx dy t | 0 x 25]
+__global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ ffeats,
+                                                         const float* __restrict__ coords,
+                                                         const float* __restrict__ times, int M,
+                                                         float* __restrict__ X) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const int s = m % S;
+    const size_t m0 = (size_t)(m - s);
+    const float dx = coords[(size_t)m * 2 + 0] - coords[m0 * 2 + 0];        // coords - coords[:,0:1] (:518)
+    const float dy = coords[(size_t)m * 2 + 1] - coords[m0 * 2 + 1];
+    const float tt = times[s];
+    float* xrow = X + (size_t)m * PIPS_KIN_PAD;
+    const float* ff = ffeats + (size_t)m * C;
     if (lane < C / 4) reinterpret_cast<float4*>(xrow)[lane] = reinterpret_cast<const float4*>(ff)[lane];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float val = a == 0 ? dx : (a == 1 ? dy : tt);
-        const float freq = (float)(lane >> 1) * 31.25f;
+        const float freq = (float)(lane >> 1) * 31.25f;                     // arange(0,64,2)*(1000/64)
         const float arg = __fmul_rn(val, freq);
         xrow[C + PIPS_NCORR + a * 64 + lane] = (lane & 1) ? cosf(arg) : sinf(arg);   // misc.py:56-63
     }
@@ -141,33 +177,264 @@ __device__ __forceinline__ void embed_row(const float* __restrict__ ff, float dx
 }
 
 // ---------------------------------------------------------------------------- tiled gather
-// LDS: feats[GMAX][C] (the item's particle features, read back as wave-uniform broadcasts)
-//      region[2][RMAX*RMAX][PIX_LD] (two stages: chunk c+1 is fetched while chunk c is consumed)
-__global__ __launch_bounds__(NW * 64) void gather_tiled_kernel(const float* __restrict__ pyramid, TiledLevels lv,
-                                                               int S_, const float* __restrict__ ffeats,
-                                                               const float* __restrict__ coords,
-                                                               const float* __restrict__ times, int N, int tiles_x,
-                                                               int max_items, const int* __restrict__ order,
-                                                               const int4* __restrict__ items,
-                                                               const int* __restrict__ nitems,
-                                                               float* __restrict__ X) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* feats = smem;                                        // [GMAX][C]
-    float* region = smem + GMAX * C;                            // [2][RMAX*RMAX*PIX_LD]
-    constexpr int RSTAGE = RMAX * RMAX * PIX_LD;
-    const int f = blockIdx.y;
-    if ((int)blockIdx.x >= nitems[f]) return;
-    const int4 it = items[(size_t)f * max_items + blockIdx.x];
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct LevelGeom {          // wave-uniform description of the staged region of one level
+    int x0, y0, RW, RH, W, H;
+    int nquads;             // RW*RH*Q 16-byte LDS positions
+    size_t base;            // float offset of the (frame, level) map in the pyramid buffer
+};
+
+__device__ __forceinline__ LevelGeom level_geom(const TiledLevels& lv, int l, int tx, int ty, size_t frame_base) {
+    LevelGeom g;
+    int x1, y1;
+    g.W = lv.W[l]; g.H = lv.H[l];
+    region_axis(tx, l, g.W, g.x0, x1);
+    region_axis(ty, l, g.H, g.y0, y1);
+    g.RW = max(x1 - g.x0 + 1, 1); g.RH = max(y1 - g.y0 + 1, 1);
+    if (x1 < g.x0 || y1 < g.y0) { g.x0 = g.y0 = 0; g.RW = g.RH = 1; }            // (tile beyond this level's map)
+    g.nquads = g.RW * g.RH * (l == 0 ? 4 : 8);
+    g.base = lv.off[l] + frame_base * g.H * g.W * C;
+    return g;
+}
+
+// XOR key of region pixel (rx, ry) for Q quads per pixel: makes (pixel index & (16/Q - 1), quad ^ key)
+// a bijection of (rx & 3, ry & 3) -> the 16 lanes of a ds_read_b128 service group (4 consecutive x
+// in each of 4 consecutive rows) hit 16 different 16-byte bank groups
+template <int Q>
+__device__ __forceinline__ int swz_key(int rx, int ry) {
+#ifdef PIPS_TILED_DBG_NOSWZ
+    return 0;
+#endif
+    return Q == 4 ? (ry & 3) : (((rx >> 1) & 1) | ((ry & 3) << 1));
+}
+
+// per-lane global byte offsets (within the (frame, level) map) of the DMA pieces this wave issues
+template <int Q>
+__device__ __forceinline__ void dma_setup(const LevelGeom& g, int wave, int lane, unsigned (&doff)[MAXPIECES]) {
+    const float inv_rw = 1.0f / (float)g.RW;
+#pragma unroll
+    for (int r = 0; r < MAXPIECES; ++r) {
+        const int L = min((wave + r * NW) * 64 + lane, g.nquads - 1);
+        const int p = L / Q, j = L - p * Q;
+        const int ry = (int)(((float)p + 0.5f) * inv_rw);         // p < 1024: exact
+        const int rx = p - ry * g.RW;
+        const int q = j ^ swz_key<Q>(rx, ry);
+        doff[r] = (unsigned)(((g.y0 + ry) * g.W + (g.x0 + rx)) * (C * 4) + q * 16);
+    }
+}
+
+// buffer resource over [ptr, ptr + 2 GiB): raw (stride 0) addressing, offsets = soffset (SGPR) + voffset (VGPR);
+// keeps every address of the hot loop out of the vector registers
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+__device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t src, int soff, const unsigned (&doff)[MAXPIECES],
+                                          int npieces, int wave, char* lds_slot) {
+#pragma unroll
+    for (int r = 0; r < MAXPIECES; ++r) {
+        const int piece = wave + r * NW;
+        if (piece < npieces)                                                     // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lptr_t)(lds_slot + piece * 1024), 16, (int)doff[r], soff, 0, 0);
+    }
+}
+
+// The particle's feature chunk sits in VGPRs, channel c0+n in lane n of every 16-lane row; the FMA takes
+// it as a DPP row broadcast, so it costs no instruction of its own (and no scalar-cache round trip).
+// 16 FMAs per asm statement: hipcc pads every statement with an s_nop.
+#define PIPS_FD(n, vn) "v_fmac_f32_dpp %0, %1, %" #vn " row_newbcast:" #n " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ float fma16_bcast(float acc, float f, const float4& a, const float4& b, const float4& c,
+                                             const float4& d) {
+#ifdef PIPS_TILED_DBG_NODPP
+    const int r0 = (threadIdx.x & 63) & 48;
+    const float p[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    for (int n = 0; n < 16; ++n) acc = fmaf(__shfl(f, r0 | n), p[n], acc);
+    return acc;
+#endif
+    asm(PIPS_FD(0, 2) PIPS_FD(1, 3) PIPS_FD(2, 4) PIPS_FD(3, 5) PIPS_FD(4, 6) PIPS_FD(5, 7) PIPS_FD(6, 8) PIPS_FD(7, 9)
+        PIPS_FD(8, 10) PIPS_FD(9, 11) PIPS_FD(10, 12) PIPS_FD(11, 13) PIPS_FD(12, 14) PIPS_FD(13, 15) PIPS_FD(14, 16)
+        PIPS_FD(15, 17)
+        : "+v"(acc)
+        : "v"(f), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y),
+          "v"(c.z), "v"(c.w), "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+    return acc;
+}
+#undef PIPS_FD
+
+// feature chunk loads of one phase: lane reads channel choff + 16*h + (lane & 15) of each slot's row
+template <int Q, int NS>
+__device__ __forceinline__ void feats_issue(__amdgpu_buffer_rsrc_t ff, int geo_row, int choff, int lane,
+                                            float (&fb)[NS][2]) {
+    const int voff = (lane & 15) * 4;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int row = __builtin_amdgcn_readlane(geo_row, k * 4);
+#pragma unroll
+        for (int h = 0; h < Q / 4; ++h)
+            fb[k][h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ff, voff, (row * C + choff + h * 16) * 4, 0));
+    }
+}
+
+// one (level, chunk) phase of one wave: Q ds_read_b128 + 4Q FMAs per slot
+template <int Q, int NS, int SLOT_OFF>
+__device__ __forceinline__ void consume(const char* smem, const unsigned (&A)[NS], float (&acc)[NS], unsigned same,
+                                        const float (&fb)[NS][2]) {
+    float4 v[Q] = {};
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        if (PIPS_TILED_REUSE == 0 || !((same >> k) & 1u)) {                      // wave-uniform
+            unsigned a = A[k];
+            asm volatile("" : "+v"(a));          // keep the Q xors here: hoisted out of the chunk loop they cost Q VGPRs per slot
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                v[q] = *reinterpret_cast<const float4*>(smem + SLOT_OFF + (a ^ (unsigned)(q << 4)));
+        }
+        float d = acc[k];
+#pragma unroll
+        for (int h = 0; h < Q / 4; ++h) d = fma16_bcast(d, fb[k][h], v[h * 4], v[h * 4 + 1], v[h * 4 + 2], v[h * 4 + 3]);
+        acc[k] = d;
+        __builtin_amdgcn_sched_barrier(0);       // keep the next slot's reads behind these FMAs (one fragment set live)
+    }
+}
+
+// per-level lane state: LDS byte address of this lane's window pixel (with the swizzle key folded in),
+// in-map mask, zeroed accumulators
+template <int Q, int NS>
+__device__ __forceinline__ void level_setup(const LevelGeom& g, int lvl, int lane, float geo_bx, float geo_by,
+                                            unsigned (&A)[NS], float (&acc)[NS], unsigned& inmask) {
+    const int wi = lane & 7, wj = lane >> 3;
+    inmask = 0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        acc[k] = 0.f;
+        const int bx = __builtin_amdgcn_readlane(__float_as_int(geo_bx), k * 4 + lvl);
+        const int by = __builtin_amdgcn_readlane(__float_as_int(geo_by), k * 4 + lvl);
+        const int px = bx + wi, py = by + wj;
+        const bool inmap = (unsigned)px < (unsigned)g.W && (unsigned)py < (unsigned)g.H;
+        const int rx = min(max(px - g.x0, 0), g.RW - 1), ry = min(max(py - g.y0, 0), g.RH - 1);
+        A[k] = (unsigned)((ry * g.RW + rx) * (Q * 16) + (swz_key<Q>(rx, ry) << 4));
+        inmask |= inmap ? (1u << k) : 0u;
+    }
+}
+
+// One level = NCH phases.  Entering it, phase 0's region and feature chunk are already in flight (slot 0 /
+// fbA); phase c issues phase c+1's (the next level's first, with Q = 8, after the last chunk) right behind
+// the barrier that frees the other slot, then consumes its own.  One barrier per phase; `s_waitcnt vmcnt(0)`
+// in front of it covers exactly the previous phase's prefetch.
+template <int Q, int NCH, int NS>
+__device__ __forceinline__ void run_level(__amdgpu_buffer_rsrc_t map, __amdgpu_buffer_rsrc_t map_next, bool has_next,
+                                          const LevelGeom& g, const LevelGeom& gn, char* smem, int wave, int lane,
+                                          unsigned same, __amdgpu_buffer_rsrc_t ffeats, int geo_row,
+                                          unsigned (&doff)[MAXPIECES], const unsigned (&A)[NS], float (&acc)[NS],
+                                          float (&fa)[NS][2], float (&fb)[NS][2]) {
+    static_assert(NCH % 2 == 0, "phases come in pairs (static slot / buffer parity)");
+    constexpr int CH = Q * 4;
+    for (int c = 0; c < NCH; c += 2) {
+        // ---- even phase: data in slot 0 / fa; prefetch phase c+1 into slot 1 / fb
+        __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0)
+        __syncthreads();
+        dma_issue(map, (c + 1) * CH * 4, doff, (g.nquads + 63) >> 6, wave, smem + SLOT_BYTES);
+        feats_issue<Q, NS>(ffeats, geo_row, (c + 1) * CH, lane, fb);
+        consume<Q, NS, 0>(smem, A, acc, same, fa);
+        // ---- odd phase: data in slot 1 / fb; prefetch phase c+2 (or the next level's first) into slot 0
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (c + 2 < NCH) {
+            dma_issue(map, (c + 2) * CH * 4, doff, (g.nquads + 63) >> 6, wave, smem);
+            feats_issue<Q, NS>(ffeats, geo_row, (c + 2) * CH, lane, fa);
+        } else if (has_next) {
+            dma_setup<8>(gn, wave, lane, doff);
+            dma_issue(map_next, 0, doff, (gn.nquads + 63) >> 6, wave, smem);
+            feats_issue<8, NS>(ffeats, geo_row, 0, lane, fa);
+        }
+        consume<Q, NS, SLOT_BYTES>(smem, A, acc, same, fb);
+    }
+}
+
+// the staged part of one work item for waves that hold NS particle slots each (a wave with fewer particles
+// repeats its last one: same values, same destination)
+template <int NS>
+__device__ __forceinline__ void tile_body(const float* __restrict__ pyramid, const TiledLevels& lv, size_t frame_base,
+                                          int tx, int ty, char* smem, int wave, int lane, __amdgpu_buffer_rsrc_t map,
+                                          LevelGeom g, unsigned (&doff)[MAXPIECES], __amdgpu_buffer_rsrc_t ffr,
+                                          float geo_bx, float geo_by, float geo_wx, float geo_wy, int geo_row,
+                                          unsigned long long samebits, float* __restrict__ X) {
+    const float scale = sqrtf((float)C);
+    unsigned A[NS];
+    float acc[NS];
+    float fbA[NS][2], fbB[NS][2];
+    unsigned inmask;
+    feats_issue<4, NS>(ffr, geo_row, 0, lane, fbA);
+
+    auto same_of = [&](int lvl) {
+        unsigned sm_ = 0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) sm_ |= (unsigned)((samebits >> (k * 4 + lvl)) & 1ull) << k;
+        return (unsigned)__builtin_amdgcn_readfirstlane(sm_);
+    };
+    auto finish_level = [&](int lvl) {
+        // blend the 8x8 correlations to the 49 taps, k = level*49 + ix*7 + iy (transposed, :379-381)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo_wx), k * 4 + lvl));
+            const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo_wy), k * 4 + lvl));
+            const int row = __builtin_amdgcn_readlane(geo_row, k * 4);
+            const float o = blend_taps(((inmask >> k) & 1u) ? acc[k] / scale : 0.f, wx, wy, lane);
+            if (lane < 49) X[(size_t)row * PIPS_KIN_PAD + C + lvl * 49 + lane] = o;
+        }
+    };
+
+    {
+        const LevelGeom gn = level_geom(lv, 1, tx, ty, frame_base);
+        const __amdgpu_buffer_rsrc_t mapn = make_rsrc(pyramid + gn.base);
+        level_setup<4, NS>(g, 0, lane, geo_bx, geo_by, A, acc, inmask);
+        run_level<4, 8, NS>(map, mapn, true, g, gn, smem, wave, lane, same_of(0), ffr, geo_row, doff, A, acc, fbA, fbB);
+        finish_level(0);
+        g = gn; map = mapn;
+    }
+    for (int lvl = 1; lvl < PIPS_LEVELS; ++lvl) {
+        const LevelGeom gn = level_geom(lv, min(lvl + 1, PIPS_LEVELS - 1), tx, ty, frame_base);
+        const __amdgpu_buffer_rsrc_t mapn = make_rsrc(pyramid + gn.base);
+        level_setup<8, NS>(g, lvl, lane, geo_bx, geo_by, A, acc, inmask);
+        run_level<8, 4, NS>(map, mapn, lvl + 1 < PIPS_LEVELS, g, gn, smem, wave, lane, same_of(lvl), ffr, geo_row, doff, A,
+                            acc, fbA, fbB);
+        finish_level(lvl);
+        g = gn; map = mapn;
+    }
+}
+
+__global__ __launch_bounds__(NW * 64, 4) void gather_tiled_kernel(const float* __restrict__ pyramid, TiledLevels lv,
+                                                                  int S_, const float* __restrict__ ffeats,
+                                                                  const float* __restrict__ coords, int N,
+                                                                  int tiles_x, int max_items, int F,
+                                                                  const int* __restrict__ order,
+                                                                  const int4* __restrict__ items,
+                                                                  const int* __restrict__ nitems,
+                                                                  float* __restrict__ X) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    // block -> (frame, item): block id mod 8 is the XCD (observed dispatch order), so XCD x works through
+    // frames x, x+8, ... one after another and a frame's tiles share that XCD's L2 for their halos
+    int f, item;
+    {
+        const int i = blockIdx.x, xcd = i & 7, j = i >> 3;
+        f = xcd + 8 * (j / max_items);
+        item = j - (j / max_items) * max_items;
+        if (f >= F) return;                                       // (F is a multiple of 8; defensive)
+    }
+    if (item >= nitems[f]) return;
+    const int4 it = items[(size_t)f * max_items + item];
     const int tile = it.x, first = it.y, count = it.z;
     const int b = f / S, s = f - b * S;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = lane & 7, wj = lane >> 3;                    // window column / row of this lane
     const size_t frame_base = (size_t)(b * S_ + s);
-    const float scale = sqrtf((float)C);
 
     if (it.w != 0) {
-        // ---- particles outside the map: no staging, lane = window pixel straight from global
+        // ---- particles anchored outside the map: no staging, lane = window pixel straight from global
+        const float scale = sqrtf((float)C);
+        const int wi = lane & 7, wj = lane >> 3;
         for (int idx = wave; idx < count; idx += NW) {
             const int n = __builtin_amdgcn_readfirstlane(order[(size_t)f * N + first + idx]);
             const size_t m = ((size_t)b * N + n) * S + s;
@@ -187,143 +454,107 @@ __global__ __launch_bounds__(NW * 64) void gather_tiled_kernel(const float* __re
                     d = fmaf(v.x, fch[q * 4 + 0], d); d = fmaf(v.y, fch[q * 4 + 1], d);
                     d = fmaf(v.z, fch[q * 4 + 2], d); d = fmaf(v.w, fch[q * 4 + 3], d);
                 }
-                blend_store((inmap ? d : 0.f) / scale, wx, wy, lane, X + m * PIPS_KIN_PAD + C + lvl * 49);
+                const float o = blend_taps((inmap ? d : 0.f) / scale, wx, wy, lane);
+                if (lane < 49) X[m * PIPS_KIN_PAD + C + lvl * 49 + lane] = o;
             }
-            embed_row(fch, cx - coords[((size_t)b * N + n) * S * 2 + 0], cy - coords[((size_t)b * N + n) * S * 2 + 1],
-                      times[s], lane, X + m * PIPS_KIN_PAD);
         }
         return;
     }
 
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    // particles of this wave: slot k <-> item particle wave + k*NW
-    int pn_[SLOTS];                                             // b*N + n, or -1
-    float cx_[SLOTS], cy_[SLOTS];
+
+    // ---- start the first stage right away: level 0, chunk 0 -> slot 0
+    unsigned doff[MAXPIECES];
+    const LevelGeom g = level_geom(lv, 0, tx, ty, frame_base);
+    dma_setup<4>(g, wave, lane, doff);
+    const __amdgpu_buffer_rsrc_t map = make_rsrc(pyramid + g.base);
+    const __amdgpu_buffer_rsrc_t ffr = make_rsrc(ffeats);
+    dma_issue(map, 0, doff, (g.nquads + 63) >> 6, wave, smem);
+
+    // ---- sort the item's particles by the Morton code of their level-0 anchor (equal anchors at the
+    //      coarse levels become neighbours), spread them over the waves
+    unsigned* skey = reinterpret_cast<unsigned*>(smem + 2 * SLOT_BYTES);            // [GMAX]
+    float* sxy = reinterpret_cast<float*>(smem + 2 * SLOT_BYTES + GMAX * 4);        // [GMAX][2]
+    int* sn = reinterpret_cast<int*>(smem + 2 * SLOT_BYTES + GMAX * 12);            // [GMAX]
+    int my_n = 0; float my_x = 0.f, my_y = 0.f; unsigned my_key = 0;
+    if (tid < count) {
+        my_n = order[(size_t)f * N + first + tid];
+        const size_t m = ((size_t)b * N + my_n) * S + s;
+        my_x = coords[m * 2 + 0]; my_y = coords[m * 2 + 1];
+        int bx, by; float wx, wy;
+        corr_window(my_x, my_y, 0, g.H, g.W, bx, by, wx, wy);
+        const unsigned ax = (unsigned)(bx + PIPS_RADIUS) & 15u, ay = (unsigned)(by + PIPS_RADIUS) & 15u;
+        unsigned mort = 0;
 #pragma unroll
-    for (int k = 0; k < SLOTS; ++k) {
-        const int idx = wave + k * NW;
-        pn_[k] = -1; cx_[k] = 0.f; cy_[k] = 0.f;
-        if (idx < count) {
-            const int n = __builtin_amdgcn_readfirstlane(order[(size_t)f * N + first + idx]);   // wave-uniform
-            pn_[k] = b * N + n;
-            const size_t m = (size_t)pn_[k] * S + s;
-            cx_[k] = coords[m * 2 + 0]; cy_[k] = coords[m * 2 + 1];
-        }
+        for (int i = 0; i < 4; ++i) mort |= ((ax >> i) & 1u) << (2 * i) | ((ay >> i) & 1u) << (2 * i + 1);
+        my_key = (mort << 8) | (unsigned)tid;
+        skey[tid] = my_key;
     }
-    // stage the item's particle features once: feats[idx][C]
-    for (int e = tid; e < count * (C / 4); e += NW * 64) {
-        const int idx = e / (C / 4), c4 = e - idx * (C / 4);
-        const int n = order[(size_t)f * N + first + idx];
-        reinterpret_cast<float4*>(feats)[e] =
-            *reinterpret_cast<const float4*>(ffeats + (((size_t)b * N + n) * S + s) * C + c4 * 4);
+    __syncthreads();
+    if (tid < count) {
+        int rank = 0;
+        for (int j = 0; j < count; ++j) rank += skey[j] < my_key ? 1 : 0;
+        sn[rank] = my_n; sxy[rank * 2 + 0] = my_x; sxy[rank * 2 + 1] = my_y;
     }
+    __syncthreads();
+    const int base_n = count / NW, rem = count - base_n * NW;
+    const int nslot = base_n + (wave < rem ? 1 : 0);              // particles of this wave (may be 0)
+    const int start = wave * base_n + min(wave, rem);
+    const int ns = base_n + (rem ? 1 : 0);                        // slots every wave of the block runs
 
-    for (int lvl = 0; lvl < PIPS_LEVELS; ++lvl) {
-        const int H = lv.H[lvl], W = lv.W[lvl];
-        // staged region of this tile at this level (inclusive bounds, clipped to the map)
-        const int x0 = max(((tx * TS) >> lvl) - HALO_LO, 0), x1 = min((((tx + 1) * TS - 1) >> lvl) + HALO_HI, W - 1);
-        const int y0 = max(((ty * TS) >> lvl) - HALO_LO, 0), y1 = min((((ty + 1) * TS - 1) >> lvl) + HALO_HI, H - 1);
-        const int RW = max(x1 - x0 + 1, 1), RH = max(y1 - y0 + 1, 1);
-        const bool any = x1 >= x0 && y1 >= y0;
-        const int nld = any ? RW * RH * (CH / 4) : 0;           // float4 loads per chunk
-        const float* lbase = pyramid + lv.off[lvl] + frame_base * H * W * C;
-
-        int bx_[SLOTS], by_[SLOTS];
-        float wx_[SLOTS], wy_[SLOTS], acc[SLOTS];
-#pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            corr_window(cx_[k], cy_[k], lvl, H, W, bx_[k], by_[k], wx_[k], wy_[k]);
-            acc[k] = 0.f;
-        }
-
-        // two-stage pipeline over the 4 channel chunks: global -> registers (chunk c+1) overlaps
-        // the LDS reads + FMAs of chunk c; up to RL float4 per thread per chunk
-        constexpr int RL = (RMAX * RMAX * (CH / 4) + NW * 64 - 1) / (NW * 64);      // 10
-        float4 stg[RL];
-#define PIPS_STAGE_LOAD(ch_)                                                                    \
-        _Pragma("unroll") for (int r = 0; r < RL; ++r) {                                        \
-            const int e = tid + r * NW * 64;                                                    \
-            const int ec = min(e, max(nld - 1, 0));                                             \
-            const int pix = ec / (CH / 4), cg = ec - pix * (CH / 4);                             \
-            const int ry = pix / RW, rx = pix - ry * RW;                                        \
-            stg[r] = *reinterpret_cast<const float4*>(                                          \
-                lbase + ((size_t)(y0 + ry) * W + (x0 + rx)) * C + (ch_) * CH + cg * 4);         \
-        }
-#define PIPS_STAGE_STORE(buf_)                                                                  \
-        _Pragma("unroll") for (int r = 0; r < RL; ++r) {                                        \
-            const int e = tid + r * NW * 64;                                                    \
-            if (e < nld) *reinterpret_cast<float4*>(&region[(buf_) * RSTAGE + (e / (CH / 4)) * PIX_LD + (e % (CH / 4)) * 4]) = stg[r]; \
-        }
-        __syncthreads();                                        // previous level's readers are done (and feats are in)
-        PIPS_STAGE_LOAD(0)
-        PIPS_STAGE_STORE(0)
-        __syncthreads();
-        for (int ch = 0; ch < C / CH; ++ch) {
-            const int buf = ch & 1;
-            if (ch + 1 < C / CH) PIPS_STAGE_LOAD(ch + 1)
-            // ---- every wave: its particles, lane = window pixel
-#pragma unroll
-            for (int k = 0; k < SLOTS; ++k) {
-                if (pn_[k] < 0) continue;                       // wave-uniform
-                const int px = bx_[k] + wi, py = by_[k] + wj;
-                const bool inmap = any && (unsigned)px < (unsigned)W && (unsigned)py < (unsigned)H;
-                const int rx = min(max(px - x0, 0), RW - 1), ry = min(max(py - y0, 0), RH - 1);
-                const float* pix = &region[buf * RSTAGE + (ry * RW + rx) * PIX_LD];
-                const float* fch = &feats[(wave + k * NW) * C + ch * CH];     // same address in every lane: broadcast
-                float d = 0.f;
-#pragma unroll
-                for (int q = 0; q < CH / 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(pix + q * 4);
-                    const float4 w = *reinterpret_cast<const float4*>(fch + q * 4);
-                    d = fmaf(v.x, w.x, d); d = fmaf(v.y, w.y, d); d = fmaf(v.z, w.z, d); d = fmaf(v.w, w.w, d);
-                }
-                acc[k] += inmap ? d : 0.f;
-            }
-            if (ch + 1 < C / CH) PIPS_STAGE_STORE(buf ^ 1)
-            __syncthreads();
-        }
-#undef PIPS_STAGE_LOAD
-#undef PIPS_STAGE_STORE
-
-        // ---- blend the 8x8 correlations to the 49 taps (transposed order k = ix*7 + iy)
-#pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            if (pn_[k] < 0) continue;                           // wave-uniform
-            blend_store(acc[k] / scale, wx_[k], wy_[k], lane,                         // corrs / sqrt(C) (:397)
-                        X + ((size_t)pn_[k] * S + s) * PIPS_KIN_PAD + C + lvl * 49);
-        }
+    // ---- lane-parallel window geometry: lane k*4+l <-> (slot k, level l); slots past the wave's own
+    //      particles repeat its last one (or the item's first, for an empty wave)
+    float geo_bx, geo_by, geo_wx, geo_wy;                              // ints travel as bit patterns
+    int geo_row;
+    {
+        const int k = min(lane >> 2, SLOTS - 1), l = lane & 3;
+        const int idx = nslot > 0 ? start + min(k, nslot - 1) : 0;
+        const float cx = sxy[idx * 2 + 0], cy = sxy[idx * 2 + 1];
+        int bx, by;
+        corr_window(cx, cy, l, lv.H[l], lv.W[l], bx, by, geo_wx, geo_wy);
+        geo_bx = __int_as_float(bx); geo_by = __int_as_float(by);
+        geo_row = (b * N + sn[idx]) * S + s;                           // mixer row m
+    }
+    // slot k re-uses slot k-1's fragments at level l when both windows have the same anchor
+    unsigned long long samebits;
+    {
+        const int pbx = __shfl_up(__float_as_int(geo_bx), 4), pby = __shfl_up(__float_as_int(geo_by), 4);
+        samebits = __ballot(lane >= 4 && pbx == __float_as_int(geo_bx) && pby == __float_as_int(geo_by));
     }
 
-    // ---- per particle: feature copy, sin/cos embedding of (dx, dy, t), raw flow, zero pad
-#pragma unroll
-    for (int k = 0; k < SLOTS; ++k) {
-        if (pn_[k] < 0) continue;
-        const size_t m = (size_t)pn_[k] * S + s;
-        embed_row(ffeats + m * C, cx_[k] - coords[(size_t)pn_[k] * S * 2 + 0], cy_[k] - coords[(size_t)pn_[k] * S * 2 + 1],
-                  times[s], lane, X + m * PIPS_KIN_PAD);
-    }
+#define PIPS_TILE_CASE(NS_)                                                                                          \
+    tile_body<NS_>(pyramid, lv, frame_base, tx, ty, smem, wave, lane, map, g, doff, ffr, geo_bx, geo_by, geo_wx,    \
+                   geo_wy, geo_row, samebits, X)
+#ifdef PIPS_TILE_ONLY
+    (void)ns;
+    PIPS_TILE_CASE(PIPS_TILE_ONLY);
+#else
+    if (ns <= 4) PIPS_TILE_CASE(4);
+    else if (ns <= 8) PIPS_TILE_CASE(8);
+    else if (ns == 9) PIPS_TILE_CASE(9);
+    else if (ns == 10) PIPS_TILE_CASE(10);
+    else PIPS_TILE_CASE(11);
+#endif
+#undef PIPS_TILE_CASE
 }
 
 // ---------------------------------------------------------------------------- host side
+static int tiled_max_items(int N, int H8, int W8) { return cdiv(W8, TS) * cdiv(H8, TS) + 1 + N / GMAX + 1; }
+
 size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8) {
     const int F = B * S;
-    const int ntiles = cdiv(W8, TS) * cdiv(H8, TS);
-    const int max_items = ntiles + 1 + N / GMAX + 1;
+    const int max_items = tiled_max_items(N, H8, W8);
     return align_up((size_t)F * N * sizeof(int), 256) + align_up((size_t)F * max_items * sizeof(int4), 256) +
            align_up((size_t)F * sizeof(int), 256);
 }
 
-// Selection.  Measured on MI355X at BASELINE config 4 (B=4, 720x1280, N=4096 grid): this kernel
-// 1.3-1.6 ms per launch against 0.73-0.86 ms for the direct kernel -- its 32 short
-// stage->barrier->consume phases per item are bound by global-load latency with one block per
-// CU, so the 6x cut in L2 traffic does not show yet.  It therefore stays OPT-IN
-// (PIPS_GATHER_TILED=1, or pips_mixer_input_build_tiled) until the chunk pipeline is deepened;
-// the direct kernel remains the default everywhere.
+// Selection: dense query sets (on average >= 16 particles per 16x16 level-0 tile) take the tiled kernel;
+// PIPS_GATHER_TILED=0/1 forces it off/on.
 bool tiled_gather_wanted(int N, int H8, int W8) {
     static int force = -2;
     if (force == -2) { const char* e = getenv("PIPS_GATHER_TILED"); force = e ? atoi(e) : -1; }
-    (void)N; (void)H8; (void)W8;
-    return force > 0;
+    if (force >= 0) return force > 0;
+    return (long)N >= 16L * cdiv(W8, TS) * cdiv(H8, TS) && N >= 1024;
 }
 
 int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B,
@@ -336,25 +567,28 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
         return PIPS_E_WORKSPACE;
     }
     const int tiles_x = cdiv(W8, TS), tiles_y = cdiv(H8, TS), ntiles = tiles_x * tiles_y;
-    const int max_items = ntiles + 1 + N / GMAX + 1;
+    const int max_items = tiled_max_items(N, H8, W8);
     char* p = (char*)scratch;
     int* order = (int*)p; p += align_up((size_t)F * N * sizeof(int), 256);
     int4* items = (int4*)p; p += align_up((size_t)F * max_items * sizeof(int4), 256);
     int* nitems = (int*)p;
     PIPS_CHECK_ARG((size_t)2 * (ntiles + 1) * sizeof(int) <= 64 * 1024, "tiled gather: map too large for the tile histogram");
+    PIPS_CHECK_ARG((size_t)H8 * W8 * C * 4 < (1ull << 31), "tiled gather: level-0 map too large for 32-bit offsets");
     hipLaunchKernelGGL(bin_particles_kernel, dim3(F), dim3(256), (size_t)2 * (ntiles + 1) * sizeof(int), st, coords, N, H8,
                        W8, tiles_x, tiles_y, max_items, order, items, nitems);
     PIPS_CHECK_LAUNCH("bin_particles_kernel");
+    const int M = B * N * S;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ffeats, coords, times, M, X);
+    PIPS_CHECK_LAUNCH("embed_rows_kernel");
     TiledLevels lv;
     for (int l = 0; l < PIPS_LEVELS; ++l) { lv.off[l] = lvl_off[l]; lv.H[l] = lvlH[l]; lv.W[l] = lvlW[l]; }
-    const size_t lds = ((size_t)GMAX * C + (size_t)2 * RMAX * RMAX * PIX_LD) * sizeof(float);
-    static bool raised = false;
-    if (!raised) {
-        (void)hipFuncSetAttribute((const void*)gather_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        raised = true;
+    if (hipFuncSetAttribute((const void*)gather_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        hipSuccess) {
+        set_error("tiled gather: cannot raise the dynamic LDS limit to %d bytes", LDS_BYTES);
+        return PIPS_E_LAUNCH;
     }
-    hipLaunchKernelGGL(gather_tiled_kernel, dim3(max_items, F), dim3(NW * 64), lds, st, pyramid, lv, S_, ffeats, coords,
-                       times, N, tiles_x, max_items, order, items, nitems, X);
+    hipLaunchKernelGGL(gather_tiled_kernel, dim3(max_items * F), dim3(NW * 64), LDS_BYTES, st, pyramid, lv, S_, ffeats,
+                       coords, N, tiles_x, max_items, F, order, items, nitems, X);
     PIPS_CHECK_LAUNCH("gather_tiled_kernel");
     return PIPS_OK;
 }

@@ -105,13 +105,13 @@ def mixer_input_build(pyr, B, H8, W8, ffeats, coords):
     return X
 
 
-def mixer_input_build_tiled(pyr, B, H8, W8, ffeats, coords):
+def mixer_input_build_tiled(pyr, B, H8, W8, ffeats, coords, out=None):
     """Same as mixer_input_build through the LDS-tiled kernel for dense query sets."""
     lib = _lib.load()
     ffeats, coords = _f32(ffeats), _f32(coords)
     M = ffeats.shape[0]
     N = M // (B * S)
-    X = torch.empty(M, KIN_PAD, dtype=torch.float32, device=ffeats.device)
+    X = out if out is not None else torch.empty(M, KIN_PAD, dtype=torch.float32, device=ffeats.device)
     tt = times_table(ffeats.device)
     nb = lib.pips_gather_scratch_bytes(B, N, H8, W8)
     scratch = torch.empty(nb, dtype=torch.uint8, device=ffeats.device)
