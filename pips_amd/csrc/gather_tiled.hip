@@ -291,7 +291,7 @@ __device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t src, int soff, 
 #define PIPS_A_OPS(K) [acc##K] "+v"(acc[K])
 #define PIPS_A_INS(K) [A##K] "v"(A[K])
 #define PIPS_A_COMMON [rows] "v"(geo_row), [fb_lo] "s"((unsigned)(fb & 0xffffffffull)), [fb_hi] "s"((unsigned)(fb >> 32)), \
-                      [same] "s"(same), [soff] "i"(SLOT_OFF)
+                      [same] "s"(same), [skip] "s"(skip), [soff] "i"(SLOT_OFF)
 #define PIPS_A_CLOBBER                                                                               \
     "memory", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",     \
     "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",        \
@@ -304,7 +304,7 @@ struct ConsumeAsm;
     template <int SLOT_OFF>                                                                                        \
     struct ConsumeAsm<NS_, SLOT_OFF> {                                                                              \
         static __device__ __forceinline__ void run(const unsigned (&A)[NS_], f2 (&acc)[NS_], unsigned same,         \
-                                                   unsigned long long fb, int geo_row) {                            \
+                                                   unsigned skip, unsigned long long fb, int geo_row) {             \
             asm volatile(PIPS_PHASE_TEXT_##NS_ : OUTS : INS, PIPS_A_COMMON : PIPS_A_CLOBBER);                       \
         }                                                                                                          \
     };
@@ -319,9 +319,10 @@ PIPS_DEFINE_CONSUME(5, PIPS_O_4 PIPS_CM PIPS_A_OPS(4), PIPS_I_4 PIPS_CM PIPS_A_I
 PIPS_DEFINE_CONSUME(6, PIPS_O_4 PIPS_CM PIPS_A_OPS(4) PIPS_CM PIPS_A_OPS(5), PIPS_I_4 PIPS_CM PIPS_A_INS(4) PIPS_CM PIPS_A_INS(5))
 
 template <int NS, int SLOT_OFF>
-__device__ __forceinline__ void consume(const unsigned (&A)[NS], f2 (&acc)[NS], unsigned same,
+__device__ __forceinline__ void consume(const unsigned (&A)[NS], f2 (&acc)[NS], unsigned same, unsigned skip,
                                         const float* __restrict__ ffeats, int geo_row, int choff) {
-    ConsumeAsm<NS, SLOT_OFF>::run(A, acc, PIPS_TILED_REUSE ? same : 0u,
+    ConsumeAsm<NS, SLOT_OFF>::run(A, acc, PIPS_TILED_REUSE ? (unsigned)__builtin_amdgcn_readfirstlane(same) : 0u,
+                                  (unsigned)__builtin_amdgcn_readfirstlane(skip),
                                   (unsigned long long)reinterpret_cast<uintptr_t>(ffeats + choff), geo_row);
 }
 
@@ -353,7 +354,7 @@ __device__ __forceinline__ void level_setup(const LevelGeom& g, int lvl, int lan
 template <int NS>
 __device__ __forceinline__ void run_level(__amdgpu_buffer_rsrc_t map, __amdgpu_buffer_rsrc_t map_next, bool has_next,
                                           const LevelGeom& g, const LevelGeom& gn, char* smem, int wave, int lane,
-                                          unsigned same, const float* __restrict__ ffeats, int geo_row,
+                                          unsigned same, unsigned skip, const float* __restrict__ ffeats, int geo_row,
                                           unsigned (&doff)[MAXPIECES], const unsigned (&A)[NS], f2 (&acc)[NS]) {
     static_assert(NCH % 2 == 0, "phases come in pairs (static slot parity)");
     constexpr int CH = Q * 4;
@@ -362,7 +363,7 @@ __device__ __forceinline__ void run_level(__amdgpu_buffer_rsrc_t map, __amdgpu_b
         __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0)
         if (!(PIPS_TILED_ABLATE & 16)) __syncthreads();
         dma_issue(map, (c + 1) * CH * 4, doff, (g.nquads + 63) >> 6, wave, smem + SLOT_BYTES);
-        consume<NS, 0>(A, acc, same, ffeats, geo_row, c * CH);
+        consume<NS, 0>(A, acc, same, skip, ffeats, geo_row, c * CH);
         // ---- odd phase: data in slot 1; prefetch phase c+2 (or the next level's first) into slot 0
         __builtin_amdgcn_s_waitcnt(0x0f70);
         if (!(PIPS_TILED_ABLATE & 16)) __syncthreads();
@@ -372,7 +373,7 @@ __device__ __forceinline__ void run_level(__amdgpu_buffer_rsrc_t map, __amdgpu_b
             dma_setup(gn, wave, lane, doff);
             dma_issue(map_next, 0, doff, (gn.nquads + 63) >> 6, wave, smem);
         }
-        consume<NS, SLOT_BYTES>(A, acc, same, ffeats, geo_row, (c + 1) * CH);
+        consume<NS, SLOT_BYTES>(A, acc, same, skip, ffeats, geo_row, (c + 1) * CH);
     }
 }
 
@@ -383,7 +384,7 @@ __device__ __forceinline__ void tile_body(const float* __restrict__ pyramid, con
                                           int tx, int ty, char* smem, int wave, int lane, __amdgpu_buffer_rsrc_t map,
                                           LevelGeom g, unsigned (&doff)[MAXPIECES], const float* __restrict__ ffeats,
                                           float geo_bx, float geo_by, float geo_wx, float geo_wy, int geo_row,
-                                          unsigned long long samebits, float* __restrict__ X) {
+                                          unsigned long long samebits, unsigned skip, float* __restrict__ X) {
     const float scale = sqrtf((float)C);
     // LDS byte address of the stage buffers
     const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
@@ -399,7 +400,7 @@ __device__ __forceinline__ void tile_body(const float* __restrict__ pyramid, con
         for (int k = 0; k < NS; ++k) same |= (unsigned)((samebits >> (k * 4 + lvl)) & 1ull) << k;
         same = __builtin_amdgcn_readfirstlane(same);
         PIPS_TR(3 + 3 * lvl);
-        run_level<NS>(map, mapn, lvl + 1 < PIPS_LEVELS, g, gn, smem, wave, lane, same, ffeats, geo_row, doff, A, acc);
+        run_level<NS>(map, mapn, lvl + 1 < PIPS_LEVELS, g, gn, smem, wave, lane, same, skip, ffeats, geo_row, doff, A, acc);
         PIPS_TR(4 + 3 * lvl);
         // blend the 8x8 correlations to the 49 taps, k = level*49 + ix*7 + iy (transposed, :379-381)
 #pragma unroll
@@ -408,7 +409,8 @@ __device__ __forceinline__ void tile_body(const float* __restrict__ pyramid, con
             const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo_wy), k * 4 + lvl));
             const int row = __builtin_amdgcn_readlane(geo_row, k * 4);
             const float o = blend_taps(((inmask >> k) & 1u) ? (acc[k].x + acc[k].y) / scale : 0.f, wx, wy, lane);   // :397
-            if (lane < 49) X[(size_t)row * PIPS_KIN_PAD + C + lvl * 49 + lane] = o;
+            // (a wave that skipped its last slot must not store it: the slot aliases the wave's last real particle)
+            if (lane < 49 && !(k == NS - 1 && skip)) X[(size_t)row * PIPS_KIN_PAD + C + lvl * 49 + lane] = o;
         }
         PIPS_TR(5 + 3 * lvl);
         g = gn; map = mapn;
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(NW * 64, 8) void gather_tiled_kernel(const float* _
     PIPS_TR(2);
 #define PIPS_TILE_CASE(NS_)                                                                                          \
     tile_body<NS_>(pyramid, lv, frame_base, tx, ty, smem, wave, lane, map, g, doff, ffeats, geo_bx, geo_by, geo_wx,  \
-                   geo_wy, geo_row, samebits, X)
+                   geo_wy, geo_row, samebits, (unsigned)__builtin_amdgcn_readfirstlane(nslot < NS_ ? 1 : 0), X)
 #ifdef PIPS_TILE_ONLY
     (void)ns;
     PIPS_TILE_CASE(PIPS_TILE_ONLY);
