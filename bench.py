@@ -1,21 +1,28 @@
 #!/usr/bin/env python
 """bench.py -- particle-updates/s of the PIPs inference hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3] [--no-extras] [--no-cpu-baseline]
 
 One "step" = one whole ``Pips.forward`` (encoder + 6 update iterations) over one batch of
 synthetic clips already resident in HBM.  Workload = BASELINE.json configs[1]:
 B=1 clip per GPU, S=8 frames, 368x496, N=256 particles, I=6 iterations, fp32, stride 8,
 seeded random-init weights (the reference checkpoint is not obtainable offline).
-N>1: one process per GPU (torch.distributed.run), clips sharded on the batch axis
-(weak scaling), one RCCL all-gather of the final [x,y,vis] per step.
+
+--gpus N > 1: one process per GPU, clips sharded on the batch axis (weak scaling), one RCCL
+all-gather of the final [x,y,vis] per step.  Launched by ``python -m torch.distributed.run``
+the script reads RANK/LOCAL_RANK/WORLD_SIZE; launched bare (WORLD_SIZE unset) it re-executes
+itself under torch.distributed.run with N ranks.  WORLD_SIZE != N is an error.
 
 Prints ONE JSON line (rank 0): the driver contract plus
-  "roofline"     -- dominant kernel (fp32-MFMA GEMM of the mixer) vs the 157.3 TF fp32 peak,
-                    timed live with HIP events on the launch stream;
-  "gather"       -- the fused correlation-gather kernel vs the HBM roofline (compulsory bytes);
-  "stages_ms"    -- where one forward's time goes;
-  "cpu_baseline" -- the CPU oracle (a port of the reference forward) on this host, N=1 only.
+  "roofline"            -- dominant kernel (fp32-MFMA GEMM of the mixer) vs the 157.3 TF fp32 peak,
+                           timed live with HIP events on the launch stream;
+  "gather"              -- the correlation-gather kernel at config 2 (L2-resident; informational);
+  "stages_ms"           -- where one forward's time goes;
+  "config3"/"config4"/"config5" -- the other BASELINE configs, each with its own numbers; config4
+                           carries the HBM roofline of the correlation gather (SURVEY.md 8(d)(i) bytes);
+  "torch_rocm_baseline" -- the same forward through stock PyTorch-ROCm ops (oracle restatement on device
+                           tensors: MIOpen/rocBLAS) on this GPU -- the same-hardware comparator;
+  "cpu_baseline"        -- the CPU oracle (a port of the reference forward) on this host, N=1 only.
 """
 from __future__ import annotations
 
@@ -23,30 +30,43 @@ import argparse
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch                       # noqa: E402
-import torch.distributed as dist   # noqa: E402
-
-B_PER_GPU, S, H, W, NPTS, ITERS, STRIDE = 1, 8, 368, 496, 256, 6, 8
+S, H, W, NPTS, ITERS, STRIDE = 8, 368, 496, 256, 6, 8
 PEAK_F32_MFMA_TF = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TF = 2500.0         # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (16x the fp32 MFMA rate)
 PEAK_HBM_GBS = 8000.0              # spec; 6290 measured-achievable
 
 
-def make_inputs(rank, device):
+def respawn_under_launcher(gpus):
+    """Bare ``python bench.py --gpus N`` (N > 1): run N ranks of this script on this node."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def make_inputs(rank, device, b, h=H, w=W, n=NPTS):
+    import torch
     g = torch.Generator().manual_seed(1 + rank)
-    rgbs = torch.randint(0, 256, (B_PER_GPU, S, 3, H, W), generator=g).float()
-    xys = torch.rand(B_PER_GPU, NPTS, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])
+    rgbs = torch.randint(0, 256, (b, S, 3, h, w), generator=g).float()
+    xys = torch.rand(b, n, 2, generator=g) * torch.tensor([w - 1.0, h - 1.0])
     return xys.to(device), rgbs.to(device)
 
 
 def ev_time_ms(fn, reps):
     """Average milliseconds of fn() over reps calls, HIP events on the current stream."""
+    import torch
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -57,15 +77,14 @@ def ev_time_ms(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def stage_profile(model, xys, rgbs, device):
+def stage_profile(model, xys, rgbs, device, b):
     """Per-stage and per-kernel timings with the staged C-ABI entry points (same kernels)."""
-    from pips_amd import ops, _lib
-    from pips_amd.weights import MIX_DEPTH
-    lib = _lib.load()
+    import torch
+    from pips_amd import ops
     arena = model._packed(device)
-    F = B_PER_GPU * S
+    F = b * S
     H8, W8 = H // STRIDE, W // STRIDE
-    M = B_PER_GPU * NPTS * S
+    M = b * NPTS * S
     frames = rgbs.reshape(F, 3, H, W)
     pyr = ops.encoder_fwd(arena, frames, STRIDE)
     out = {}
@@ -73,43 +92,32 @@ def stage_profile(model, xys, rgbs, device):
     g = torch.Generator().manual_seed(0)
     ffeats = torch.randn(M, 128, generator=g).to(device)
     coords = (torch.rand(M, 2, generator=g) * torch.tensor([W8 - 1.0, H8 - 1.0])).to(device)
-    X = ops.mixer_input_build(pyr, B_PER_GPU, H8, W8, ffeats, coords)
-    t_gather = ev_time_ms(lambda: ops.mixer_input_build(pyr, B_PER_GPU, H8, W8, ffeats, coords), 20)
+    X = ops.mixer_input_build(pyr, b, H8, W8, ffeats, coords)
+    t_gather = ev_time_ms(lambda: ops.mixer_input_build(pyr, b, H8, W8, ffeats, coords), 20)
     out["mixer_input(gather)"] = t_gather * ITERS
     delta = ops.mixer_fwd(arena, X)
     out["mixer"] = ev_time_ms(lambda: ops.mixer_fwd(arena, X), 5) * ITERS
     c0 = coords.clone()
     out["state_update"] = ev_time_ms(
-        lambda: ops.state_update(arena, delta, ffeats, coords, c0, B_PER_GPU, NPTS, float(STRIDE)), 10) * ITERS
+        lambda: ops.state_update(arena, delta, ffeats, coords, c0, b, NPTS, float(STRIDE)), 10) * ITERS
 
     # dominant kernel: the channel-mix GEMMs (igemm_f32_kernel), timed IN SITU: a real mixer pass
     # on the real weights/activations with a HIP event pair around every GEMM launch on the
     # launch stream (pips_mixer_fwd_timed); mean over the 12 layers and 5 passes.
-    ups, downs, ovh = [], [], []
-    for _ in range(5):
-        _, t = ops.mixer_fwd_timed(arena, X)
-        ups.append(t["up_proj"])
-        downs.append(t["down_proj"])
-        ovh.append(t["event_overhead"])
-    # an event pair costs a marker-to-marker gap even with nothing between; subtract it
-    t_ovh = sum(ovh) / len(ovh)
-    t_up = sum(ups) / len(ups) - t_ovh
-    t_down = sum(downs) / len(downs) - t_ovh
+    def timed(flags):
+        ups, downs, ovh = [], [], []
+        for _ in range(5):
+            _, t = ops.mixer_fwd_timed(arena, X, flags=flags)
+            ups.append(t["up_proj"]); downs.append(t["down_proj"]); ovh.append(t["event_overhead"])
+        o = sum(ovh) / len(ovh)      # an event pair costs a marker-to-marker gap even with nothing between
+        return sum(ups) / len(ups) - o, sum(downs) / len(downs) - o
+    t_up, t_down = timed(0)
     flops = 2.0 * M * 2048 * 512
     kern = {
         "up_proj(M=%d,N=2048,K=512)" % M: {"ms": t_up, "tflops": flops / t_up / 1e9},
         "down_proj(M=%d,N=512,K=2048)" % M: {"ms": t_down, "tflops": flops / t_down / 1e9},
     }
-    # the same two launches on the split-bf16 path (gemm_x3_kernel): fp32-equivalent rate, and the bf16
-    # MFMA work actually issued (6 products per fp32 product) against the dense bf16 peak
-    ups, downs, ovh = [], [], []
-    for _ in range(5):
-        _, t = ops.mixer_fwd_timed(arena, X, flags=16)
-        ups.append(t["up_proj"])
-        downs.append(t["down_proj"])
-        ovh.append(t["event_overhead"])
-    s_ovh = sum(ovh) / len(ovh)
-    s_up, s_down = sum(ups) / len(ups) - s_ovh, sum(downs) / len(downs) - s_ovh
+    s_up, s_down = timed(16)
     split = {
         "up_proj_ms": s_up, "down_proj_ms": s_down,
         "fp32_equiv_tflops": {"up_proj": flops / s_up / 1e9, "down_proj": flops / s_down / 1e9},
@@ -118,23 +126,134 @@ def stage_profile(model, xys, rgbs, device):
         "mixer_ms": ev_time_ms(lambda: ops.mixer_fwd(arena, X, split=True), 5) * ITERS,
         "encoder_ms": min(ev_time_ms(lambda: ops.encoder_fwd(arena, frames, STRIDE, split=True), 3) for _ in range(3)),
     }
-    # gather: compulsory bytes per launch: pyramid + ffeats + coords + fcorrs
     lv = sum((H8 >> l) * (W8 >> l) for l in range(4))
-    comp_bytes = B_PER_GPU * S * (lv * 128 * 4 + NPTS * 128 * 4 + NPTS * 8 + NPTS * 196 * 4)
-    gathered_bytes = M * (4 * 64 * 128 * 4 + 128 * 4 + 8 + 196 * 4)
+    comp_bytes = b * S * (lv * 128 * 4 + NPTS * 128 * 4 + NPTS * 8 + NPTS * 196 * 4)
     gather = {
-        "kernel": "mixer_input_kernel",
-        "ms_per_launch": t_gather,
+        "kernel": "mixer_input_kernel", "ms_per_launch": t_gather,
         "compulsory_GBs": comp_bytes / t_gather / 1e6,
-        "gathered_GBs(L2-level)": gathered_bytes / t_gather / 1e6,
-        "frac_of_hbm_peak": comp_bytes / t_gather / 1e6 / PEAK_HBM_GBS,
-        "note": "config 2's 18 MB footprint is L2/MALL-resident; HBM fraction is meaningful at config 4",
+        "note": "config 2's 18 MB footprint is L2/MALL-resident: launch-latency-bound; the HBM roofline of the "
+                "gather is reported at config 4 (config4.gather_roofline)",
     }
     return out, kern, gather, split
 
 
+def config3_leg(device):
+    """BASELINE configs[2] per-GPU share: B=8 clips, bf16 MFMA operands."""
+    import torch
+    from pips_amd import Pips
+    b = 8
+    model = Pips(S=S, stride=STRIDE).to(device).eval()
+    model.mixer_dtype = model.encoder_dtype = torch.bfloat16
+    xys, rgbs = make_inputs(0, device, b)
+    fn = lambda: model(xys, rgbs, iters=ITERS)
+    for _ in range(2):
+        fn()
+    t = ev_time_ms(fn, 5)
+    flop_per_update = 72.2e6
+    ups = b * S * NPTS * ITERS / t * 1e3
+    return {"workload": "BASELINE configs[2], one GPU's share: B=8 S=8 368x496 N=256 I=6, bf16 MFMA operands "
+                        "(fp32 accumulate/state), encoder included",
+            "value": ups, "unit": "particle-updates/s", "ms_per_step": t, "dtype": "bf16 MFMA operands",
+            "roofline": {"bound": "mfma", "achieved": ups * flop_per_update / 1e12, "peak": PEAK_BF16_MFMA_TF,
+                         "unit": "TFLOP/s", "frac": ups * flop_per_update / 1e12 / PEAK_BF16_MFMA_TF,
+                         "note": "whole forward: 72.2 MFLOP per particle-update (SURVEY 8d) against the dense bf16 MFMA peak"}}
+
+
+def config4_leg(device):
+    """BASELINE configs[3]: B=4 S=8 720x1280, N=4096 on a 64x64 grid, I=6, fp32.  The HBM-bound kernel of
+    the config is the correlation gather: timed per launch with HIP events around the kernel itself,
+    against SURVEY.md 8(d)(i) compulsory bytes (pyramid + ffeats + coords + fcorrs = 483.9 MB)."""
+    import torch
+    from pips_amd import Pips, ops
+    b, h, w, n = 4, 720, 1280, 4096
+    model = Pips(S=S, stride=STRIDE).to(device).eval()
+    g = torch.Generator().manual_seed(1)
+    rgbs = torch.randint(0, 256, (b, S, 3, h, w), generator=g, dtype=torch.uint8).to(device).float()
+    k = int(round(n ** 0.5))
+    gy, gx = torch.meshgrid(torch.linspace(8, h - 8, k), torch.linspace(8, w - 8, k), indexing="ij")
+    xys = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1).unsqueeze(0).repeat(b, 1, 1).to(device)
+    fwd = lambda: model(xys, rgbs, iters=ITERS)
+    preds = fwd()[0]
+    t_fwd = ev_time_ms(fwd, 2)
+    # gather in isolation on the real maps: iteration-0 state (the dense grid) and the state after 6 updates
+    arena = model._packed(device)
+    H8, W8, F, M = h // STRIDE, w // STRIDE, b * S, b * n * S
+    pyr = ops.encoder_fwd(arena, rgbs.reshape(F, 3, h, w), STRIDE)
+    ffeats = torch.randn(M, 128, generator=g).to(device)        # (values do not influence the timing)
+    lv = sum((H8 >> l) * (W8 >> l) for l in range(4))
+    comp = F * (lv * 512 + n * 512 + n * 8 + n * 196 * 4)                          # SURVEY 8(d)(i): 483.9 MB
+    out = {}
+    for name, coords_bsn in (("iter0_grid", (xys / STRIDE).unsqueeze(1).expand(b, S, n, 2)), ("after_6_updates", preds[-1] / STRIDE)):
+        c = coords_bsn.permute(0, 2, 1, 3).reshape(M, 2).contiguous()
+        ts = {"bin": [], "embed": [], "gather": []}
+        for i in range(12):
+            _, t = ops.mixer_input_build_tiled_timed(pyr, b, H8, W8, ffeats, c)
+            if i >= 2:
+                for kk in ts:
+                    ts[kk].append(t[kk])
+        tg = statistics.mean(ts["gather"])
+        t_direct = ev_time_ms(lambda: ops.mixer_input_build(pyr, b, H8, W8, ffeats, c), 3)
+        out[name] = {"gather_tiled_kernel_ms": tg, "bin_particles_kernel_ms": statistics.mean(ts["bin"]),
+                     "embed_rows_kernel_ms": statistics.mean(ts["embed"]), "direct_kernel_ms(mixer_input_kernel)": t_direct,
+                     "achieved_GBs": comp / tg / 1e6, "frac_of_8TBs": comp / tg / 1e6 / PEAK_HBM_GBS}
+    dom = out["iter0_grid"]
+    return {"workload": "BASELINE configs[3]: B=4 S=8 720x1280 N=4096 (64x64 grid) I=6 fp32 stride 8, encoder included",
+            "value": b * S * n * ITERS / t_fwd * 1e3, "unit": "particle-updates/s", "ms_per_step": t_fwd, "dtype": "f32",
+            "gather_roofline": {"bound": "hbm", "kernel": "gather_tiled_kernel", "achieved": dom["achieved_GBs"],
+                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": None,
+                                "algorithmic_bytes_per_launch": comp,
+                                "timing": "HIP event pair around the kernel launch (pips_mixer_input_build_tiled_timed), "
+                                          "mean of 10 launches on the real maps"},
+            "gather": out}
+
+
+def config5_leg(device):
+    """BASELINE configs[4]: 100-frame clip (synthetic 360x640 frames: demo_images/ is not on the bench box),
+    stride 4, N=256 grid at frame 0, visibility-aware chaining (chain_demo.py:40-83) on the cached maps."""
+    import torch
+    from pips_amd import Pips, drivers
+    T, h, w, n = 100, 360, 640, 256
+    model = Pips(S=S, stride=4).to(device).eval()
+    g = torch.Generator().manual_seed(3)
+    rgbs = torch.randint(0, 256, (1, T, 3, h, w), generator=g, dtype=torch.uint8).to(device).float()
+    gy, gx = torch.meshgrid(torch.linspace(16, h - 16, 16), torch.linspace(16, w - 16, 16), indexing="ij")
+    xy0 = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1).unsqueeze(0).to(device)
+    drivers.track_chained(model, rgbs, xy0, iters=ITERS)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    drivers.track_chained(model, rgbs, xy0, iters=ITERS)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "BASELINE configs[4]: 100 frames 360x640 (synthetic), stride 4, N=256, S=8 windows chained on "
+                        "visibility, encoder once per frame", "seconds_per_video": dt, "frames_x_tracks_per_s": T * n / dt}
+
+
+def torch_rocm_baseline(device):
+    """The same forward through stock PyTorch-ROCm ops on this GPU (checker code on device tensors)."""
+    import torch
+    from oracle import pips_oracle as O
+    from pips_amd.weights import init_state_dict
+    sd = {k: v.to(device) for k, v in init_state_dict(0).items()}
+    xys, rgbs = make_inputs(0, device, 1)
+    fn = lambda: O.forward(sd, xys, rgbs, iters=ITERS, stride=STRIDE)
+    t_start = time.time()
+    with torch.no_grad():
+        fn()                                   # MIOpen / rocBLAS warm-up (kernel selection)
+        fn()
+        torch.cuda.synchronize()
+        if time.time() - t_start > 90:
+            reps = 1
+        else:
+            reps = 5
+        t = ev_time_ms(fn, reps)
+    return {"value": S * NPTS * ITERS / t * 1e3, "unit": "particle-updates/s", "ms_per_step": t,
+            "what": f"oracle/pips_oracle.py (bit-identical restatement of nets/pips.py) on cuda tensors, torch {torch.__version__} "
+                    "eager fp32 (MIOpen convs, rocBLAS matmuls), same workload as the headline"}
+
+
 def cpu_baseline():
     """The CPU oracle (port of nets/pips.py forward) on this host: same workload, bounded sample."""
+    import torch
     from oracle import pips_oracle as O
     from pips_amd.weights import init_state_dict
     from oracle.hostinfo import effective_cpus
@@ -157,46 +276,74 @@ def cpu_baseline():
                       f"torch {torch.__version__} CPU ops, oracle/pips_oracle.py"}
 
 
-def main():
+class _CpuStandIn:
+    """PIPS_BENCH_FAKE=1 (launcher self-test on a box without GPUs): stands in for Pips on CPU tensors."""
+
+    def __call__(self, xys, rgbs, iters=6, **kw):
+        b, n, _ = xys.shape
+        base = xys.reshape(b, 1, n, 2).repeat(1, rgbs.shape[1], 1, 1) + rgbs.mean(dim=(2, 3, 4)).reshape(b, -1, 1, 1)
+        preds = [base + i for i in range(iters)]
+        return preds, [base, base] + preds + [preds[-1]] * 2, base.sum(-1), None
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config 3/4/5 legs and the torch-ROCm baseline")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3),
                     help="2 (default, the headline: B=1/GPU fp32) or 3 (B=8/GPU, bf16 MFMA operands)")
     ap.add_argument("--matmul", default="exact", choices=("exact", "split"),
                     help="config 2 only: exact-fp32 MFMA (default, the headline) or the fp32-grade split-bf16 path")
-    args = ap.parse_args()
-    global B_PER_GPU
-    if args.config == 3:
-        B_PER_GPU = 8
+    args = ap.parse_args(argv)
+    gpus = max(1, args.gpus)
+    if "WORLD_SIZE" not in os.environ and gpus > 1:
+        sys.exit(respawn_under_launcher(gpus))
 
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # one rank per GPU; PIPS_BENCH_BACKEND=gloo (smoke-testing the launcher on a 1-GPU box) lets
-    # several ranks share a device
+    if world != gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {gpus} bench.py --gpus {gpus} ...)")
+    fake = os.environ.get("PIPS_BENCH_FAKE") == "1"
+    # one rank per GPU over RCCL; PIPS_BENCH_BACKEND=gloo (launcher smoke test on a 1-GPU or GPU-less box)
+    # lets several ranks share a device
     backend = os.environ.get("PIPS_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local = local % torch.cuda.device_count()
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
+    if fake:
+        device = torch.device("cpu")
+    else:
+        if backend != "nccl":
+            local = local % torch.cuda.device_count()
+        elif local >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} needs cuda:{local}, only {torch.cuda.device_count()} device(s) visible")
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
+        if backend == "nccl" and not fake:
             dist.init_process_group("nccl", device_id=device)
         else:
-            dist.init_process_group(backend)
-    assert world == max(1, args.gpus) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+            dist.init_process_group("gloo")
+    sync = (lambda: None) if fake else torch.cuda.synchronize
 
-    from pips_amd import Pips, dist as pdist
-    model = Pips(S=S, stride=STRIDE).to(device).eval()               # seeded random init (seed 0)
-    if args.config == 3:
-        model.mixer_dtype = model.encoder_dtype = torch.bfloat16     # BASELINE configs[2]
-    model.matmul = args.matmul
-    xys, rgbs = make_inputs(rank, device)
+    from pips_amd import dist as pdist
+    b_per_gpu = 8 if args.config == 3 else 1
+    if fake:
+        model = _CpuStandIn()
+        xys, rgbs = make_inputs(rank, device, b_per_gpu, 32, 32, 16)
+    else:
+        from pips_amd import Pips
+        model = Pips(S=S, stride=STRIDE).to(device).eval()               # seeded random init (seed 0)
+        if args.config == 3:
+            model.mixer_dtype = model.encoder_dtype = torch.bfloat16     # BASELINE configs[2]
+        model.matmul = args.matmul
+        xys, rgbs = make_inputs(rank, device, b_per_gpu)
 
     def step():
         preds, _, vis, _ = model(xys, rgbs, iters=ITERS)
@@ -208,20 +355,20 @@ def main():
         step()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([dt], device=device if (backend == "nccl" and not fake) else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    updates = world * B_PER_GPU * S * NPTS * ITERS * args.steps
+    updates = world * b_per_gpu * S * (16 if fake else NPTS) * ITERS * args.steps
     res = {
         "metric": "particle-updates/sec (B*S*N*iters/s) at S=8 N=256 368x496",
         "value": updates / dt,
@@ -241,42 +388,47 @@ def main():
                                 "inputs resident in HBM") if args.config == 2 else
                                ("BASELINE configs[2]: B=8/GPU S=8 368x496 N=256 I=6 bf16 operands stride 8, encoder "
                                 "included, inputs resident in HBM"),
-                   "clips_per_gpu": B_PER_GPU, "parallelism": f"clip-sharded x{world}"},
+                   "clips_per_gpu": b_per_gpu, "parallelism": f"clip-sharded x{world}",
+                   "collective": ("none" if world == 1 else f"one all_gather of [x,y,vis] per step, backend "
+                                  f"{'gloo' if (fake or backend != 'nccl') else 'nccl (RCCL)'}")},
     }
-    if rank == 0 and world == 1 and args.config == 2 and args.matmul == "exact" and not args.no_stage_profile:
+    if fake:
+        res["data"] = "PIPS_BENCH_FAKE=1: CPU stand-in model, launcher/collective self-test only -- not a measurement"
+    headline = rank == 0 and world == 1 and args.config == 2 and args.matmul == "exact" and not fake
+    if headline and not args.no_stage_profile:
         # the same workload on the fp32-grade split-bf16 matrix path (Pips.matmul = "split"; passes the
         # same fp32 parity gates, tests/test_forward_gpu.py) -- reported beside the exact-fp32 headline
         model.matmul = "split"
         for _ in range(args.warmup):
             step()
-        torch.cuda.synchronize()
+        sync()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        torch.cuda.synchronize()
+        sync()
         dts = time.perf_counter() - t1
         model.matmul = "exact"
         res["split_bf16"] = {"value": updates / dts, "unit": "particle-updates/s", "ms_per_step": dts / args.steps * 1e3,
                              "note": "Pips.matmul='split' (PIPS_FLAG_SPLIT_BF16): mixer GEMMs + the larger convs as "
                                      "6 exact bf16 MFMA products per fp32 product; same parity gates as fp32"}
-    if rank == 0 and not args.no_stage_profile and args.config == 2 and args.matmul == "exact":
-        stages, kern, gather, split = stage_profile(model, xys, rgbs, device)
-        if "split_bf16" in res:
-            res["split_bf16"].update(split)
+        stages, kern, gather, split = stage_profile(model, xys, rgbs, device, b_per_gpu)
+        res["split_bf16"].update(split)
         dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
-        # HBM-side bytes per launch of that kernel from the committed PMC passes (separate rocprofv3
-        # --pmc FETCH_SIZE / WRITE_SIZE runs of this command; profiles/r1_pmc_traffic.json)
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
-            key = "pips::igemm_f32_kernel<64, 64, 2, 2, 1, false>" if dom[0].startswith("up") else \
-                "pips::igemm_f32_kernel<64, 64, 2, 2, 2, false>"
-            traffic = pmc[key]["hbm_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM-side bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+        # command, committed per round under profiles/ (a live bench run cannot collect PMC counters itself)
+        traffic, traffic_src = None, None
+        for name in ("r2_pmc_traffic.json",):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+                key = "pips::igemm_f32_kernel<64, 64, 2, 2, 1, false>" if dom[0].startswith("up") else \
+                    "pips::igemm_f32_kernel<64, 64, 2, 2, 2, false>"
+                traffic, traffic_src = pmc[key]["hbm_bytes"], "profiles/" + name
+            except (OSError, KeyError, ValueError):
+                pass
         # both GEMM shapes run the same kernel template; report the slower (dominant) launch
         res["roofline"] = {"bound": "mfma", "achieved": dom[1]["tflops"], "peak": PEAK_F32_MFMA_TF,
                            "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_F32_MFMA_TF, "traffic": traffic,
+                           "traffic_source": traffic_src,
                            "kernel": "igemm_f32_kernel " + dom[0], "launch_ms": dom[1]["ms"],
                            "timing": "HIP event pair around each in-situ launch, empty-pair overhead subtracted",
                            "all": kern}
@@ -284,12 +436,22 @@ def main():
         res["stages_ms"] = stages
         flop_per_update = 72.2e6
         res["forward_mfma_frac"] = res["value"] / world * flop_per_update / (PEAK_F32_MFMA_TF * 1e12)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:
+    if headline and not args.no_extras:
+        for name, leg in (("config3", config3_leg), ("config4", config4_leg), ("config5", config5_leg),
+                          ("torch_rocm_baseline", torch_rocm_baseline)):
+            try:
+                torch.cuda.empty_cache()
+                res[name] = leg(device)
+            except Exception as e:                                   # a leg must not take the headline down
+                res[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    if headline and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return res
 
 
 if __name__ == "__main__":

@@ -13,10 +13,13 @@
  *     last error of the calling thread is available from pips_last_error();
  *   - all pointers are DEVICE pointers unless the name ends in _host;
  *   - the caller owns every buffer (inputs, outputs, weight arena, workspace); the
- *     library never allocates, frees or synchronises (pips_mixer_fwd_timed excepted), and keeps
- *     no mutable state between calls beyond idempotent one-time settings (kernel LDS-size
- *     attributes, PIPS_* tuning environment variables read once): calls are re-entrant,
- *     stream-ordered on `stream` (a hipStream_t passed as void*) and safe to capture in a hipGraph;
+ *     library never allocates, frees or synchronises (the *_timed entry points excepted).  The
+ *     only state kept between calls is idempotent: the dynamic-LDS attribute of each kernel
+ *     instantiation (raised on its first launch on a device, tracked per device with atomics)
+ *     and PIPS_* tuning environment variables read once.  Calls are re-entrant and stream-ordered
+ *     on `stream` (a hipStream_t passed as void*).  hipGraph capture: run the same call once
+ *     eagerly first (so no attribute is set while capturing), then capture and replay -- replays
+ *     are bit-identical to the eager call (tests/test_forward_gpu.py::test_forward_in_hip_graph);
  *   - all tensors are dense fp32 unless stated; "frames" F = B*S; mixer rows are ordered
  *     m = (b*N + n)*S + s ("particle-major"), map levels are channel-last
  *     [F][H_l][W_l][128].
@@ -132,6 +135,13 @@ int    pips_encoder_fwd_bf16(const void* arena, const float* rgbs, int F, int H,
 int    pips_encoder_fwd_ex(const void* arena, const void* rgbs, int F, int H, int W, int stride, int flags,
                            float* pyramid, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The callers' frame pre-processing (demo.py:22-28, chain_demo.py:26-28, test_on_davis.py:93-95):
+ * F.interpolate(rgbs, (H,W), mode='bilinear') (align_corners=False) of decoded frames, on the device.
+ * src: planes = F*3 images of h x w, uint8 (src_is_u8 != 0) or float; dst: float (planes,H,W), values 0..255,
+ * i.e. exactly what pips_forward / pips_encoder_fwd take as rgbs. */
+int    pips_resize_frames(const void* src, int src_is_u8, int planes, int h, int w,
+                          float* dst, int H, int W, void* stream);
+
 /* utils.samp.bilinear_sample2d (utils/samp.py:5-78): clamped-index point sample of frame
  * 0 of every clip.  xy (B,N,2) in map pixels -> out (B,N,128). */
 int    pips_point_sample(const float* level0, int B, int S, int H8, int W8,
@@ -145,15 +155,22 @@ int    pips_mixer_input_build(const float* pyramid, int B, int S, int H8, int W8
                               const float* ffeats, const float* coords, const float* times,
                               int N, float* X, void* stream);
 
-/* Same result as pips_mixer_input_build through the LDS-tiled kernel meant for dense query sets
- * (particles binned by 16x16 map tile, the tile's halo region staged in LDS once per tile).
- * Opt-in: slower than the direct kernel at the measured sizes, kept for the
- * dense-grid work of later rounds; pips_track uses it only under PIPS_GATHER_TILED=1.  scratch
- * holds the per-frame sort; values agree with the direct kernel to fp32 summation order. */
+/* Same result as pips_mixer_input_build through the LDS-tiled kernels meant for dense query sets
+ * (BASELINE configs[3], test_on_davis.py:103-130): particles binned by 16x16 map tile, the tile's
+ * halo region at each level staged in LDS once per tile (csrc/gather_tiled.hip).  pips_track /
+ * pips_forward pick it by themselves when the query set is dense (>= 1024 particles and >= 16 per
+ * tile on average; PIPS_GATHER_TILED=0/1 overrides).  scratch holds the per-frame sort; values agree
+ * with the direct kernel to fp32 summation order.  The _timed form also returns the HIP-event
+ * durations (ms) of its three launches {bin_particles, embed_rows, gather_tiled} in ms3_host and
+ * synchronises the stream (measurement only). */
 size_t pips_gather_scratch_bytes(int B, int N, int H8, int W8);
 int    pips_mixer_input_build_tiled(const float* pyramid, int B, int S, int H8, int W8,
                                     const float* ffeats, const float* coords, const float* times,
                                     int N, float* X, void* scratch, size_t scratch_bytes, void* stream);
+int    pips_mixer_input_build_tiled_timed(const float* pyramid, int B, int S, int H8, int W8,
+                                          const float* ffeats, const float* coords, const float* times,
+                                          int N, float* X, void* scratch, size_t scratch_bytes, void* stream,
+                                          float* ms3_host);
 
 /* MLPMixer (nets/pips.py:111-123): X (M,544) -> delta (M/8, 1040).  M = B*N*8. */
 size_t pips_mixer_workspace_bytes(int M);

@@ -13,12 +13,23 @@ from . import pips_oracle as O
 
 
 @torch.no_grad()
-def chain(sd, rgbs, xy0, iters=6, stride=8):
-    """rgbs (1,T,3,H,W), xy0 (1,N,2) -> trajs_e (1,T,N,2), list of hop sequences per particle."""
+def chain(sd, rgbs, xy0, iters=6, stride=8, cache_frames=False):
+    """rgbs (1,T,3,H,W), xy0 (1,N,2) -> trajs_e (1,T,N,2), list of hop sequences per particle.
+
+    The loop is restated statement by statement; it cannot be pinned by running chain_demo.py itself (the script imports
+    cv2 / tensorboardX / imageio, absent here), only by reading it side by side.  ``cache_frames=True`` is a cost
+    shortcut for long/large test videos, not part of the reference: every frame goes through the encoder ONCE and the
+    windows index the cached maps -- exact in real arithmetic because InstanceNorm is per frame (nets/pips.py:153-157);
+    tests/test_oracle_golden.py checks it against the faithful loop."""
     B, T = rgbs.shape[:2]
     N = xy0.shape[1]
     trajs_e = torch.zeros(B, T, N, 2)
     hops = []
+    frame_maps = None
+    if cache_frames:
+        H, W = rgbs.shape[-2:]
+        x = 2 * (rgbs[0] / 255.0) - 1.0
+        frame_maps = torch.cat([O.encoder(sd, x[t:t + 1], stride) for t in range(T)], dim=0)     # (T,128,H/s,W/s)
     for n in range(N):                                                    # chain_demo.py:40
         cur, done = 0, False
         traj_e = torch.zeros(B, T, 2)
@@ -30,8 +41,12 @@ def chain(sd, rgbs, xy0, iters=6, stride=8):
             rgb_seq = rgbs[:, cur:end]
             S_local = rgb_seq.shape[1]
             rgb_seq = torch.cat([rgb_seq, rgb_seq[:, -1].unsqueeze(1).repeat(1, 8 - S_local, 1, 1, 1)], dim=1)
+            fmaps = None
+            if frame_maps is not None:
+                idx = torch.arange(cur, cur + 8).clamp(max=T - 1)
+                fmaps = frame_maps[idx].unsqueeze(0)
             preds, _, vis, ffeat = O.forward(sd, traj_e[:, cur].reshape(1, -1, 2), rgb_seq, iters=iters,
-                                             stride=stride, feat_init=feat_init)
+                                             stride=stride, feat_init=feat_init, fmaps=fmaps)
             feat_init = ffeat                                             # :57
             vis = torch.sigmoid(vis)
             xys = preds[-1].reshape(1, 8, 2)

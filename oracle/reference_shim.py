@@ -28,7 +28,16 @@ def load_reference_pips(sd, stride=8, S=8):
         # nets/pips.py:429 does torch.tensor(0.0).cuda() (dead value); without a GPU make
         # .cuda() the identity for the duration of this process.
         torch.Tensor.cuda = lambda self, *a, **k: self
-    from nets.pips import Pips                 # noqa: E402
+    # by file path: this repository ships its own ``nets`` package (the drop-in import path), which as a regular
+    # package would shadow the reference's namespace package ``nets`` whatever the sys.path order
+    import importlib.util
+    name = "_reference_nets_pips"
+    if name not in sys.modules:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REFERENCE_ROOT, "nets", "pips.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    Pips = sys.modules[name].Pips
 
     m = Pips(S=S, stride=stride).eval()
     missing = m.load_state_dict(sd, strict=True)

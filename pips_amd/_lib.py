@@ -34,11 +34,14 @@ SIGNATURES = {
     "pips_encoder_fwd_bf16": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_encoder_fwd_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, fp, c_void_p, c_size_t,
                                     c_void_p]),
+    "pips_resize_frames": (c_int, [c_void_p, c_int, c_int, c_int, c_int, fp, c_int, c_int, c_void_p]),
     "pips_point_sample": (c_int, [fp, c_int, c_int, c_int, c_int, fp, c_int, fp, c_void_p]),
     "pips_mixer_input_build": (c_int, [fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, fp, c_void_p]),
     "pips_gather_scratch_bytes": (c_size_t, [c_int] * 4),
     "pips_mixer_input_build_tiled": (c_int, [fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, fp, c_void_p, c_size_t,
                                              c_void_p]),
+    "pips_mixer_input_build_tiled_timed": (c_int, [fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, fp, c_void_p,
+                                                   c_size_t, c_void_p, C.POINTER(c_float)]),
     "pips_mixer_workspace_bytes": (c_size_t, [c_int]),
     "pips_mixer_fwd": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_bf16": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),

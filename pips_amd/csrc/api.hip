@@ -477,6 +477,12 @@ static int encoder_impl(const void* arena_v, const void* rgbs, int F, int H, int
     return PIPS_OK;
 }
 
+int pips_resize_frames(const void* src, int src_is_u8, int planes, int h, int w, float* dst, int H, int W, void* stream) {
+    PIPS_CHECK_ARG(src && dst, "resize_frames: null pointer");
+    PIPS_CHECK_ARG(planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "resize_frames: empty image");
+    return launch_resize_frames(src, src_is_u8, planes, h, w, dst, H, W, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ tracker stages
 int pips_point_sample(const float* level0, int B, int S, int H8, int W8, const float* xy, int N, float* out,
                       void* stream) {
@@ -487,7 +493,7 @@ int pips_point_sample(const float* level0, int B, int S, int H8, int W8, const f
 // scratch != null and a dense, un-windowed query set: LDS-tiled kernel; otherwise the direct one
 static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats, const float* coords,
                        const float* times, int N, const int* win_start, float* X, hipStream_t st,
-                       void* scratch = nullptr, size_t scratch_bytes = 0, int force_tiled = -1) {
+                       void* scratch = nullptr, size_t scratch_bytes = 0, int force_tiled = -1, hipEvent_t* ev = nullptr) {
     size_t off[PIPS_LEVELS];
     int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
     lh[0] = H8; lw[0] = W8;
@@ -502,7 +508,7 @@ static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const
                           scratch_bytes >= tiled_gather_scratch_bytes(B, N, H8, W8);
     const bool tiled = force_tiled >= 0 ? (force_tiled != 0) : tiled_gather_wanted(N, H8, W8);
     if (tiled && can_tile)
-        return launch_mixer_input_tiled(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, scratch, scratch_bytes, st);
+        return launch_mixer_input_tiled(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, scratch, scratch_bytes, st, ev);
     PIPS_CHECK_ARG(force_tiled != 1, "tiled gather needs scratch of %zu bytes, no win_start and 8 frames per clip",
                    tiled_gather_scratch_bytes(B, N, H8, W8));
     return launch_mixer_input(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, win_start, X, st);
@@ -527,6 +533,23 @@ int pips_mixer_input_build_tiled(const float* pyramid, int B, int S, int H8, int
     PIPS_CHECK_ARG(S == PIPS_S && B > 0 && N > 0, "mixer_input_tiled: S must be %d", PIPS_S);
     return mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, nullptr, X, (hipStream_t)stream, scratch,
                        scratch_bytes, 1);
+}
+
+int pips_mixer_input_build_tiled_timed(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats,
+                                       const float* coords, const float* times, int N, float* X, void* scratch,
+                                       size_t scratch_bytes, void* stream, float* ms3_host) {
+    PIPS_CHECK_ARG(pyramid && ffeats && coords && times && X && scratch && ms3_host, "mixer_input_tiled_timed: null pointer");
+    PIPS_CHECK_ARG(S == PIPS_S && B > 0 && N > 0, "mixer_input_tiled: S must be %d", PIPS_S);
+    hipEvent_t ev[4];
+    for (int i = 0; i < 4; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) { set_error("hipEventCreate failed"); return PIPS_E_LAUNCH; }
+    int rc = mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, nullptr, X, (hipStream_t)stream, scratch,
+                         scratch_bytes, 1, ev);
+    if (rc == PIPS_OK && hipEventSynchronize(ev[3]) != hipSuccess) rc = PIPS_E_LAUNCH;
+    if (rc == PIPS_OK)
+        for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms3_host[i], ev[i], ev[i + 1]);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }
 
 size_t pips_mixer_workspace_bytes(int M) {
@@ -727,7 +750,7 @@ int pips_track(const void* arena, const float* pyramid, int B, int T, int H8, in
                int stride, int iters, int flags, void* workspace, size_t workspace_bytes, float* out_trajs,
                float* out_vis, float* out_ffeat0, void* stream) {
     PIPS_CHECK_ARG(arena && pyramid && xys && times && workspace && out_trajs && out_vis, "track: null pointer");
-    PIPS_CHECK_ARG(B > 0 && N > 0 && T >= 1 && iters >= 1 && stride >= 1, "track: need B,N,T,iters,stride >= 1");
+    PIPS_CHECK_ARG(B > 0 && N > 0 && T >= 1 && iters >= 0 && stride >= 1, "track: need B,N,T,stride >= 1 and iters >= 0");
     PIPS_CHECK_ARG(H8 >= 8 && W8 >= 8, "track: map %dx%d too small for a 4-level pyramid", H8, W8);
     const TrackPlan P = plan_track(B, N);
     if (workspace_bytes < P.total * sizeof(float)) {
@@ -748,6 +771,8 @@ int pips_track(const void* arena, const float* pyramid, int B, int T, int H8, in
         RUN(launch_point_sample_strided(pyramid, B, T, H8, W8, coords, S * 2, N, win_start, ffeat0, st));   // :463
     }
     RUN(launch_init_ffeats(ffeat0, B * N, ffeats, st));                                                      // :466
+    if (iters == 0)       // the loop body never runs: vis_e comes from the initial features (:559)
+        RUN(launch_vis_head((const float*)arena, ffeats, B, N, out_vis, st));
     for (int it = 0; it < iters; ++it) {                                                                     // :499
         // the mixer workspace is idle while the gather runs: it doubles as the binning scratch
         RUN(mixer_input(pyramid, B, T, H8, W8, ffeats, coords, times, N, win_start, ws + P.X, st, ws + P.mixer,
@@ -773,7 +798,7 @@ int pips_forward(const void* arena, const float* rgbs, const float* xys, const f
     PIPS_CHECK_ARG(arena && xys && times && workspace && out_trajs && out_vis, "forward: null pointer");
     PIPS_CHECK_ARG((flags & PIPS_FLAG_REUSE_MAPS) || rgbs != nullptr, "forward: rgbs is null");
     PIPS_CHECK_ARG(S == PIPS_S, "forward: S=%d, the mixer weights fix S=%d (nets/pips.py:295-301)", S, PIPS_S);
-    PIPS_CHECK_ARG(B > 0 && N > 0 && iters >= 1, "forward: need B,N >= 1 and iters >= 1");
+    PIPS_CHECK_ARG(B > 0 && N > 0 && iters >= 0, "forward: need B,N >= 1 and iters >= 0");
     RUN(check_geometry(B * S, H, W, stride));
     const FwdPlan P = plan_forward(B, S, H, W, N, stride);
     if (workspace_bytes < P.total * sizeof(float)) {

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libpips_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/pips_hip.h"
@@ -71,6 +72,22 @@ __device__ __forceinline__ f2 gelu_exact2(f2 v) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Dynamic-LDS limit of one kernel instantiation, raised once per (instantiation, device).  The only state
+// the launchers keep: an idempotent attribute, tracked per device, safe from several host threads.
+inline int ensure_dynamic_lds(std::atomic<unsigned long long>& done, const void* kern, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("hipGetDevice failed"); return PIPS_E_LAUNCH; }
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return PIPS_OK;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("cannot raise the dynamic LDS limit of a kernel to %zu bytes on device %d", bytes, dev);
+        return PIPS_E_LAUNCH;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return PIPS_OK;
+}
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---------------------------------------------------------------- GEMM / conv core
@@ -193,6 +210,7 @@ int launch_inorm_apply(const float* x, const float* stats, const float* res, con
 int launch_resize_into(const float* src, int F, int Hs, int Ws, int C, float* dst, int Hd, int Wd,
                        int Cdst, int coff, hipStream_t st);
 int launch_avgpool2(const float* src, int F, int H, int W, int C, float* dst, hipStream_t st);
+int launch_resize_frames(const void* src, int src_u8, int planes, int h, int w, float* dst, int H, int W, hipStream_t st);
 
 // ---------------------------------------------------------------- tracker pieces (track.hip)
 int launch_point_sample(const float* level0, int B, int S, int H8, int W8, const float* xy, int N,
@@ -208,13 +226,15 @@ int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* l
 // LDS-tiled gather for dense query sets (gather_tiled.hip)
 size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8);
 bool tiled_gather_wanted(int N, int H8, int W8);
+// ev != null: 4 events recorded around the three launches (bin, embed, gather)
 int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B,
                              int S, const float* ffeats, const float* coords, const float* times, int N,
-                             float* X, void* scratch, size_t scratch_bytes, hipStream_t st);
+                             float* X, void* scratch, size_t scratch_bytes, hipStream_t st, hipEvent_t* ev = nullptr);
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
                      hipStream_t st);
 int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,
                    hipStream_t st);
+int launch_vis_head(const float* arena, const float* ffeats, int B, int N, float* out_vis, hipStream_t st);
 int launch_state_update(const float* arena, const float* delta, float* ffeats, float* coords,
                         const float* coords0, int B, int N, float stride, float* out_traj,
                         float* out_vis, hipStream_t st);

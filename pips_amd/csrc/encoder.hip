@@ -300,4 +300,43 @@ int launch_avgpool2(const float* src, int F, int H, int W, int C, float* dst, hi
     return PIPS_OK;
 }
 
+// ------------------------------------------------------------------------ input resize
+// The callers' pre-processing (demo.py:22-28, chain_demo.py:26-28): decoded uint8 frames (F,3,h,w) ->
+// F.interpolate(..., (H,W), mode='bilinear') (align_corners=False, no antialias) -> float 0..255 in the
+// (F,3,H,W) layout the stem reads.  Source index = scale*(dst+0.5)-0.5 clamped at 0, second tap clamped at the
+// border, weights and blend in fp32 in ATen's order (upsample_bilinear2d: h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11)).
+template <typename T>
+__global__ __launch_bounds__(256) void resize_frames_kernel(const T* __restrict__ src, int planes, int h, int w,
+                                                            float* __restrict__ dst, int H, int W, float sh, float sw) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)planes * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const size_t pl = i / ((size_t)W * H);
+    const float fy = fmaxf(__fsub_rn(__fmul_rn(sh, (float)y + 0.5f), 0.5f), 0.f);
+    const float fx = fmaxf(__fsub_rn(__fmul_rn(sw, (float)x + 0.5f), 0.5f), 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const T* p = src + pl * (size_t)h * w;
+    const float p00 = (float)p[(size_t)y0 * w + x0], p01 = (float)p[(size_t)y0 * w + x1];
+    const float p10 = (float)p[(size_t)y1 * w + x0], p11 = (float)p[(size_t)y1 * w + x1];
+    const float top = __fadd_rn(__fmul_rn(lx0, p00), __fmul_rn(lx1, p01));
+    const float bot = __fadd_rn(__fmul_rn(lx0, p10), __fmul_rn(lx1, p11));
+    dst[i] = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+}
+
+int launch_resize_frames(const void* src, int src_u8, int planes, int h, int w, float* dst, int H, int W, hipStream_t st) {
+    const size_t total = (size_t)planes * H * W;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (src_u8)
+        hipLaunchKernelGGL(resize_frames_kernel<unsigned char>, dim3(blocks), dim3(256), 0, st, (const unsigned char*)src,
+                           planes, h, w, dst, H, W, sh, sw);
+    else
+        hipLaunchKernelGGL(resize_frames_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, planes, h, w, dst,
+                           H, W, sh, sw);
+    PIPS_CHECK_LAUNCH("resize_frames_kernel");
+    return PIPS_OK;
+}
+
 }  // namespace pips

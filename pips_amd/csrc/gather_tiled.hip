@@ -527,7 +527,7 @@ bool tiled_gather_wanted(int N, int H8, int W8) {
 
 int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B,
                              int S_, const float* ffeats, const float* coords, const float* times, int N,
-                             float* X, void* scratch, size_t scratch_bytes, hipStream_t st) {
+                             float* X, void* scratch, size_t scratch_bytes, hipStream_t st, hipEvent_t* ev) {
     const int F = B * S, H8 = lvlH[0], W8 = lvlW[0];
     PIPS_CHECK_ARG(S_ == S, "tiled gather: the map buffer must hold %d frames per clip", S);
     if (scratch_bytes < tiled_gather_scratch_bytes(B, N, H8, W8)) {
@@ -543,21 +543,25 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     const size_t bin_lds = ((size_t)2 * 16 * ntiles + ntiles + 1) * sizeof(int);
     PIPS_CHECK_ARG(bin_lds <= 64 * 1024, "tiled gather: map too large for the tile histogram");
     PIPS_CHECK_ARG((size_t)H8 * W8 * C * 4 < (1ull << 31), "tiled gather: level-0 map too large for 32-bit offsets");
+    if (ev) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(bin_particles_kernel, dim3(F), dim3(1024), bin_lds, st, coords, N, H8, W8, tiles_x, tiles_y, max_items,
                        order, items, nitems);
     PIPS_CHECK_LAUNCH("bin_particles_kernel");
     const int M = B * N * S;
+    if (ev) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(embed_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ffeats, coords, times, M, X);
     PIPS_CHECK_LAUNCH("embed_rows_kernel");
     TiledLevels lv;
     for (int l = 0; l < PIPS_LEVELS; ++l) { lv.off[l] = lvl_off[l]; lv.H[l] = lvlH[l]; lv.W[l] = lvlW[l]; }
-    if (hipFuncSetAttribute((const void*)gather_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
-        hipSuccess) {
-        set_error("tiled gather: cannot raise the dynamic LDS limit to %d bytes", LDS_BYTES);
-        return PIPS_E_LAUNCH;
+    {
+        static std::atomic<unsigned long long> raised{0};
+        const int rc = ensure_dynamic_lds(raised, (const void*)gather_tiled_kernel, LDS_BYTES);
+        if (rc != PIPS_OK) return rc;
     }
+    if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(gather_tiled_kernel, dim3(max_items * F), dim3(NW * 64), LDS_BYTES, st, pyramid, lv, S_, ffeats,
                        coords, N, tiles_x, max_items, F, order, items, nitems, X);
+    if (ev) (void)hipEventRecord(ev[3], st);
     PIPS_CHECK_LAUNCH("gather_tiled_kernel");
     return PIPS_OK;
 }

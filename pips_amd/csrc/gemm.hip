@@ -450,11 +450,9 @@ static int launch_tile(const GemmArgs& a_in, int frames, hipStream_t st) {
     size_t lds = (size_t)2 * (BM + BN) * (32 * KS + 4) * sizeof(float);
     auto kern = igemm_f32_kernel<BM, BN, WGM, WGN, KS, CONV>;
     if (lds > 64 * 1024) {
-        static bool raised = false;          // idempotent attribute, set once per instantiation
-        if (!raised) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            raised = true;
-        }
+        static std::atomic<unsigned long long> raised{0};      // per instantiation, one bit per device
+        const int rc = ensure_dynamic_lds(raised, (const void*)kern, lds);
+        if (rc != PIPS_OK) return rc;
     }
 #ifdef PIPS_GEMM_TRACE
     a.trace = trace_buffer();

@@ -323,11 +323,9 @@ static int launch_bf16_tile(const GemmArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * (BM + BN) * (64 * KS * 2 + 16);
     auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, KS, A_BF16, OUT_BF16>;
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            raised = true;
-        }
+        static std::atomic<unsigned long long> raised{0};      // per instantiation, one bit per device
+        const int rc = ensure_dynamic_lds(raised, (const void*)kern, lds);
+        if (rc != PIPS_OK) return rc;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     PIPS_CHECK_LAUNCH("gemm_bf16_kernel");

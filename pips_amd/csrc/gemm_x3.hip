@@ -338,11 +338,9 @@ static int launch_x3_tile(const GemmArgs& a, int frames, hipStream_t st) {
     const size_t lds = (size_t)2 * 3 * (BM + BN) * (BKE * KS * 2);
     auto kern = gemm_x3_kernel<BM, BN, WGM, WGN, KS, CONV, BKE>;
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            raised = true;
-        }
+        static std::atomic<unsigned long long> raised{0};      // per instantiation, one bit per device
+        const int rc = ensure_dynamic_lds(raised, (const void*)kern, lds);
+        if (rc != PIPS_OK) return rc;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     PIPS_CHECK_LAUNCH("gemm_x3_kernel");

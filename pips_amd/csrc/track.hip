@@ -534,6 +534,31 @@ __global__ __launch_bounds__(256) void state_update_kernel(const float* __restri
     }
 }
 
+// vis_predictor alone (nets/pips.py:421-426,559) on the current features: the iters = 0 forward, where
+// the reference returns the visibility logits of the INITIAL features.  One wave per mixer row.
+__global__ __launch_bounds__(256) void vis_head_kernel(const float* __restrict__ arena, size_t o_wv, size_t o_bv,
+                                                       const float* __restrict__ ffeats, int N, int M,
+                                                       float* __restrict__ out_vis) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const float* f = ffeats + (size_t)m * C;
+    float v = f[lane] * arena[o_wv + lane] + f[lane + 64] * arena[o_wv + lane + 64];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) {
+        const int t = m % S, pn = m / S, b = pn / N, n = pn - b * N;
+        out_vis[((size_t)b * S + t) * N + n] = v + arena[o_bv];
+    }
+}
+
+int launch_vis_head(const float* arena, const float* ffeats, int B, int N, float* out_vis, hipStream_t st) {
+    const ArenaLayout& A = arena_layout();
+    const int M = B * N * S;
+    hipLaunchKernelGGL(vis_head_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, arena, A.w_vis, A.b_vis, ffeats, N, M, out_vis);
+    PIPS_CHECK_LAUNCH("vis_head_kernel");
+    return PIPS_OK;
+}
+
 int launch_state_update(const float* arena, const float* delta, float* ffeats, float* coords,
                         const float* coords0, int B, int N, float stride, float* out_traj,
                         float* out_vis, hipStream_t st) {

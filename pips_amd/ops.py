@@ -78,6 +78,21 @@ def encoder_fwd(arena, rgbs, stride, bf16=False, split=False):
     return pyr
 
 
+def resize_frames(rgbs, size):
+    """uint8 or float frames (..., 3, h, w) -> float32 (..., 3, H, W), values 0..255: the on-device form of the callers'
+    ``F.interpolate(rgbs, (H, W), mode='bilinear')`` (demo.py:26-27).  Feed the result to ``Pips.forward``."""
+    lib = _lib.load()
+    H, W = int(size[0]), int(size[1])
+    h, w = rgbs.shape[-2:]
+    src = rgbs.contiguous() if rgbs.dtype == torch.uint8 else _f32(rgbs)
+    planes = src.numel() // (h * w)
+    out = torch.empty(tuple(rgbs.shape[:-2]) + (H, W), dtype=torch.float32, device=rgbs.device)
+    with torch.cuda.device(rgbs.device):
+        _lib.check(lib.pips_resize_frames(_lib.ptr(src), 1 if src.dtype == torch.uint8 else 0, planes, h, w, _lib.ptr(out),
+                                          H, W, _stream()), "pips_resize_frames")
+    return out
+
+
 def point_sample(level0, B, xy):
     """level0 (B*S,H8,W8,128), xy (B,N,2) map pixels -> (B,N,128)."""
     lib = _lib.load()
@@ -120,6 +135,24 @@ def mixer_input_build_tiled(pyr, B, H8, W8, ffeats, coords, out=None):
                                                     _lib.ptr(tt), N, _lib.ptr(X), _lib.ptr(scratch), nb, _stream()),
                    "pips_mixer_input_build_tiled")
     return X
+
+
+def mixer_input_build_tiled_timed(pyr, B, H8, W8, ffeats, coords):
+    """(X, {"bin": ms, "embed": ms, "gather": ms}): HIP-event durations of the three launches of the tiled path."""
+    lib = _lib.load()
+    ffeats, coords = _f32(ffeats), _f32(coords)
+    M = ffeats.shape[0]
+    N = M // (B * S)
+    X = torch.empty(M, KIN_PAD, dtype=torch.float32, device=ffeats.device)
+    tt = times_table(ffeats.device)
+    nb = lib.pips_gather_scratch_bytes(B, N, H8, W8)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=ffeats.device)
+    ms = (C.c_float * 3)()
+    with torch.cuda.device(ffeats.device):
+        _lib.check(lib.pips_mixer_input_build_tiled_timed(_lib.ptr(pyr), B, S, H8, W8, _lib.ptr(ffeats), _lib.ptr(coords),
+                                                          _lib.ptr(tt), N, _lib.ptr(X), _lib.ptr(scratch), nb, _stream(), ms),
+                   "pips_mixer_input_build_tiled_timed")
+    return X, {"bin": ms[0], "embed": ms[1], "gather": ms[2]}
 
 
 def mixer_fwd(arena, X, bf16=False, split=False):

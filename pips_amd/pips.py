@@ -8,11 +8,16 @@ return_feat, is_train)`` signature and the same returned tuple:
 ``(coord_predictions [iters x (B,S,N,2)], coord_predictions2 [iters+4], vis_e (B,S,N),
 losses)`` or, with ``return_feat=True``, ``(..., vis_e, ffeat (B,N,128), losses)``.
 
-Inference only: ``is_train=True`` raises; the tensorboard branches behind
-``sw.save_this`` are not drawn; ``losses`` carries ``(seq_loss, vis_loss, None)`` when
-``trajs_g`` is given (the score-map loss needs the dense correlation volume this path
-never forms, nets/pips.py:504-511,603).  There is no PyTorch fallback: without the HIP
-library or a GPU the forward raises.
+Inference only: ``is_train=True`` raises; a summary writer whose ``save_this`` is set raises
+(the tensorboard drawings of nets/pips.py:477-497,541-557,564-598 need the dense score maps this
+path never forms); ``losses`` carries ``(seq_loss, vis_loss, None)`` when ``trajs_g`` is given
+(the score-map loss needs the same volume, nets/pips.py:504-511,603).  ``S`` must be 8 (the HIP
+kernels are specialised for the window every shipped checkpoint and caller uses).  There is no
+PyTorch fallback: without the HIP library or a GPU the forward raises.
+
+Weights are repacked for the kernels when a parameter's storage or version counter changes
+(``load_state_dict``, ``.to()``, in-place ops).  Writes through ``param.data`` bump neither: call
+``invalidate_weights()`` after such surgery.
 """
 from __future__ import annotations
 
@@ -77,17 +82,30 @@ class Pips(nn.Module):
         # bf16 products per fp32 product, fp32 accumulation) -- same accuracy class, ~1.2x faster.
         self.matmul = os.environ.get("PIPS_MATMUL", "exact")      # process-wide default, e.g. for unmodified callers
         self._names = list(param_table(S).keys())
+        self._plist = None
         self._arena = None
         self._arena_key = None
         self._ws = {}
         self._times = None
 
     # ------------------------------------------------------------------ weights
+    def invalidate_weights(self):
+        """Drop the packed kernel-side copy of the weights; the next forward repacks.  Needed only after
+        writes that bypass autograd's version counter (``p.data.copy_()``, ``p.data.mul_()``)."""
+        self._arena = self._arena_key = self._plist = None
+
+    def _apply(self, fn, *a, **kw):                     # .to() / .cuda() / .float(): parameters may be re-created
+        out = super()._apply(fn, *a, **kw)
+        self.invalidate_weights()
+        return out
+
     def _packed(self, device):
-        sd = dict(self.named_parameters())
-        key = (str(device),) + tuple((sd[k].data_ptr(), sd[k]._version) for k in self._names)
+        if self._plist is None:
+            sd = dict(self.named_parameters())
+            self._plist = [sd[k] for k in self._names]
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self._plist)
         if self._arena is None or key != self._arena_key:
-            self._arena = ops.pack_weights({k: sd[k] for k in self._names}, device)
+            self._arena = ops.pack_weights(dict(zip(self._names, self._plist)), device)
             self._arena_key = key
         return self._arena
 
@@ -117,6 +135,9 @@ class Pips(nn.Module):
                 valids=None, sw=None, return_feat=False, is_train=False):
         if is_train:
             raise NotImplementedError("pips_amd.Pips is the inference path (nets/pips.py:535: is_train=False)")
+        if sw is not None and getattr(sw, "save_this", False):
+            raise NotImplementedError("pips_amd.Pips does not draw the tensorboard summaries of nets/pips.py:477-598 "
+                                      "(they need the dense score maps); pass sw=None or a writer with save_this=False")
         B, N, D = xys.shape
         assert D == 2
         B2, S, C3, H, W = rgbs.shape
@@ -240,23 +261,34 @@ class Pips(nn.Module):
 
 
 def _masked_mean(x, mask):
-    return (x * mask).sum() / (mask.sum() + 1e-6)           # utils.basic.reduce_masked_mean
+    return (x * mask).sum() / (mask.sum() + 1e-6)           # utils.basic.reduce_masked_mean (EPS = 1e-6)
+
+
+def balanced_ce_loss(pred, gt, valid=None):
+    """nets/pips.py:14-37: (balanced_loss, per-element loss).  Evaluation-side torch code on a few KB of outputs."""
+    assert pred.shape == gt.shape and (valid is None or valid.shape == gt.shape)
+    if valid is None:
+        valid = torch.ones_like(gt)
+    pos = (gt > 0.95).float()
+    neg = (gt < 0.05).float()
+    a = -(pos * 2.0 - 1.0) * pred
+    b = torch.relu(a)
+    loss = b + torch.log(torch.exp(-b) + torch.exp(a - b))
+    return _masked_mean(loss, pos * valid) + _masked_mean(loss, neg * valid), loss
+
+
+def sequence_loss(flow_preds, flow_gt, vis, valids, gamma=0.8):
+    """nets/pips.py:39-56: exponentially weighted L1 over the iterates."""
+    n = len(flow_preds)
+    loss = 0.0
+    for i, p in enumerate(flow_preds):
+        loss = loss + gamma ** (n - i - 1) * _masked_mean((p - flow_gt).abs().mean(dim=3), valids)
+    return loss / n
 
 
 def _inference_losses(preds, vis_e, trajs_g, vis_g, valids, gamma=0.8):
-    """sequence_loss / balanced_ce_loss of nets/pips.py:39-56, 14-37 on the outputs (evaluation
-    scripts pass trajs_g but discard the result, test_on_flt.py:87-100).  Plain torch on a few
-    KB of outputs -- not part of the hot path.  The score-map loss is not available."""
-    n = len(preds)
-    seq = 0.0
-    for i, p in enumerate(preds):
-        w = gamma ** (n - i - 1)
-        seq = seq + w * _masked_mean((p - trajs_g).abs().mean(dim=3), valids)
-    seq = seq / n
-    pos = (vis_g > 0.95).float()
-    neg = (vis_g < 0.05).float()
-    a = -(pos * 2.0 - 1.0) * vis_e
-    b = torch.relu(a)
-    loss = b + torch.log(torch.exp(-b) + torch.exp(a - b))
-    vis_loss = _masked_mean(loss, pos * valids) + _masked_mean(loss, neg * valids)
-    return seq, vis_loss, None
+    """The losses tuple of nets/pips.py:600-606 on the outputs (evaluation scripts pass trajs_g but discard the
+    result, test_on_flt.py:87-100): (seq_loss, vis_loss, None) -- the score-map loss needs the dense volume."""
+    if len(preds) == 0:
+        return torch.zeros((), device=vis_e.device), balanced_ce_loss(vis_e, vis_g, valids)[0], None
+    return sequence_loss(preds, trajs_g, vis_g, valids, gamma), balanced_ce_loss(vis_e, vis_g, valids)[0], None

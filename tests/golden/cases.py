@@ -49,3 +49,14 @@ def make_inputs(case: dict, seed: int = 1, S: int = 8):
         coords_init = xys.reshape(B, 1, N, 2).repeat(1, S, 1, 1) + torch.randn(B, S, N, 2, generator=g) * 2.0
         feat_init = torch.randn(B, N, 128, generator=g) * 0.5
     return xys, rgbs, coords_init, feat_init
+
+
+def make_targets(case: dict, seed: int = 7, S: int = 8):
+    """Ground-truth-like targets for the losses of nets/pips.py:600-606: (trajs_g (B,S,N,2) px, vis_g, valids (B,S,N))."""
+    B, N = case["B"], case["N"]
+    xys = make_inputs(case)[0]
+    g = torch.Generator().manual_seed(seed)
+    trajs_g = xys.reshape(B, 1, N, 2).repeat(1, S, 1, 1) + torch.randn(B, S, N, 2, generator=g) * 3.0
+    vis_g = (torch.rand(B, S, N, generator=g) > 0.3).float()
+    valids = (torch.rand(B, S, N, generator=g) > 0.1).float()
+    return trajs_g, vis_g, valids

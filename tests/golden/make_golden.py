@@ -60,5 +60,25 @@ def main():
         json.dump(keys, f, indent=0)
 
 
+def main_losses(name="s8_raw_i3"):
+    """(seq_loss, vis_loss, ce_loss) of the reference forward called with trajs_g / vis_g / valids
+    (nets/pips.py:600-606, the way test_on_flt.py:87 calls it) -> <case>_losses.npz."""
+    assert R.available(), "reference not mounted at /root/reference"
+    case = G.CASES[name]
+    sd = init_state_dict(0, tamed=case["tamed"])
+    xys, rgbs, ci, fi = G.make_inputs(case)
+    trajs_g, vis_g, valids = G.make_targets(case)
+    ref = R.load_reference_pips(sd, stride=case["stride"])
+    with torch.no_grad():
+        out = ref(xys, rgbs, coords_init=ci, feat_init=fi, iters=case["iters"], trajs_g=trajs_g, vis_g=vis_g, valids=valids)
+    seq, vis, ce = out[3]
+    np.savez_compressed(os.path.join(HERE, name + "_losses.npz"), seq_loss=np.float32(seq), vis_loss=np.float32(vis),
+                        ce_loss=np.float32(ce))
+    print(name, "losses: seq", float(seq), "vis", float(vis), "ce", float(ce))
+
+
 if __name__ == "__main__":
-    main()
+    if "--losses" not in sys.argv:
+        main()
+    main_losses("s8_raw_i3")
+    main_losses("s8_tamed_i6")

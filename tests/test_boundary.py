@@ -68,3 +68,44 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} references the oracle"
+
+
+def test_reference_import_path_resolves_to_the_hip_model():
+    """Every reference caller does `from nets.pips import Pips` (demo.py:9, chain_demo.py:9, test_on_flt.py:6, ...)."""
+    import nets.pips
+    import pips_amd
+    assert nets.pips.Pips is pips_amd.Pips
+
+
+def test_reference_saverloader_round_trip(tmp_path, weights_tamed):
+    """The reference's own saverloader.save / saverloader.load (saverloader.py:5-69), unmodified, on pips_amd.Pips
+    (build container only: needs /root/reference)."""
+    ref_root = "/root/reference"
+    if not os.path.isfile(os.path.join(ref_root, "saverloader.py")):
+        pytest.skip("reference checkout not mounted")
+    import importlib.util
+    import sys
+    sys.dont_write_bytecode = True
+    spec = importlib.util.spec_from_file_location("_reference_saverloader", os.path.join(ref_root, "saverloader.py"))
+    saverloader = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(saverloader)
+    from nets.pips import Pips
+    src = Pips(stride=8)
+    src.load_state_dict(weights_tamed)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+    ckpt_dir = str(tmp_path / "ckpt")
+    saverloader.save(ckpt_dir, opt, src, global_step=7)
+    dst = Pips(stride=8)                                        # seeded init != tamed weights
+    assert saverloader.load(ckpt_dir, dst) == 7
+    for (ka, a), (kb, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert ka == kb and torch.equal(a, b)
+
+
+def test_packed_weights_follow_parameter_changes():
+    """The kernel-side arena is rebuilt when storage or version of a parameter changes; .data writes need invalidate."""
+    from pips_amd import Pips
+    m = Pips()
+    assert m._plist is None and m._arena is None
+    m.invalidate_weights()
+    m2 = m.float()                                             # _apply path
+    assert m2 is m and m._arena is None

@@ -1,0 +1,96 @@
+"""GPU parity at the geometries of BASELINE configs[3] (720x1280, N=4096 on a 64x64 grid: the dense-query path
+through the LDS-tiled gather) and configs[4] (360x640, stride 4, chained windows over a longer video)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _grid(n, h, w, margin=8.0):
+    k = int(round(n ** 0.5))
+    gy, gx = torch.meshgrid(torch.linspace(margin, h - margin, k), torch.linspace(margin, w - margin, k), indexing="ij")
+    return torch.stack([gx.reshape(-1), gy.reshape(-1)], -1)
+
+
+def _pm(t):
+    B, S, N, X = t.shape
+    return t.permute(0, 2, 1, 3).reshape(B * N * S, X).contiguous()
+
+
+def test_config4_gather_direct_and_tiled_vs_oracle():
+    """CorrBlock.corr + sample at 90x160 maps, N=4096 grid (+ per-frame jitter, some points pushed outside):
+    both the direct kernel and the LDS-tiled kernels against the oracle, all 4096 x 8 x 196 taps."""
+    from pips_amd import ops, _lib
+    from oracle import pips_oracle as O
+    lib = _lib.load()
+    B, H8, W8, N = 1, 90, 160, 4096
+    g = torch.Generator().manual_seed(21)
+    fmaps = torch.randn(B, 8, 128, H8, W8, generator=g)
+    ffeats = torch.randn(B, 8, N, 128, generator=g)
+    coords = (_grid(N, H8 * 8, W8 * 8) / 8.0).reshape(1, 1, N, 2).repeat(B, 8, 1, 1) + torch.randn(B, 8, N, 2, generator=g) * 1.5
+    coords[0, :, 0] = torch.tensor([-6.0, 3.0])                      # window half outside / fully outside the map
+    coords[0, :, 1] = torch.tensor([W8 + 40.0, H8 + 2.0])
+    coords[0, :, 2] = torch.tensor([31.999998, 16.0])                # on tile / pixel boundaries
+    coords[0, :, 3] = torch.tensor([16.0, 47.999996])
+    pyr_ref = O.build_pyramid(fmaps)
+    ref = torch.cat([O.corr_sample(pyr_ref, ffeats[:, :, n0:n0 + 512], coords[:, :, n0:n0 + 512])
+                     for n0 in range(0, N, 512)], dim=2)             # (B,8,N,196), chunked: 236 MB of volume at a time
+    buf = torch.zeros(lib.pips_pyramid_floats(B * 8, H8 * 8, W8 * 8, 8))
+    for l, p in enumerate(pyr_ref):
+        off = lib.pips_pyramid_offset(B * 8, H8 * 8, W8 * 8, 8, l)
+        flat = p.reshape(B * 8, 128, p.shape[-2], p.shape[-1]).permute(0, 2, 3, 1).reshape(-1)
+        buf[off:off + flat.numel()] = flat
+    pyr = buf.to(DEV)
+    ff, co = _pm(ffeats).to(DEV), _pm(coords).to(DEV)
+    ref_pm = _pm(ref)
+    Xd = ops.mixer_input_build(pyr, B, H8, W8, ff, co).cpu()
+    Xt = ops.mixer_input_build_tiled(pyr, B, H8, W8, ff, co).cpu()
+    e_d = float((Xd[:, 128:324] - ref_pm).abs().max())
+    e_t = float((Xt[:, 128:324] - ref_pm).abs().max())
+    print(f"config-4 geometry gather: direct {e_d:.2e}, tiled {e_t:.2e} (|corr| ~ {float(ref_pm.abs().max()):.1f})")
+    assert e_d < 5e-5 and e_t < 5e-5                                 # 128-term fp32 dots, values O(5)
+    assert torch.equal(Xd[:, :128], Xt[:, :128]) and torch.equal(Xd[:, 324:], Xt[:, 324:])
+
+
+def test_config4_teacher_forced_iteration(weights_raw):
+    """B=1, 8 x 720x1280 frames, N=4096 grid, one update iteration through the product path (encoder -> tiled gather
+    -> mixer -> update).  Particles are independent given the maps, so the oracle (CPU) runs a 256-particle subset."""
+    from pips_amd import Pips
+    from oracle import pips_oracle as O
+    H, W, N = 720, 1280, 4096
+    g = torch.Generator().manual_seed(2)
+    rgbs = torch.randint(0, 256, (1, 8, 3, H, W), generator=g).float()
+    xys = _grid(N, H, W).unsqueeze(0)
+    sub = torch.randperm(N, generator=g)[:256]
+    ref_p, _, ref_vis, ref_ff = O.forward(weights_raw, xys[:, sub], rgbs, iters=1, stride=8)
+    m = Pips(stride=8)
+    m.load_state_dict(weights_raw)
+    m = m.to(DEV).eval()
+    preds, _, vis, ffeat, _ = m(xys.to(DEV), rgbs.to(DEV), iters=1, return_feat=True)
+    err = float((preds[0].cpu()[:, :, sub] - ref_p[0]).abs().max())
+    verr = float((vis.cpu()[:, :, sub] - ref_vis).abs().max())
+    print(f"config-4 geometry, first iterate (raw weights): max |dtraj| = {err:.2e} px, |dvis| = {verr:.2e}")
+    assert err < 1e-3 and verr < 1e-3
+    assert float((ffeat.cpu()[:, sub] - ref_ff).abs().max()) < 2e-4
+
+
+def test_config5_chained_tracking_stride4(weights_tamed):
+    """chain_demo.py geometry: 360x640 frames, stride 4, S=8 windows chained on visibility over T=24 frames, N=64
+    particles, against the loop restatement (frame maps cached in the oracle too: oracle/chain_oracle.py)."""
+    from pips_amd import Pips, drivers
+    from oracle import chain_oracle
+    g = torch.Generator().manual_seed(5)
+    T, H, W, N = 24, 360, 640, 64
+    base = torch.randint(0, 256, (1, 1, 3, H, W), generator=g).float()
+    video = torch.cat([(base * (1 - 0.02 * t) + 5.0 * t).clamp(0, 255).round() for t in range(T)], dim=1)
+    video = (video + torch.randint(0, 30, video.shape, generator=g).float()).clamp(0, 255)
+    xy0 = _grid(N, H, W, margin=16.0).unsqueeze(0)
+    ref, hops = chain_oracle.chain(weights_tamed, video, xy0, iters=6, stride=4, cache_frames=True)
+    m = Pips(stride=4)
+    m.load_state_dict(weights_tamed)
+    m = m.to(DEV).eval()
+    got = drivers.track_chained(m, video.to(DEV), xy0.to(DEV), iters=6).cpu()
+    err = float((got - ref).abs().max())
+    print("config-5 geometry chained: max |dtraj| px", err, " hops/particle", sum(len(h) for h in hops) / N)
+    assert tuple(got.shape) == (1, T, N, 2) and err < 1e-3

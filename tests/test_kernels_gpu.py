@@ -359,3 +359,28 @@ def test_state_update(weights_raw, arenas):
     assert float((traj.cpu() - co_ref * 8.0).abs().max()) < 1e-4
     assert float((vis.cpu() - vis_ref).abs().max()) < 2e-5
     assert torch.equal(traj.cpu()[:, 0], (coords0 * 8.0)[:, 0])                         # frame 0 locked
+
+
+@pytest.mark.parametrize("src_hw,dst_hw,u8", [((180, 320), (360, 640), True), ((720, 1280), (360, 640), True),
+                                              ((360, 640), (360, 640), True), ((97, 131), (368, 496), False)])
+def test_resize_frames_matches_interpolate(src_hw, dst_hw, u8):
+    """The callers' F.interpolate(rgbs, (H,W), mode='bilinear') (demo.py:26-27) on the device, from decoded uint8
+    frames: against ATen on the same values (CPU) to fp32 round-off; identity when the size is unchanged."""
+    import os
+    import numpy as np
+    from pips_amd import ops
+    g = torch.Generator().manual_seed(8)
+    if src_hw == (180, 320):
+        fr = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_half_frames.npz"))["frames"]
+        src = torch.from_numpy(fr).permute(0, 3, 1, 2).contiguous().unsqueeze(0)          # (1,8,3,180,320) uint8, real frames
+    else:
+        src = torch.randint(0, 256, (2, 3, 3) + src_hw, generator=g, dtype=torch.uint8)
+    if not u8:
+        src = src.float() + torch.rand(src.shape, generator=g)
+    ref = F.interpolate(src.float().reshape((-1, 3) + src_hw), dst_hw, mode="bilinear").reshape(src.shape[:-2] + dst_hw)
+    got = ops.resize_frames(src.to(DEV), dst_hw).cpu()
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    err = float((got - ref).abs().max())
+    assert err < 1e-4, err
+    if src_hw == dst_hw:
+        assert torch.equal(got, src.float())

@@ -54,3 +54,18 @@ def test_oracle_fp64_noise_floor(weights_tamed):
     p64 = O.forward(O.to_dtype(weights_tamed, torch.float64), xys.double(), rgbs.double(), iters=6, stride=8)[0]
     err = max(float((a.double() - b).abs().max()) for a, b in zip(p32, p64))
     assert err < 1e-3
+
+
+def test_chain_oracle_frame_cache_equals_faithful_loop(weights_tamed):
+    """oracle/chain_oracle.chain(cache_frames=True) (every frame encoded once) against its faithful form (8 frames
+    re-encoded per window, as chain_demo.py:44-54 does): same hops, same trajectories up to conv summation order."""
+    from oracle import chain_oracle
+    g = torch.Generator().manual_seed(11)
+    T, H, W, N = 13, 64, 96, 3
+    base = torch.randint(0, 256, (1, 1, 3, H, W), generator=g).float()
+    video = torch.cat([(base * (1 - 0.04 * t) + 9.0 * t).clamp(0, 255).round() for t in range(T)], dim=1)
+    xy0 = torch.rand(1, N, 2, generator=g) * torch.tensor([W - 17.0, H - 17.0]) + 8.0
+    a, ha = chain_oracle.chain(weights_tamed, video, xy0, iters=3, stride=8)
+    b, hb = chain_oracle.chain(weights_tamed, video, xy0, iters=3, stride=8, cache_frames=True)
+    assert ha == hb
+    assert float((a - b).abs().max()) < 1e-4
