@@ -49,6 +49,7 @@ def chain(sd, rgbs, xy0, iters=6, stride=8, cache_frames=False):
                                              stride=stride, feat_init=feat_init, fmaps=fmaps)
             feat_init = ffeat                                             # :57
             vis = torch.sigmoid(vis)
+            assert torch.isfinite(vis).all(), "non-finite visibility: the reference's threshold scan (:63-77) would never end"
             xys = preds[-1].reshape(1, 8, 2)
             traj_e[:, cur:end] = xys[:, :S_local]
             thr, si = 0.9, 7                                              # :63-77

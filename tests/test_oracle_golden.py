@@ -61,7 +61,7 @@ def test_chain_oracle_frame_cache_equals_faithful_loop(weights_tamed):
     re-encoded per window, as chain_demo.py:44-54 does): same hops, same trajectories up to conv summation order."""
     from oracle import chain_oracle
     g = torch.Generator().manual_seed(11)
-    T, H, W, N = 13, 64, 96, 3
+    T, H, W, N = 13, 128, 160, 3            # level-3 map 2x2: a 1-pixel level divides by (W-1)=0 (:318) and the scan never ends
     base = torch.randint(0, 256, (1, 1, 3, H, W), generator=g).float()
     video = torch.cat([(base * (1 - 0.04 * t) + 9.0 * t).clamp(0, 255).round() for t in range(T)], dim=1)
     xy0 = torch.rand(1, N, 2, generator=g) * torch.tensor([W - 17.0, H - 17.0]) + 8.0
