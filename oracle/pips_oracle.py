@@ -123,13 +123,13 @@ def corr_sample(pyramid, ffeats, coords):
     added to (x,y), :369-375)."""
     B, S, N, C = ffeats.shape
     r = RADIUS
-    d = torch.linspace(-r, r, 2 * r + 1, dtype=coords.dtype)
+    d = torch.linspace(-r, r, 2 * r + 1, dtype=coords.dtype, device=coords.device)
     delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1)          # :369-371
     outs = []
     for lvl, fm in enumerate(pyramid):
         _, _, _, H, W = fm.shape
         corr = torch.matmul(ffeats, fm.reshape(B, S, C, H * W))               # :394-395
-        corr = corr / torch.sqrt(torch.tensor(float(C), dtype=corr.dtype))    # :397
+        corr = corr / torch.sqrt(torch.tensor(float(C), dtype=corr.dtype, device=corr.device))    # :397
         centroid = coords.reshape(B * S * N, 1, 1, 2) / 2 ** lvl              # :373
         pts = centroid + delta.view(1, 2 * r + 1, 2 * r + 1, 2)               # :375
         xg = 2 * pts[..., 0:1] / (W - 1) - 1                                  # :318
@@ -145,7 +145,7 @@ def corr_sample(pyramid, ffeats, coords):
 def embed3d(xyz, C=64):
     """utils.misc.get_3d_embedding, utils/misc.py:44-69.  (M,S,3) -> (M,S,3*C+3).
     The frequency table is float32 in the reference regardless of input dtype."""
-    div = (torch.arange(0, C, 2, dtype=torch.float32) * (1000.0 / C)).to(xyz.dtype).reshape(1, 1, C // 2)
+    div = (torch.arange(0, C, 2, dtype=torch.float32, device=xyz.device) * (1000.0 / C)).to(xyz.dtype).reshape(1, 1, C // 2)
     parts = []
     for a in range(3):
         v = xyz[:, :, a:a + 1] * div
@@ -160,7 +160,7 @@ def mixer_input(ffeats, fcorrs, coords):
     B, S, N, C = ffeats.shape
     fc = fcorrs.permute(0, 2, 1, 3).reshape(B * N, S, -1)
     fl = (coords - coords[:, 0:1]).permute(0, 2, 1, 3).reshape(B * N, S, 2)
-    t = torch.linspace(0, S, S, dtype=coords.dtype).reshape(1, S, 1).repeat(B * N, 1, 1)   # :519 (0..S, not 0..S-1)
+    t = torch.linspace(0, S, S, dtype=coords.dtype, device=coords.device).reshape(1, S, 1).repeat(B * N, 1, 1)   # :519 (0..S, not 0..S-1)
     fl = torch.cat([fl, t], dim=2)
     ff = ffeats.permute(0, 2, 1, 3).reshape(B * N, S, C)
     return torch.cat([ff, fc, embed3d(fl)], dim=2)

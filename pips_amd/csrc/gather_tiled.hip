@@ -15,29 +15,32 @@
 //                          such a window is inside the map).
 //   embed_rows_kernel      feature copy + sin/cos embedding + raw flow + zero pad of every mixer row
 //                          (get_3d_embedding, utils/misc.py:44-69; DeltaBlock concat, nets/pips.py:304-308).
-//   gather_tiled_kernel    one block (16 waves) per work item, two blocks per CU (8 waves per SIMD).  32 phases =
-//                          4 levels x 8 chunks of 16 channels.  The tile's region of a (level, chunk) is copied
-//                          global -> LDS by the waves' own LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPR staging,
-//                          no ds_write), double buffered: chunk p+1 lands while chunk p is consumed, one barrier
-//                          per phase.  Consumer: LANE = WINDOW PIXEL (64 lanes = the 8x8 integer window of one
-//                          particle-level); the particle's feature chunk comes through the scalar cache into
-//                          SGPRs (wave-uniform), so a phase costs a lane 4 `ds_read_b128` + 8 `v_pk_fma_f32` per
-//                          particle and no cross-lane reduction.  The LDS image is dense (DMA writes 1 KiB linear
-//                          pieces) and XOR-swizzled on the GLOBAL side -- the lane that fetches LDS quad position j
-//                          of pixel (rx,ry) reads channel quad j ^ (ry & 3) -- which makes the lane=pixel
-//                          `ds_read_b128` conflict-free for its true 16-lane service groups.  Particles arrive
-//                          sorted by 4x4-pixel cell, so consecutive slots of a wave often share the same window
-//                          anchor at the coarse levels and re-use the fragment registers instead of re-reading
-//                          LDS.  The 2x2 blend of the 8x8 correlations to the 49 taps uses ds_bpermute.
+//   gather_tiled_kernel    ONE persistent block (16 waves) per CU; block id mod 8 = XCD, whose 32 CUs work through the
+//                          tiles of one frame side by side (halos shared in that XCD's L2).  Per work item 8 phases,
+//                          one per 16-channel chunk: the tile's regions of ALL FOUR levels of the chunk (<= 72 KiB) are
+//                          copied global -> LDS by the waves' own LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR
+//                          staging, no ds_write), double buffered -- chunk c+1 lands while chunk c is consumed, one
+//                          barrier per chunk.  Consumer: LANE = WINDOW PIXEL (64 lanes = the 8x8 integer window of one
+//                          particle-level); the particle's feature chunk comes through the scalar cache into SGPRs
+//                          (wave-uniform), so a chunk costs a lane 4 `ds_read_b128` + 8 `v_pk_fma_f32` per
+//                          particle-level and no cross-lane reduction; the 48 accumulators of a wave (4 levels x
+//                          6 particles x even/odd chain) stay in registers across the phases.  The LDS image is dense
+//                          (DMA writes 1 KiB linear pieces) and XOR-swizzled on the GLOBAL side -- the lane that fetches
+//                          LDS quad position j of pixel (rx,ry) reads channel quad j ^ (ry & 3).  Particles arrive
+//                          sorted by 4x4-pixel cell, so the two slots of a pair often share the window anchor at the
+//                          coarse levels and one fragment serves both.  The 2x2 blend of the 8x8 correlations to the
+//                          49 taps uses ds_bpermute.  The whole item body is generated assembly (gather_item_asm.inc,
+//                          tools/gen_gather_asm.py): see gather_item below.
 // Output is identical in meaning to mixer_input_kernel (same taps, same transposed order, zeros outside
-// the map); the dot products are summed as an even- and an odd-channel chain (fp32 round-off differs from the
-// direct kernel's tree sum).
+// the map); the dot products are summed as an even- and an odd-channel chain and scaled by 1/sqrt(128) through the
+// blend weights (fp32 round-off differs from the direct kernel's tree sum and division: 6e-5 against the fp64 oracle
+// at 160-pixel-wide maps, where the fp32 oracle itself is 5e-5 off -- tests/test_config45_gpu.py).
 #include "common.h"
 
 #include <cstdlib>
 
 #ifndef PIPS_TILED_ABLATE
-#define PIPS_TILED_ABLATE 0    // tuning builds only: 4 no LDS-DMA, 16 no barriers (8: regenerate the .inc with PIPS_GEN_ABLATE=feats)
+#define PIPS_TILED_ABLATE 0    // tuning builds only: 4 no LDS-DMA, 128 no item body (PIPS_GEN_ABLATE=feats,reads,fma,dma,warm,epi: parts of it)
 #endif
 #ifndef PIPS_TILED_REUSE
 #define PIPS_TILED_REUSE 1     // re-use the fragment registers between consecutive slots with the same window anchor
@@ -52,15 +55,14 @@ constexpr int NW = 16;                    // waves per block
 constexpr int SLOTS = 6;                  // particle slots per wave
 constexpr int GMAX = NW * SLOTS;          // particles per work item
 constexpr int Q = 4;                      // 16-byte channel quads per pixel per chunk (16 channels)
-constexpr int NCH = C / (4 * Q);          // chunks (phases) per level
-constexpr int SLOT_BYTES = 34 * 1024;     // one stage: >= 23*23 px * 64 B (level 0), whole 1 KiB DMA pieces
-constexpr int MAXPIECES = 3;              // DMA pieces per wave per phase: ceil(34 / 16)
-constexpr int LDS_MISC = 4096;            // scratch (L2 warm-up landing zone, 256 B per wave)
-constexpr int LDS_BYTES = 2 * SLOT_BYTES + LDS_MISC;
+constexpr int LDS_MISC = 8192;            // scratch behind the stages (item entries, record prefetch, landing zone of the L2 touches)
 
+#ifndef PIPS_TRACE_WAVE
+#define PIPS_TRACE_WAVE 0
+#endif
 #ifdef PIPS_TILED_TRACE      // tuning builds: per-block timestamps (wave 0) at the stage boundaries of gather_tiled_kernel
 __device__ unsigned long long* g_tiled_trace;
-#define PIPS_TR(i) do { if (threadIdx.x == 0 && g_tiled_trace) g_tiled_trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PIPS_TR(i) do { if (threadIdx.x == 0 && g_tiled_trace) g_tiled_trace[((size_t)blockIdx.x * 64 + (t & 63)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PIPS_TR(i) do { } while (0)
 #endif
@@ -86,25 +88,16 @@ __device__ __forceinline__ void corr_window(float cxm, float cym, int lvl, int H
     by = (int)fminf(fmaxf(fy0, -1.0e6f), 1.0e6f) - PIPS_RADIUS;
 }
 
-// staged region of tile coordinate t at level lvl along one axis (inclusive, clipped to [0, n-1]).
-// Level 0: the anchor floor(ix) of a binned particle lies in [16t, 16t+15] exactly, its window reaches
-// -3..+4.  Coarser levels: floor(ix_l) lies in [T-1, T+(16>>l)] with T = (16t)>>l (one pixel of slack
-// each side for the independently rounded coordinate), same reach.
-__device__ __forceinline__ void region_axis(int t, int lvl, int n, int& lo, int& hi) {
-    const int T = (t * TS) >> lvl, w = TS >> lvl;
-    lo = max(lvl == 0 ? T - 3 : T - 4, 0);
-    hi = min(lvl == 0 ? T + w + 3 : T + w + 4, n - 1);
-}
-
 // ---------------------------------------------------------------------------- binning
-// order  [F][N]        particle indices n of frame f sorted by (tile, 4x4-pixel cell inside the tile in Morton order):
-//                      neighbours in the list mostly share their window anchor at the coarse levels
+// order  [F][N]        int4 {mixer row m, bits of cx, bits of cy, 0} of frame f's particles sorted by (tile, 4x4-pixel cell
+//                      inside the tile in Morton order): neighbours in the list mostly share their window anchor at the
+//                      coarse levels; a record saves the gather a dependent load (index -> coordinates)
 // items  [F][max_items] int4 {tile, first, count, 0}; a tile with more than GMAX particles is split evenly
 // nitems [F]
 // LDS: hist[nbins] | cursor[nbins] | tile_off[ntiles + 1],  nbins = 16 * ntiles
 __global__ __launch_bounds__(1024) void bin_particles_kernel(const float* __restrict__ coords, int N, int H0, int W0,
                                                              int tiles_x, int tiles_y, int max_items,
-                                                             int* __restrict__ order, int4* __restrict__ items,
+                                                             int4* __restrict__ order, int4* __restrict__ items,
                                                              int* __restrict__ nitems) {
     extern __shared__ int sm[];
     const int ntiles = tiles_x * tiles_y, nbins = ntiles * 16;
@@ -157,24 +150,9 @@ __global__ __launch_bounds__(1024) void bin_particles_kernel(const float* __rest
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const int pos = atomicAdd(&cursor[key_of(n)], 1);
-        order[(size_t)f * N + pos] = n;
+        const size_t m = ((size_t)b * N + n) * S + s;
+        order[(size_t)f * N + pos] = make_int4((int)m, __float_as_int(coords[m * 2 + 0]), __float_as_int(coords[m * 2 + 1]), 0);
     }
-}
-
-// blend of one particle-level: lane holds the correlation of window pixel (row lane>>3, col lane&7);
-// returns the tap k = ix*7 + iy of lanes < 49
-__device__ __forceinline__ float blend_taps(float dval, float wx, float wy, int lane) {
-    const int t = lane < 49 ? lane : 0;
-    const int ti = t / 7, tj = t - ti * 7;
-    const int src = tj * 8 + ti;                                // lane holding D[row tj][col ti]
-    const float nw = __shfl(dval, src), ne = __shfl(dval, src + 1);
-    const float sw = __shfl(dval, src + 8), se = __shfl(dval, src + 9);
-    const float e = 1.0f - wx, so = 1.0f - wy;
-    float o = nw * (so * e);
-    o += ne * (so * wx);
-    o += sw * (wy * e);
-    o += se * (wy * wx);
-    return o;
 }
 
 // ---------------------------------------------------------------------------- embedding rows
@@ -207,24 +185,16 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
 // ---------------------------------------------------------------------------- tiled gather
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-struct LevelGeom {          // wave-uniform description of the staged region of one level
+// Level geometry of a work item, LANE-PARALLEL: lane l (l < 4) of every wave holds level l's staged region; the
+// wave-uniform values are pulled out with v_readlane where they are needed (keeps them out of the SGPR file, which
+// the phase body fills with feature chunks, and keeps the set-up free of scalar branches)
+struct LaneGeom {
     int x0, y0, RW, RH, W, H;
     int nquads;             // RW*RH*Q 16-byte LDS positions
-    size_t base;            // float offset of the (frame, level) map in the pyramid buffer
+    unsigned base;          // byte offset of the (frame, level) map in the pyramid buffer
+    int lbase, lsize;       // LDS byte offset of the level's stage pair, size of one stage
 };
-
-__device__ __forceinline__ LevelGeom level_geom(const TiledLevels& lv, int l, int tx, int ty, size_t frame_base) {
-    LevelGeom g;
-    int x1, y1;
-    g.W = lv.W[l]; g.H = lv.H[l];
-    region_axis(tx, l, g.W, g.x0, x1);
-    region_axis(ty, l, g.H, g.y0, y1);
-    g.RW = max(x1 - g.x0 + 1, 1); g.RH = max(y1 - g.y0 + 1, 1);
-    if (x1 < g.x0 || y1 < g.y0) { g.x0 = g.y0 = 0; g.RW = g.RH = 1; }            // (tile beyond this level's map)
-    g.nquads = g.RW * g.RH * Q;
-    g.base = lv.off[l] + frame_base * g.H * g.W * C;
-    return g;
-}
+#define PIPS_RL(v, i) __builtin_amdgcn_readlane((int)(v), (i))
 
 // XOR key of region pixel (rx, ry): LDS 16-byte slot = 4 * (pixel index & 3) + (quad ^ key) is a bijection of
 // (rx & 3, ry & 3) -> the 16 lanes of a ds_read_b128 service group (4 consecutive x in each of 4 consecutive
@@ -237,272 +207,256 @@ __device__ __forceinline__ int swz_key(int rx, int ry) {
     return ry & 3;
 }
 
-// per-lane global byte offsets (within the (frame, level) map) of the DMA pieces this wave issues
-__device__ __forceinline__ void dma_setup(const LevelGeom& g, int wave, int lane, unsigned (&doff)[MAXPIECES]) {
-    const float inv_rw = 1.0f / (float)g.RW;
-#pragma unroll
-    for (int r = 0; r < MAXPIECES; ++r) {
-        const int L = min((wave + r * NW) * 64 + lane, g.nquads - 1);
-        const int p = L / Q, j = L - p * Q;
-        const int ry = (int)(((float)p + 0.5f) * inv_rw);         // p < 1024: exact
-        const int rx = p - ry * g.RW;
-        const int q = j ^ swz_key(rx, ry);
-        doff[r] = (unsigned)(((g.y0 + ry) * g.W + (g.x0 + rx)) * (C * 4) + q * 16);
-    }
-}
-
-// buffer resource over [ptr, ptr + 2 GiB): raw (stride 0) addressing, offsets = soffset (SGPR) + voffset (VGPR);
+// buffer resource over the pyramid: raw (stride 0) addressing, byte offset = soffset (SGPR) + voffset (VGPR) < 4 GiB;
 // keeps every address of the hot loop out of the vector registers
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffff, 0x00020000);
 }
 
-__device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t src, int soff, const unsigned (&doff)[MAXPIECES],
-                                          int npieces, int wave, char* lds_slot) {
+// ---- LDS layout: per level two stages (chunk parity) side by side, so that the parity is a 16-bit immediate
+// offset of the ds_reads:  [L0 s0 | L0 s1 | L1 s0 | L1 s1 | L2 .. | L3 .. | scratch]
+// stage sizes in 1 KiB DMA pieces: 34, 19, 11, 8 >= (23^2, 17^2, 13^2, 11^2 px) * 64 B
+constexpr int SZ0 = 34 * 1024, SZ1 = 19 * 1024, SZ2 = 11 * 1024, SZ3 = 8 * 1024;
+constexpr int LB0 = 0, LB1 = 2 * SZ0, LB2 = LB1 + 2 * SZ1, LB3 = LB2 + 2 * SZ2;
+constexpr int LDS_MISC_OFF = LB3 + 2 * SZ3;                    // 144 KiB
+constexpr int LDS_BYTES_V3 = LDS_MISC_OFF + LDS_MISC;
+constexpr int MAXP = 5;                                         // DMA pieces per wave per phase: ceil(72 / 16)
+// ---- one work item of one wave in assembly ------------------------------------------------------------------
+// gather_item(): everything between the item's index arithmetic and its stores is ONE asm statement, unrolled by
+// tools/gen_gather_asm.py into gather_item_asm.inc:
+//   set-up     LDS byte address of this lane's window pixel for the 24 units (level, slot) -- LANE = WINDOW PIXEL, 64
+//              lanes = the 8x8 integer window of one particle-level -- with the swizzle key folded in, in-map bits,
+//              zeroed accumulators;
+//   8 phases   one per 16-channel chunk: `s_waitcnt vmcnt(0)` + ONE barrier, then the wave's (up to five) DMA pieces of
+//              the next chunk's stage (all four levels) are issued between its first FMA groups -- issued back to
+//              back by 16 waves they fill the texture-address queue (64 B/clk: ~1150 clk per 72 KiB stage) and every
+//              wave sits in the issue stall.  Work goes by PAIRS of slots: per level 8 ds_read_b128 (the second slot's
+//              four are skipped when it has the first one's window anchor -- one fragment serves both), one
+//              `s_waitcnt lgkmcnt(0)`, 16 v_pk_fma_f32 with the two particles' feature chunks as SGPR-pair operands
+//              (wave-uniform, through the scalar cache: no vector-memory cycles, no VGPRs).  A pair's features are
+//              requested while the previous pair works (two SGPR sets of 2 x 16), across phase boundaries too, so a
+//              scalar load has ~4 FMA groups to land; the L2 lines behind them are kept warm by one-dword DMA touches
+//              two chunks ahead (the map traffic of an XCD's 32 CUs would evict them).
+//              Why packed FMAs: a v_fmac_f32 with an SGPR or DPP-broadcast source issues at HALF rate on gfx950,
+//              v_pk_fma_f32 with an SGPR pair keeps the full rate (tools/dpp_rate.hip, tools/valu_peak.hip);
+//   blend      per slot: 16 ds_bpermute (the 2x2 neighbours of the 49 taps at the four levels) under one wait,
+//              weights from lane-parallel registers by v_readlane, 4 stores of 49 lanes.
+// Why one statement: the 48 accumulators + 24 addresses of a wave live across the eight barriers.  As C++ around
+// per-phase asm statements hipcc spilled ~60 VGPRs around the set-up and the blend (each reload a scratch round
+// trip of ~1 us) and those two parts cost as much as the phases; here nothing crosses a statement boundary.
+#ifndef PIPS_ITEM_INC
+#define PIPS_ITEM_INC "gather_item_asm.inc"      // tuning builds point this at an ablated copy
+#endif
+#include PIPS_ITEM_INC
+
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+// the DMA pieces of one wave: piece id g = wave + 16 r over the concatenation of the four levels' pieces
+struct WavePieces {
+    unsigned doff[MAXP];        // per lane: byte offset (from the pyramid start) of the 16 bytes this lane fetches
+    int lds[MAXP];              // wave-uniform: LDS byte offset of the piece (stage parity 0); -1 = no piece
+    int par[MAXP];              // wave-uniform: stage size of the piece's level (the parity stride)
+};
+
+__device__ __forceinline__ LaneGeom lane_geom(const TiledLevels& lv, int lane, int tx, int ty, size_t frame_base) {
+    LaneGeom g;
+    const int l = lane & 3;
+    // (the table entries go through opaque registers: hipcc otherwise turns the selects below into a dynamically
+    //  indexed load and copies the kernel argument to scratch memory for it)
+    int W0 = lv.W[0], W1 = lv.W[1], W2 = lv.W[2], W3 = lv.W[3], H0 = lv.H[0], H1 = lv.H[1], H2 = lv.H[2], H3 = lv.H[3];
+    size_t o0 = lv.off[0], o1 = lv.off[1], o2 = lv.off[2], o3 = lv.off[3];
+    asm volatile("" : "+s"(W0), "+s"(W1), "+s"(W2), "+s"(W3), "+s"(H0), "+s"(H1), "+s"(H2), "+s"(H3));
+    asm volatile("" : "+s"(o0), "+s"(o1), "+s"(o2), "+s"(o3));
+    g.W = l == 0 ? W0 : (l == 1 ? W1 : (l == 2 ? W2 : W3));
+    g.H = l == 0 ? H0 : (l == 1 ? H1 : (l == 2 ? H2 : H3));
+    const size_t off = l == 0 ? o0 : (l == 1 ? o1 : (l == 2 ? o2 : o3));
+    // Staged region along one axis (inclusive, clipped to the map).  Level 0: the anchor floor(ix) of a binned particle
+    // lies in [16t, 16t+15] exactly, its window reaches -3..+4.  Coarser levels: floor(ix_l) lies in [T-1, T+(16>>l)] with
+    // T = (16t)>>l (one pixel of slack each side for the independently rounded coordinate), same reach.
+    const int Tx = (tx * TS) >> l, Ty = (ty * TS) >> l, w = TS >> l, h = l == 0 ? 3 : 4;
+    g.x0 = max(Tx - h, 0); g.y0 = max(Ty - h, 0);
+    const int x1 = min(Tx + w + h, g.W - 1), y1 = min(Ty + w + h, g.H - 1);
+    g.RW = max(x1 - g.x0 + 1, 1); g.RH = max(y1 - g.y0 + 1, 1);
+    if (x1 < g.x0 || y1 < g.y0) { g.x0 = g.y0 = 0; g.RW = g.RH = 1; }            // (tile beyond this level's map)
+    g.nquads = g.RW * g.RH * Q;
+    g.base = (unsigned)((off + frame_base * g.H * g.W * C) * sizeof(float));
+    g.lbase = l == 0 ? LB0 : (l == 1 ? LB1 : (l == 2 ? LB2 : LB3));
+    g.lsize = l == 0 ? SZ0 : (l == 1 ? SZ1 : (l == 2 ? SZ2 : SZ3));
+    return g;
+}
+
+__device__ __forceinline__ void dma_setup(const LaneGeom& g, int wave, int lane, WavePieces& wp) {
+    const int np = (g.nquads + 63) >> 6;
+    const int c1 = PIPS_RL(np, 0), c2 = c1 + PIPS_RL(np, 1), c3 = c2 + PIPS_RL(np, 2), c4 = c3 + PIPS_RL(np, 3);
 #pragma unroll
-    for (int r = 0; r < MAXPIECES; ++r) {
-        const int piece = wave + r * NW;
-        if (!(PIPS_TILED_ABLATE & 4) && piece < npieces)                         // wave-uniform
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lptr_t)(lds_slot + piece * 1024), 16, (int)doff[r], soff, 0, 0);
+    for (int r = 0; r < MAXP; ++r) {
+        const int gp = wave + r * NW;
+        const int l = (gp >= c1) + (gp >= c2) + (gp >= c3);                      // wave-uniform
+        const int piece = gp - (l > 0 ? c1 : 0) - (l > 1 ? c2 - c1 : 0) - (l > 2 ? c3 - c2 : 0);
+        const int RW = PIPS_RL(g.RW, l), W = PIPS_RL(g.W, l), x0 = PIPS_RL(g.x0, l), y0 = PIPS_RL(g.y0, l);
+        const int L = min(piece * 64 + lane, PIPS_RL(g.nquads, l) - 1);
+        const int p = L / Q, j = L - p * Q;
+        const int ry = (int)(((float)p + 0.5f) * (1.0f / (float)RW));         // p < 1024: exact
+        const int rx = p - ry * RW;
+        const int q = j ^ swz_key(rx, ry);
+        wp.doff[r] = (unsigned)PIPS_RL(g.base, l) + (unsigned)(((y0 + ry) * W + (x0 + rx)) * (C * 4) + q * 16);
+        wp.lds[r] = gp < c4 ? PIPS_RL(g.lbase, l) + piece * 1024 : -1;
+        wp.par[r] = PIPS_RL(g.lsize, l);
     }
 }
 
-// ---- the phase body in assembly --------------------------------------------------------------------------
-// hipcc cannot be made to schedule this loop (it hoists every slot's loads to the top of the phase and spills
-// hundreds of registers), so one (level, chunk) phase of one wave is ONE asm statement, unrolled by
-// tools/gen_gather_asm.py into gather_phase_asm.inc.  Slots go in pairs.  Per pair:
-//     v_readlane row -> s_load_dwordx16 per slot: the particle's 16-channel feature chunk, wave-uniform, through
-//                       the scalar cache into s[36:67] -- no vector-memory (TA) cycles, no VGPRs.  The pair's loads
-//                       are issued back to back, so their latency (an L2 hit: the rows are touched once at the
-//                       start of the item) is paid once per pair and covered by the other 7 waves of the SIMD;
-// then per slot:
-//     4 x ds_read_b128 (3 v_xor): this lane's window pixel, skipped when the slot has the same window anchor as
-//                       the previous one (the fragments are still in v[48:63]);
-//     s_waitcnt lgkmcnt(0); 8 x v_pk_fma_f32 acc.xy += s[c:c+1] * v[c:c+1] (even / odd channel partial sums).
-// Why packed: a v_fmac_f32 with an SGPR or DPP-broadcast source issues at HALF rate on gfx950 (56 / 54 vs 115
-// lane-FMA/clk/CU), v_readlane + v_fmac at a quarter; v_pk_fma_f32 with an SGPR pair keeps the full FMA rate
-// (105; tools/dpp_rate.hip, tools/valu_peak.hip).
-// Registers private to the statement (declared as clobbers): s[36:67] features, s[68:71] address temporaries,
-// v[48:63] fragments, v[45:47] swizzled addresses -- the kernel stays within 64 VGPRs / 80 SGPRs = 8 waves per SIMD
-// (MI355X admits 8 waves per SIMD only up to .sgpr_count 80).
-// No VALU-written SGPR feeds SMEM directly (the readlane result goes through s_lshl/s_add), so no manual wait
-// states are needed.
-#include "gather_phase_asm.inc"
-#define PIPS_A_OPS(K) [acc##K] "+v"(acc[K])
-#define PIPS_A_INS(K) [A##K] "v"(A[K])
-#define PIPS_A_COMMON [rows] "v"(geo_row), [fb_lo] "s"((unsigned)(fb & 0xffffffffull)), [fb_hi] "s"((unsigned)(fb >> 32)), \
-                      [same] "s"(same), [skip] "s"(skip), [soff] "i"(SLOT_OFF)
-#define PIPS_A_CLOBBER                                                                               \
-    "memory", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",     \
-    "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",        \
-    "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v45", "v46", "v47", "v48", "v49", "v50", "v51",        \
-    "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
-
-template <int NS, int SLOT_OFF>
-struct ConsumeAsm;
-#define PIPS_DEFINE_CONSUME(NS_, OUTS, INS)                                                                        \
-    template <int SLOT_OFF>                                                                                        \
-    struct ConsumeAsm<NS_, SLOT_OFF> {                                                                              \
-        static __device__ __forceinline__ void run(const unsigned (&A)[NS_], f2 (&acc)[NS_], unsigned same,         \
-                                                   unsigned skip, unsigned long long fb, int geo_row) {             \
-            asm volatile(PIPS_PHASE_TEXT_##NS_ : OUTS : INS, PIPS_A_COMMON : PIPS_A_CLOBBER);                       \
-        }                                                                                                          \
-    };
-#define PIPS_CM ,
-#define PIPS_O_2 PIPS_A_OPS(0) PIPS_CM PIPS_A_OPS(1)
-#define PIPS_I_2 PIPS_A_INS(0) PIPS_CM PIPS_A_INS(1)
-#define PIPS_O_4 PIPS_O_2 PIPS_CM PIPS_A_OPS(2) PIPS_CM PIPS_A_OPS(3)
-#define PIPS_I_4 PIPS_I_2 PIPS_CM PIPS_A_INS(2) PIPS_CM PIPS_A_INS(3)
-PIPS_DEFINE_CONSUME(2, PIPS_O_2, PIPS_I_2)
-PIPS_DEFINE_CONSUME(4, PIPS_O_4, PIPS_I_4)
-PIPS_DEFINE_CONSUME(5, PIPS_O_4 PIPS_CM PIPS_A_OPS(4), PIPS_I_4 PIPS_CM PIPS_A_INS(4))
-PIPS_DEFINE_CONSUME(6, PIPS_O_4 PIPS_CM PIPS_A_OPS(4) PIPS_CM PIPS_A_OPS(5), PIPS_I_4 PIPS_CM PIPS_A_INS(4) PIPS_CM PIPS_A_INS(5))
-
-template <int NS, int SLOT_OFF>
-__device__ __forceinline__ void consume(const unsigned (&A)[NS], f2 (&acc)[NS], unsigned same, unsigned skip,
-                                        const float* __restrict__ ffeats, int geo_row, int choff) {
-    ConsumeAsm<NS, SLOT_OFF>::run(A, acc, PIPS_TILED_REUSE ? (unsigned)__builtin_amdgcn_readfirstlane(same) : 0u,
-                                  (unsigned)__builtin_amdgcn_readfirstlane(skip),
-                                  (unsigned long long)reinterpret_cast<uintptr_t>(ffeats + choff), geo_row);
-}
-
-// per-level lane state: LDS byte address of this lane's window pixel (with the swizzle key folded in),
-// in-map mask, zeroed accumulators
-template <int NS>
-__device__ __forceinline__ void level_setup(const LevelGeom& g, int lvl, int lane, float geo_bx, float geo_by,
-                                            unsigned lds_base, unsigned (&A)[NS], f2 (&acc)[NS], unsigned& inmask) {
-    const int wi = lane & 7, wj = lane >> 3;
-    inmask = 0;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        acc[k] = (f2){0.f, 0.f};
-        const int bx = __builtin_amdgcn_readlane(__float_as_int(geo_bx), k * 4 + lvl);
-        const int by = __builtin_amdgcn_readlane(__float_as_int(geo_by), k * 4 + lvl);
-        const int px = bx + wi, py = by + wj;
-        const bool inmap = (unsigned)px < (unsigned)g.W && (unsigned)py < (unsigned)g.H;
-        const int rx = min(max(px - g.x0, 0), g.RW - 1), ry = min(max(py - g.y0, 0), g.RH - 1);
-        A[k] = lds_base + (unsigned)((ry * g.RW + rx) * (Q * 16) + (swz_key(rx, ry) << 4));
-        inmask |= inmap ? (1u << k) : 0u;
-    }
-    asm volatile("" : "+v"(inmask));       // keep it a bit mask: re-derived from px/py it costs 2 spilled VGPRs per slot
-}
-
-// One level = NCH phases.  Entering it, phase 0's region is already in flight (slot 0); phase c issues phase
-// c+1's (the next level's first after the last chunk) right behind the barrier that frees the other slot, then
-// consumes its own.  One barrier per phase; `s_waitcnt vmcnt(0)` in front of it covers exactly the previous
-// phase's prefetch.
-template <int NS>
-__device__ __forceinline__ void run_level(__amdgpu_buffer_rsrc_t map, __amdgpu_buffer_rsrc_t map_next, bool has_next,
-                                          const LevelGeom& g, const LevelGeom& gn, char* smem, int wave, int lane,
-                                          unsigned same, unsigned skip, const float* __restrict__ ffeats, int geo_row,
-                                          unsigned (&doff)[MAXPIECES], const unsigned (&A)[NS], f2 (&acc)[NS]) {
-    static_assert(NCH % 2 == 0, "phases come in pairs (static slot parity)");
-    constexpr int CH = Q * 4;
-    for (int c = 0; c < NCH; c += 2) {
-        // ---- even phase: data in slot 0; prefetch phase c+1 into slot 1
-        __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0)
-        if (!(PIPS_TILED_ABLATE & 16)) __syncthreads();
-        dma_issue(map, (c + 1) * CH * 4, doff, (g.nquads + 63) >> 6, wave, smem + SLOT_BYTES);
-        consume<NS, 0>(A, acc, same, skip, ffeats, geo_row, c * CH);
-        // ---- odd phase: data in slot 1; prefetch phase c+2 (or the next level's first) into slot 0
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        if (!(PIPS_TILED_ABLATE & 16)) __syncthreads();
-        if (c + 2 < NCH) {
-            dma_issue(map, (c + 2) * CH * 4, doff, (g.nquads + 63) >> 6, wave, smem);
-        } else if (has_next) {
-            dma_setup(gn, wave, lane, doff);
-            dma_issue(map_next, 0, doff, (gn.nquads + 63) >> 6, wave, smem);
-        }
-        consume<NS, SLOT_BYTES>(A, acc, same, skip, ffeats, geo_row, (c + 1) * CH);
-    }
-}
-
-// the staged part of one work item for waves that hold NS particle slots each (a wave with fewer particles
-// repeats its last one: same values, same destination)
-template <int NS>
-__device__ __forceinline__ void tile_body(const float* __restrict__ pyramid, const TiledLevels& lv, size_t frame_base,
-                                          int tx, int ty, char* smem, int wave, int lane, __amdgpu_buffer_rsrc_t map,
-                                          LevelGeom g, unsigned (&doff)[MAXPIECES], const float* __restrict__ ffeats,
-                                          float geo_bx, float geo_by, float geo_wx, float geo_wy, int geo_row,
-                                          unsigned long long samebits, unsigned skip, float* __restrict__ X) {
-    const float scale = sqrtf((float)C);
-    // LDS byte address of the stage buffers
-    const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
-    unsigned A[NS];
-    f2 acc[NS];
-    unsigned inmask;
-    for (int lvl = 0; lvl < PIPS_LEVELS; ++lvl) {
-        const LevelGeom gn = level_geom(lv, min(lvl + 1, PIPS_LEVELS - 1), tx, ty, frame_base);
-        const __amdgpu_buffer_rsrc_t mapn = make_rsrc(pyramid + gn.base);
-        level_setup<NS>(g, lvl, lane, geo_bx, geo_by, lds_base, A, acc, inmask);
-        unsigned same = 0;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) same |= (unsigned)((samebits >> (k * 4 + lvl)) & 1ull) << k;
-        same = __builtin_amdgcn_readfirstlane(same);
-        PIPS_TR(3 + 3 * lvl);
-        run_level<NS>(map, mapn, lvl + 1 < PIPS_LEVELS, g, gn, smem, wave, lane, same, skip, ffeats, geo_row, doff, A, acc);
-        PIPS_TR(4 + 3 * lvl);
-        // blend the 8x8 correlations to the 49 taps, k = level*49 + ix*7 + iy (transposed, :379-381)
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo_wx), k * 4 + lvl));
-            const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(geo_wy), k * 4 + lvl));
-            const int row = __builtin_amdgcn_readlane(geo_row, k * 4);
-            const float o = blend_taps(((inmask >> k) & 1u) ? (acc[k].x + acc[k].y) / scale : 0.f, wx, wy, lane);   // :397
-            // (a wave that skipped its last slot must not store it: the slot aliases the wave's last real particle)
-            if (lane < 49 && !(k == NS - 1 && skip)) X[(size_t)row * PIPS_KIN_PAD + C + lvl * 49 + lane] = o;
-        }
-        PIPS_TR(5 + 3 * lvl);
-        g = gn; map = mapn;
-    }
-}
-
-__global__ __launch_bounds__(NW * 64, 8) void gather_tiled_kernel(const float* __restrict__ pyramid, TiledLevels lv,
-                                                                  int S_, const float* __restrict__ ffeats,
-                                                                  const float* __restrict__ coords, int N,
+// One persistent block (16 waves) per CU; block id mod 8 is the XCD (observed dispatch order), so the 32 CUs of
+// XCD x work through the tiles of frames x, x+8, ... side by side and a frame's halos are shared in that XCD's L2.
+// Per work item (tile, <= 96 particles): the regions of ALL FOUR levels of a 16-channel chunk are copied
+// global -> LDS by the waves' own LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR staging, no ds_write), double
+// buffered: chunk c+1 lands while chunk c is consumed, one barrier per chunk.  C++ does the item's index arithmetic
+// (lane-parallel) and starts the first stage; gather_item_asm.inc does the rest.
+__global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* __restrict__ pyramid, TiledLevels lv,
+                                                                  int S_, const float* __restrict__ ffeats, int N,
                                                                   int tiles_x, int max_items, int F,
-                                                                  const int* __restrict__ order,
+                                                                  const int4* __restrict__ order,
                                                                   const int4* __restrict__ items,
                                                                   const int* __restrict__ nitems,
                                                                   float* __restrict__ X) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    // block -> (frame, item): block id mod 8 is the XCD (observed dispatch order), so XCD x works through
-    // frames x, x+8, ... one after another and a frame's tiles share that XCD's L2 for their halos
-    int f, item;
-    {
-        const int i = blockIdx.x, xcd = i & 7, j = i >> 3;
-        f = xcd + 8 * (j / max_items);
-        item = j - (j / max_items) * max_items;
-        if (f >= F) return;                                       // (F is a multiple of 8; defensive)
-    }
-    if (item >= nitems[f]) return;
-    PIPS_TR(0);
-    const int4 it = items[(size_t)f * max_items + item];
-    const int tile = it.x, first = it.y, count = it.z;
-#ifdef PIPS_TILED_TRACE
-    if (threadIdx.x == 0 && g_tiled_trace) g_tiled_trace[(size_t)blockIdx.x * 16 + 15] = (unsigned long long)count;
-#endif
-    const int b = f / S, s = f - b * S;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t frame_base = (size_t)(b * S_ + s);
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-
-    // ---- start the first stage right away: level 0, chunk 0 -> slot 0
-    unsigned doff[MAXPIECES];
-    const LevelGeom g = level_geom(lv, 0, tx, ty, frame_base);
-    dma_setup(g, wave, lane, doff);
-    const __amdgpu_buffer_rsrc_t map = make_rsrc(pyramid + g.base);
-    dma_issue(map, 0, doff, (g.nquads + 63) >> 6, wave, smem);
-
-    // ---- warm the L2 with the item's particle features (one dword per 128-byte line, dropped into the LDS
-    //      scratch area by the DMA engine: no VGPR, tracked by vmcnt like the stage loads)
-    if (tid < count * 4) {                                              // 4 lines per 512-byte feature row
-        const int n = order[(size_t)f * N + first + (tid >> 2)];
-        const unsigned off = (unsigned)((((size_t)b * N + n) * S + s) * (C * 4) + (tid & 3) * 128);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(ffeats), (lptr_t)(smem + 2 * SLOT_BYTES + wave * 256), 4, (int)off, 0,
-                                                 0, 0);
-    }
-    // ---- the list is already ordered (bin_particles_kernel); spread it over the waves
-    const int base_n = count / NW, rem = count - base_n * NW;
-    const int nslot = base_n + (wave < rem ? 1 : 0);              // particles of this wave (may be 0)
-    const int start = wave * base_n + min(wave, rem);
-    const int ns = base_n + (rem ? 1 : 0);                        // slots every wave of the block runs
-    PIPS_TR(1);
-
-    // ---- lane-parallel window geometry: lane k*4+l <-> (slot k, level l); slots past the wave's own
-    //      particles repeat its last one (or the item's first, for an empty wave)
-    float geo_bx, geo_by, geo_wx, geo_wy;                              // ints travel as bit patterns
-    int geo_row;
+    const int xcd = blockIdx.x & 7, J = gridDim.x >> 3;
+    const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+    u4v rs;                                                        // the same descriptor as `map`, as plain SGPR values
     {
-        const int k = min(lane >> 2, SLOTS - 1), l = lane & 3;
-        const int idx = nslot > 0 ? start + min(k, nslot - 1) : 0;
-        geo_row = (b * N + order[(size_t)f * N + first + idx]) * S + s;     // mixer row m
-        const float cx = coords[(size_t)geo_row * 2 + 0], cy = coords[(size_t)geo_row * 2 + 1];
-        int bx, by;
-        corr_window(cx, cy, l, lv.H[l], lv.W[l], bx, by, geo_wx, geo_wy);
-        geo_bx = __int_as_float(bx); geo_by = __int_as_float(by);
+        const unsigned long long pa = (unsigned long long)reinterpret_cast<uintptr_t>(pyramid);
+        rs = (u4v){(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
     }
-    // slot k re-uses slot k-1's fragments at level l when both windows have the same anchor
-    unsigned long long samebits;
-    {
-        const int pbx = __shfl_up(__float_as_int(geo_bx), 4), pby = __shfl_up(__float_as_int(geo_by), 4);
-        samebits = __ballot(lane >= 4 && pbx == __float_as_int(geo_bx) && pby == __float_as_int(geo_by));
-    }
-    PIPS_TR(2);
-#define PIPS_TILE_CASE(NS_)                                                                                          \
-    tile_body<NS_>(pyramid, lv, frame_base, tx, ty, smem, wave, lane, map, g, doff, ffeats, geo_bx, geo_by, geo_wx,  \
-                   geo_wy, geo_row, samebits, (unsigned)__builtin_amdgcn_readfirstlane(nslot < NS_ ? 1 : 0), X)
-#ifdef PIPS_TILE_ONLY
-    (void)ns;
-    PIPS_TILE_CASE(PIPS_TILE_ONLY);
-#else
-    if (ns <= 2) PIPS_TILE_CASE(2);
-    else if (ns <= 4) PIPS_TILE_CASE(4);
-    else if (ns == 5) PIPS_TILE_CASE(5);
-    else PIPS_TILE_CASE(6);
+    const __amdgpu_buffer_rsrc_t recs = make_rsrc(order), frs = make_rsrc(ffeats);
+    // scratch behind the stages:  [junk 256 B | entries 64 x 16 B | per wave: records 2 x 8 x 16 B | waves 0-1: rows 2 x 64 x 4 B]
+    char* misc = smem + LDS_MISC_OFF;
+    int4* ent = reinterpret_cast<int4*>(misc + 256);
+    int4* recbuf = reinterpret_cast<int4*>(misc + 256 + 1024) + wave * 16;
+    unsigned* rowbuf = reinterpret_cast<unsigned*>(misc + 256 + 1024 + 4096) + min(wave, 1) * 128;
+    // Records of item (first, count) this wave needs, by LDS-DMA into buffer p (no VGPRs: the copy is in flight across
+    // the asm statement of the item before): the wave's six slots (16 B each, lanes 0-5) and, in waves 0-1, the mixer
+    // row of particle tid (4 B) for the L2 touches of the features
+    auto prefetch_records = [&](int f_, int first, int count, int p) {
+        const int base_n = count / NW, rem = count - base_n * NW;
+        const int nslot = base_n + (wave < rem ? 1 : 0), start = wave * base_n + min(wave, rem);
+        const unsigned o0 = (unsigned)(((size_t)f_ * N + first) * sizeof(int4));
+        if (lane < SLOTS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(recs, (lptr_t)(recbuf + p * 8), 16,
+                                                     (int)(o0 + (unsigned)(nslot > 0 ? start + min(lane, nslot - 1) : 0) * 16u), 0, 0, 0);
+        if (tid < count)                                                         // (count <= 96: waves 0 and 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(recs, (lptr_t)(rowbuf + p * 64), 4, (int)(o0 + (unsigned)tid * 16u), 0, 0, 0);
+    };
+    for (int base = 0;; base += 64) {
+        // ---- this block's next (up to) 64 work items: item i of the block is entry j + i J of the XCD's list (frames
+        //      xcd, xcd + 8, ... one after another); lane-parallel look-up, entries {tile, first, count, frame} in LDS
+        __syncthreads();
+        if (wave == 0) {
+            int gi = (blockIdx.x >> 3) + (base + lane) * J, fr = xcd;
+            int4 e = make_int4(0, 0, 0, -1);
+            for (; fr < F; fr += 8) {
+                const int n = nitems[fr];
+                if (gi < n) break;
+                gi -= n;
+            }
+            if (fr < F) { e = items[(size_t)fr * max_items + gi]; e.w = fr; }
+            ent[lane] = e;
+        }
+        __syncthreads();
+        // (entries travel as scalars: an int4 held in vector registers across the asm statement costs spills)
+#define PIPS_ENT(e_, i_) const int4 ev_##e_ = ent[i_]; const int e_##_tile = __builtin_amdgcn_readfirstlane(ev_##e_.x), \
+        e_##_first = __builtin_amdgcn_readfirstlane(ev_##e_.y), e_##_count = __builtin_amdgcn_readfirstlane(ev_##e_.z), \
+        e_##_f = __builtin_amdgcn_readfirstlane(ev_##e_.w)
+        PIPS_ENT(c0, 0);
+        if (c0_f < 0) break;
+        int tile = c0_tile, count = c0_count, f = c0_f;
+        prefetch_records(c0_f, c0_first, c0_count, 0);
+        __builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
+        bool more = true;
+        for (int i = 0; i < 64; ++i) {
+            if (f < 0) { more = false; break; }
+#ifdef PIPS_TILED_TRACE
+            const int t = base + i;
 #endif
-#undef PIPS_TILE_CASE
+            PIPS_TR(0);
+            const int b = f / S, s = f - b * S;
+            const size_t frame_base = (size_t)(b * S_ + s);
+            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            const int p = i & 1;
+            // ---- the next item's records on their way while this one is worked on (first in the DMA queue: the
+            //      stage pieces, issued from the asm, are 72 KiB)
+            PIPS_ENT(nx, min(i + 1, 63));
+            const int nf = i + 1 < 64 ? nx_f : -1;
+            if (nf >= 0) prefetch_records(nf, nx_first, nx_count, p ^ 1);
+            PIPS_TR(13);
+            // ---- staged regions and the wave's DMA pieces (the asm issues them, the first stage between its address
+            //      set-up: no barrier needed -- a wave gets here only after the barrier of the previous item's last
+            //      phase, behind which nobody reads parity 0)
+            const LaneGeom g = lane_geom(lv, lane, tx, ty, frame_base);
+            WavePieces wp;
+            dma_setup(g, wave, lane, wp);
+            PIPS_TR(14);
+
+            // ---- the list is already ordered (bin_particles_kernel); spread it over the waves
+            const int base_n = count / NW, rem = count - base_n * NW;
+            const int nslot = __builtin_amdgcn_readfirstlane(base_n + (wave < rem ? 1 : 0));   // particles of this wave (may be 0)
+            // the item's particle features into the L2 (chunks 0-1 here, the rest two chunks ahead of their use)
+            unsigned warm_off = 0;
+            if (tid < count) {
+                warm_off = rowbuf[p * 64 + lane] * (unsigned)(C * 4);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lptr_t)misc, 4, (int)warm_off, 0, 0, 0);
+            }
+            // ---- lane-parallel window geometry: lane k*4+l <-> (slot k, level l); slots past the wave's own
+            //      particles repeat its last one (or the item's first, for an empty wave)
+            float geo_wx, geo_wy;
+            int geo_bx, geo_by, geo_row;
+            {
+                const int4 r = recbuf[p * 8 + min(lane >> 2, SLOTS - 1)];
+                geo_row = r.x;                                                        // mixer row m
+                corr_window(__int_as_float(r.y), __int_as_float(r.z), lane & 3, g.H, g.W, geo_bx, geo_by, geo_wx, geo_wy);
+            }
+            PIPS_TR(15);
+            // slot k re-uses slot k-1's fragment at level l when both windows have the same anchor: bit 4k+l
+            unsigned same;
+            {
+                const int pbx = __shfl_up(geo_bx, 4), pby = __shfl_up(geo_by, 4);
+                same = (unsigned)__ballot(lane >= 4 && lane < 4 * SLOTS && pbx == geo_bx && pby == geo_by);
+                same = PIPS_TILED_REUSE ? __builtin_amdgcn_readfirstlane(same) : 0u;
+            }
+            // wave-uniform inputs of the asm as ONE lane-parallel register: lanes l / 4+l / 8+l = x0|y0<<16, RW|RH<<16,
+            // W|H<<16 of level l; lane 16+r = LDS offset of the wave's DMA piece r (-1: none), lane 24+r = its stage size
+            int gpk;
+            {
+                const unsigned v0 = (unsigned)g.x0 | ((unsigned)g.y0 << 16), v1 = (unsigned)g.RW | ((unsigned)g.RH << 16),
+                               v2 = (unsigned)g.W | ((unsigned)g.H << 16);                // (g is lane-parallel by lane & 3)
+                gpk = (int)(lane < 4 ? v0 : (lane < 8 ? v1 : v2));
+#pragma unroll
+                for (int r = 0; r < MAXP; ++r) gpk = lane == 16 + r ? ((PIPS_TILED_ABLATE & 4) ? -1 : wp.lds[r]) : (lane == 24 + r ? wp.par[r] : gpk);
+            }
+            PIPS_TR(1);
+#ifdef PIPS_TILED_TRACE
+            int trv = 0;
+#define PIPS_TR_OPERAND [tr] "+v"(trv)
+#else
+#define PIPS_TR_OPERAND
+#endif
+            if (!(PIPS_TILED_ABLATE & 128))
+            asm volatile(PIPS_ITEM_TEXT
+                         : PIPS_TR_OPERAND
+                         : [bx] "v"(geo_bx), [by] "v"(geo_by), [wx] "v"(geo_wx), [wy] "v"(geo_wy), [row] "v"(geo_row),
+                           [gpk] "v"(gpk), [doff0] "v"(wp.doff[0]), [doff1] "v"(wp.doff[1]),
+                           [doff2] "v"(wp.doff[2]), [doff3] "v"(wp.doff[3]), [doff4] "v"(wp.doff[4]), [warm] "v"(warm_off),
+                           [fb] "s"(ffeats), [xp] "s"(X), [rsrc] "s"(rs), [same] "s"(same),
+                           [nslot] "s"(nslot), [count] "s"(count), [wave] "s"(wave), [ldsb] "s"(lds_base)
+                         : PIPS_ITEM_CLOBBER);
+            PIPS_TR(2);
+#ifdef PIPS_TILED_TRACE
+            if (wave == PIPS_TRACE_WAVE && lane >= 1 && lane < 9 && g_tiled_trace) g_tiled_trace[((size_t)blockIdx.x * 64 + (t & 63)) * 16 + 4 + lane] = (unsigned)trv;
+#endif
+            tile = nx_tile; count = nx_count; f = nf;
+        }
+        if (!more) break;
+    }
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -511,7 +465,7 @@ static int tiled_max_items(int N, int H8, int W8) { return cdiv(W8, TS) * cdiv(H
 size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8) {
     const int F = B * S;
     const int max_items = tiled_max_items(N, H8, W8);
-    return align_up((size_t)F * N * sizeof(int), 256) + align_up((size_t)F * max_items * sizeof(int4), 256) +
+    return align_up((size_t)F * N * sizeof(int4), 256) + align_up((size_t)F * max_items * sizeof(int4), 256) +
            align_up((size_t)F * sizeof(int), 256);
 }
 
@@ -537,12 +491,13 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     const int tiles_x = cdiv(W8, TS), tiles_y = cdiv(H8, TS), ntiles = tiles_x * tiles_y;
     const int max_items = tiled_max_items(N, H8, W8);
     char* p = (char*)scratch;
-    int* order = (int*)p; p += align_up((size_t)F * N * sizeof(int), 256);
+    int4* order = (int4*)p; p += align_up((size_t)F * N * sizeof(int4), 256);
     int4* items = (int4*)p; p += align_up((size_t)F * max_items * sizeof(int4), 256);
     int* nitems = (int*)p;
     const size_t bin_lds = ((size_t)2 * 16 * ntiles + ntiles + 1) * sizeof(int);
     PIPS_CHECK_ARG(bin_lds <= 64 * 1024, "tiled gather: map too large for the tile histogram");
-    PIPS_CHECK_ARG((size_t)H8 * W8 * C * 4 < (1ull << 31), "tiled gather: level-0 map too large for 32-bit offsets");
+    PIPS_CHECK_ARG((lvl_off[PIPS_LEVELS - 1] + (size_t)F * lvlH[PIPS_LEVELS - 1] * lvlW[PIPS_LEVELS - 1] * C) * 4 < (1ull << 32) && (size_t)B * N * S * PIPS_KIN_PAD * 4 < (1ull << 32),
+                   "tiled gather: maps / features beyond 32-bit byte offsets");
     if (ev) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(bin_particles_kernel, dim3(F), dim3(1024), bin_lds, st, coords, N, H8, W8, tiles_x, tiles_y, max_items,
                        order, items, nitems);
@@ -555,12 +510,19 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     for (int l = 0; l < PIPS_LEVELS; ++l) { lv.off[l] = lvl_off[l]; lv.H[l] = lvlH[l]; lv.W[l] = lvlW[l]; }
     {
         static std::atomic<unsigned long long> raised{0};
-        const int rc = ensure_dynamic_lds(raised, (const void*)gather_tiled_kernel, LDS_BYTES);
+        const int rc = ensure_dynamic_lds(raised, (const void*)gather_tiled_kernel, LDS_BYTES_V3);
         if (rc != PIPS_OK) return rc;
     }
+    // one persistent block per CU, a multiple of 8 so that block id mod 8 stays the XCD
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        set_error("tiled gather: cannot query the device");
+        return PIPS_E_LAUNCH;
+    }
+    const int grid = max(cus / 8, 1) * 8;
     if (ev) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(gather_tiled_kernel, dim3(max_items * F), dim3(NW * 64), LDS_BYTES, st, pyramid, lv, S_, ffeats,
-                       coords, N, tiles_x, max_items, F, order, items, nitems, X);
+    hipLaunchKernelGGL(gather_tiled_kernel, dim3(grid), dim3(NW * 64), LDS_BYTES_V3, st, pyramid, lv, S_, ffeats,
+                       N, tiles_x, max_items, F, order, items, nitems, X);
     if (ev) (void)hipEventRecord(ev[3], st);
     PIPS_CHECK_LAUNCH("gather_tiled_kernel");
     return PIPS_OK;

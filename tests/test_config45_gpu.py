@@ -43,13 +43,22 @@ def test_config4_gather_direct_and_tiled_vs_oracle():
         buf[off:off + flat.numel()] = flat
     pyr = buf.to(DEV)
     ff, co = _pm(ffeats).to(DEV), _pm(coords).to(DEV)
-    ref_pm = _pm(ref)
+    # fp64 run of the same oracle = the yardstick: at 160-pixel-wide maps a sample position carries ~1e-5 px of fp32
+    # rounding from the normalise/un-normalise round trip (:318-319 + grid_sample), worth ~5e-5 on a tap -- the fp32
+    # oracle itself is that far from fp64, so the kernels are held to twice the oracle's own fp32 error
+    ref64 = torch.cat([O.corr_sample([p.double() for p in pyr_ref], ffeats[:, :, n0:n0 + 512].double(),
+                                     coords[:, :, n0:n0 + 512].double()) for n0 in range(0, N, 512)], dim=2)
+    ref_pm, ref64_pm = _pm(ref), _pm(ref64)
     Xd = ops.mixer_input_build(pyr, B, H8, W8, ff, co).cpu()
     Xt = ops.mixer_input_build_tiled(pyr, B, H8, W8, ff, co).cpu()
-    e_d = float((Xd[:, 128:324] - ref_pm).abs().max())
-    e_t = float((Xt[:, 128:324] - ref_pm).abs().max())
-    print(f"config-4 geometry gather: direct {e_d:.2e}, tiled {e_t:.2e} (|corr| ~ {float(ref_pm.abs().max()):.1f})")
-    assert e_d < 5e-5 and e_t < 5e-5                                 # 128-term fp32 dots, values O(5)
+    floor = float((ref_pm.double() - ref64_pm).abs().max())
+    e_d = float((Xd[:, 128:324].double() - ref64_pm).abs().max())
+    e_t = float((Xt[:, 128:324].double() - ref64_pm).abs().max())
+    print(f"config-4 geometry gather vs fp64 oracle: direct {e_d:.2e}, tiled {e_t:.2e}, fp32 oracle {floor:.2e} "
+          f"(|corr| ~ {float(ref_pm.abs().max()):.1f})")
+    assert floor < 1e-4 and e_d < 2 * floor and e_t < 2 * floor
+    assert float((Xd[:, 128:324] - ref_pm).abs().max()) < 2e-4 and float((Xt[:, 128:324] - ref_pm).abs().max()) < 2e-4
+    assert torch.equal(Xt[8:16, 128:324], torch.zeros(8, 196))       # particle 1 sits fully outside the map at every level
     assert torch.equal(Xd[:, :128], Xt[:, :128]) and torch.equal(Xd[:, 324:], Xt[:, 324:])
 
 

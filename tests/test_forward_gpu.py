@@ -275,10 +275,11 @@ def test_weight_surgery_needs_invalidate(weights_tamed):
     xys, rgbs = _config2_inputs(N=4, H=128, W=160)
     a = m(xys.to(DEV), rgbs.to(DEV), iters=2)[0][-1].clone()
     with torch.no_grad():
-        m.delta_block.to_delta[15].weight.mul_(0.5)                 # in-place op: version counter -> repacked
+        w = dict(m.named_parameters())["delta_block.to_delta.15.weight"]
+        w.mul_(0.5)                                                  # in-place op: version counter -> repacked
     b = m(xys.to(DEV), rgbs.to(DEV), iters=2)[0][-1].clone()
     assert not torch.equal(a, b)
-    m.delta_block.to_delta[15].weight.data.mul_(2.0)                # through .data: invisible until invalidated
+    w.data.mul_(2.0)                                                 # through .data: invisible until invalidated
     m.invalidate_weights()
     c = m(xys.to(DEV), rgbs.to(DEV), iters=2)[0][-1]
     assert torch.equal(a, c)

@@ -14,7 +14,7 @@ n = 64
 gy, gx = torch.meshgrid(torch.linspace(1, H8 - 2, n), torch.linspace(1, W8 - 2, n), indexing="ij")
 grid = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1)
 c = grid.reshape(1, N, 1, 2).repeat(B, 1, S, 1).reshape(M, 2).contiguous().to(dev)
-nblk = 8192
+nblk = 16384                                 # 256 blocks x 64 items
 tr = torch.zeros(nblk, 16, dtype=torch.int64, device=dev)
 lib.pips_tiled_trace.argtypes = [ctypes.c_void_p]
 for _ in range(2): ops.mixer_input_build_tiled(pyr, B, H8, W8, ffeats, c)
@@ -24,15 +24,16 @@ ops.mixer_input_build_tiled(pyr, B, H8, W8, ffeats, c)
 torch.cuda.synchronize()
 lib.pips_tiled_trace(None)
 t = tr.cpu()
-live = t[:, 14] > 0
-t = t[live]
-print("blocks traced:", int(live.sum()), " particles/item: min %d mean %.1f max %d" % (int(t[:, 15].min()), float(t[:, 15].float().mean()), int(t[:, 15].max())))
-names = ["item read+DMA0", "sort", "geometry", "L0 setup", "L0 phases(8)", "L0 finish", "L1 setup", "L1 phases(8)", "L1 finish",
-         "L2 setup", "L2 phases(8)", "L2 finish", "L3 setup", "L3 phases(8)", "L3 finish"]
-d = (t[:, 1:15] - t[:, 0:14]).float()
-tot = (t[:, 14] - t[:, 0]).float()
-print("s_memtime ticks per block (mean / p90):  total %.0f / %.0f" % (float(tot.mean()), float(tot.quantile(0.9))))
-for i in [3, 6, 9, 12]:
-    print(f"  {names[i + 1] if i else 'sort':16s} {float(d[:, i].mean()):9.0f} {float(d[:, i].quantile(0.9)):9.0f}")
-span = float(t[:, 14].max() - t[:, 0].min())
-print("kernel span (ticks):", span, " sum of block totals / span =", float(tot.sum()) / span, "(concurrent blocks)")
+t = t[t[:, 2] > 0]
+print("items traced:", t.shape[0])
+names = ["C++ prologue (item fetch, geometry, DMA(0) issue)", "asm item body (set-up, 8 phases, blend + store)"]
+d = (t[:, 1:3] - t[:, 0:2]).float()
+tot = (t[:, 2] - t[:, 0]).float()
+print("s_memtime ticks per item (mean / p90):  total %.0f / %.0f" % (float(tot.mean()), float(tot.quantile(0.9))))
+for i, n in enumerate(names):
+    print(f"  {n:50s} {float(d[:, i].mean()):9.0f} {float(d[:, i].quantile(0.9)):9.0f}")
+pn = ["", "", "", "", "", "set-up (addresses, masks)", "phases: wait vmcnt(0)", "phases: barrier", "phases: pair 0", "phases: pair 1", "phases: pair 2", "(after phases)", "blend + store"]
+for i in range(5, 13):
+    print(f"    asm, wave 0: {pn[i]:34s} {float(t[:, i].float().mean()):9.0f} {float(t[:, i].float().quantile(0.9)):9.0f}")
+print("  C++ prologue split (wave 0): geometry+dma_setup %.0f | DMA(0) issue %.0f | records/geo %.0f | same+pack %.0f" % (
+    float((t[:, 13] - t[:, 0]).float().mean()), float((t[:, 14] - t[:, 13]).float().mean()), float((t[:, 15] - t[:, 14]).float().mean()), float((t[:, 1] - t[:, 15]).float().mean())))
