@@ -137,6 +137,21 @@ def stage_profile(model, xys, rgbs, device, b):
     return out, kern, gather, split
 
 
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of a kernel from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs of the same commands, tools/profile_round.sh; a live bench run cannot collect PMC
+    counters itself).  Returns (bytes or None, source)."""
+    name = "r2_pmc_traffic.json"
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+        for k, v in pmc.items():
+            if kernel_substr in k:
+                return v["hbm_bytes"], "profiles/" + name
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def config3_leg(device):
     """BASELINE configs[2] per-GPU share: B=8 clips, bf16 MFMA operands."""
     import torch
@@ -197,10 +212,12 @@ def config4_leg(device):
                      "embed_rows_kernel_ms": statistics.mean(ts["embed"]), "direct_kernel_ms(mixer_input_kernel)": t_direct,
                      "achieved_GBs": comp / tg / 1e6, "frac_of_8TBs": comp / tg / 1e6 / PEAK_HBM_GBS}
     dom = out["iter0_grid"]
+    traffic, traffic_src = pmc_traffic("gather_tiled_kernel")
     return {"workload": "BASELINE configs[3]: B=4 S=8 720x1280 N=4096 (64x64 grid) I=6 fp32 stride 8, encoder included",
             "value": b * S * n * ITERS / t_fwd * 1e3, "unit": "particle-updates/s", "ms_per_step": t_fwd, "dtype": "f32",
             "gather_roofline": {"bound": "hbm", "kernel": "gather_tiled_kernel", "achieved": dom["achieved_GBs"],
-                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": None,
+                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": traffic,
+                                "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": comp,
                                 "timing": "HIP event pair around the kernel launch (pips_mixer_input_build_tiled_timed), "
                                           "mean of 10 launches on the real maps"},
@@ -296,10 +313,20 @@ def main(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the config 3/4/5 legs and the torch-ROCm baseline")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3),
                     help="2 (default, the headline: B=1/GPU fp32) or 3 (B=8/GPU, bf16 MFMA operands)")
+    ap.add_argument("--leg", default=None, choices=("config3", "config4", "config5", "torch_rocm_baseline"),
+                    help="run ONE of the extra legs alone and print its JSON (what the rocprofv3 passes under profiles/ wrap)")
     ap.add_argument("--matmul", default="exact", choices=("exact", "split"),
                     help="config 2 only: exact-fp32 MFMA (default, the headline) or the fp32-grade split-bf16 path")
     args = ap.parse_args(argv)
     gpus = max(1, args.gpus)
+    if args.leg:
+        import torch
+        device = torch.device("cuda", 0)
+        torch.cuda.set_device(device)
+        res = {"config3": config3_leg, "config4": config4_leg, "config5": config5_leg,
+               "torch_rocm_baseline": torch_rocm_baseline}[args.leg](device)
+        print(json.dumps({args.leg: res}), flush=True)
+        return res
     if "WORLD_SIZE" not in os.environ and gpus > 1:
         sys.exit(respawn_under_launcher(gpus))
 
@@ -416,15 +443,8 @@ def main(argv=None):
         dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
         # HBM-side bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
         # command, committed per round under profiles/ (a live bench run cannot collect PMC counters itself)
-        traffic, traffic_src = None, None
-        for name in ("r2_pmc_traffic.json",):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
-                key = "pips::igemm_f32_kernel<64, 64, 2, 2, 1, false>" if dom[0].startswith("up") else \
-                    "pips::igemm_f32_kernel<64, 64, 2, 2, 2, false>"
-                traffic, traffic_src = pmc[key]["hbm_bytes"], "profiles/" + name
-            except (OSError, KeyError, ValueError):
-                pass
+        traffic, traffic_src = pmc_traffic("igemm_f32_kernel<64, 64, 2, 2, 1, false>" if dom[0].startswith("up") else
+                                           "igemm_f32_kernel<64, 64, 2, 2, 2, false>")
         # both GEMM shapes run the same kernel template; report the slower (dominant) launch
         res["roofline"] = {"bound": "mfma", "achieved": dom[1]["tflops"], "peak": PEAK_F32_MFMA_TF,
                            "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_F32_MFMA_TF, "traffic": traffic,
