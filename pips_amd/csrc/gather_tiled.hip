@@ -33,8 +33,8 @@
 //                          tools/gen_gather_asm.py): see gather_item below.
 // Output is identical in meaning to mixer_input_kernel (same taps, same transposed order, zeros outside
 // the map); the dot products are summed as an even- and an odd-channel chain and scaled by 1/sqrt(128) through the
-// blend weights (fp32 round-off differs from the direct kernel's tree sum and division: 6e-5 against the fp64 oracle
-// at 160-pixel-wide maps, where the fp32 oracle itself is 5e-5 off -- tests/test_config45_gpu.py).
+// blend weights (fp32 round-off differs from the direct kernel's tree sum and division: 6e-5 against an fp64 run of the
+// reference arithmetic at 160-pixel-wide maps, where its fp32 run is itself 5e-5 off -- tests/test_config45_gpu.py).
 #include "common.h"
 
 #include <cstdlib>
