@@ -273,70 +273,50 @@ def phase(a, NP, par):
             dma_slot(g)
 
     dma_slot(0)
-    def feats_hook(j, last):
-        # features of the NEXT pair (this chunk), or of pair 0 of the next chunk, into the other set -- behind a wait,
-        # so that the scalar loads are not what that wait waits for
-        if not last:
-            feat_request(a, (par * NP + j + 1) & 1, 2 * (j + 1), S_FOFF)
-        else:
-            nof = a.label()
-            a("s_cmp_eq_u32 s%d, -1" % S_NONEXT)
-            a("s_cbranch_scc1 %df" % nof)
-            feat_request(a, ((1 - par) * NP) & 1, 0, S_DSOFF)
-            a("%d:" % nof)
-
-    # Rolling read pipeline.  Slot a of a pair reads into fragment A, slot b into B; entering a level, a's reads are
-    # already in flight.  If b has its own fragment: issue b's reads, wait for a's (lgkmcnt(4): LDS returns in order,
-    # scalar loads in flight only make the wait stricter), FMAs of a, issue the NEXT level's (or pair's) reads of a into
-    # fragment A, wait for b's, FMAs of b.  So every FMA group runs under the other fragment's LDS latency.
-    reads(a, 0, 0, FA, par)
     for j in range(NP):
         ka, kb = 2 * j, 2 * j + 1
         s = SET[(par * NP + j) & 1]
         last = j == NP - 1
         for l in range(LEVELS):
-            nxt = (l + 1, ka) if l + 1 < LEVELS else ((0, ka + 2) if not last else None)
-            g = 4 * j + l + 1
-            if g < 8:
-                dma_slot(g)
-            if NP == 1 and l == LEVELS - 1:
-                dma_rest(5)
-            nob, join = a.label(), a.label()
+            # ---- LDS reads of the pair's two units at this level
+            reads(a, l, ka, FA, par)
+            nob = a.label()
             if last:                                  # the wave's last pair may hold one slot only
                 a("s_cmp_lt_u32 %d, %%[nslot]" % kb)
                 a("s_cbranch_scc0 %df" % nob)
             a("s_bitcmp1_b32 %%[same], %d" % (4 * kb + l))   # same window anchor as slot a: its fragment serves both
             a("s_cbranch_scc1 %df" % nob)
-            # ---- b has its own fragment
             reads(a, l, kb, FB, par)
-            a("s_waitcnt lgkmcnt(4)")
-            if l == 0:
-                feats_hook(j, last)
-            fmas(a, l, ka, s, FA)
-            if nxt:
-                reads(a, nxt[0], nxt[1], FA, par)
-                a("s_waitcnt lgkmcnt(4)")
-            else:
-                a("s_waitcnt lgkmcnt(0)")
-            fmas(a, l, kb, s + 16, FB)
-            a("s_branch %df" % join)
-            # ---- b shares a's fragment, or there is no b
             a("%d:" % nob)
             a("s_waitcnt lgkmcnt(0)")
             if l == 0:
-                feats_hook(j, last)
+                # features of the NEXT pair (this chunk), or of pair 0 of the next chunk, into the other set
+                if not last:
+                    feat_request(a, (par * NP + j + 1) & 1, 2 * (j + 1), S_FOFF)
+                else:
+                    nof = a.label()
+                    a("s_cmp_eq_u32 s%d, -1" % S_NONEXT)
+                    a("s_cbranch_scc1 %df" % nof)
+                    feat_request(a, ((1 - par) * NP) & 1, 0, S_DSOFF)
+                    a("%d:" % nof)
+            g = 4 * j + l + 1
+            if g < 8:
+                dma_slot(g)
+            if NP == 1 and l == LEVELS - 1:
+                dma_rest(5)
             fmas(a, l, ka, s, FA)
+            done = a.label()
             if last:
                 a("s_cmp_lt_u32 %d, %%[nslot]" % kb)
-                nofb = a.label()
-                a("s_cbranch_scc0 %df" % nofb)
-                fmas(a, l, kb, s + 16, FA)
-                a("%d:" % nofb)
-            else:
-                fmas(a, l, kb, s + 16, FA)
-            if nxt:
-                reads(a, nxt[0], nxt[1], FA, par)
-            a("%d:" % join)
+                a("s_cbranch_scc0 %df" % done)
+            usea = a.label()
+            a("s_bitcmp1_b32 %%[same], %d" % (4 * kb + l))
+            a("s_cbranch_scc1 %df" % usea)
+            fmas(a, l, kb, s + 16, FB)
+            a("s_branch %df" % done)
+            a("%d:" % usea)
+            fmas(a, l, kb, s + 16, FA)
+            a("%d:" % done)
         probe(a, 4 + j)
 
 
