@@ -30,7 +30,7 @@ def _stale(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tail.h"), os.path.join(CSRC, "gather_phase_asm.inc"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tail.h"), os.path.join(CSRC, "gather_item_asm.inc"),
                os.path.join(HERE, "..", "include", "pips_hip.h")]
     objs = []
     procs = []
