@@ -16,3 +16,9 @@ torch.cuda.synchronize()
 print("ok", float(X[:, 128:324].abs().max()), flush=True)
 Xd = ops.mixer_input_build(pyr, B, H8, W8, ffeats, c)
 print("max diff vs direct", float((X[:, 128:324] - Xd[:, 128:324]).abs().max()))
+d = (X[:, 128:324] - Xd[:, 128:324]).abs()
+bad = (d > 1e-4).any(1).nonzero().flatten()
+print("bad rows", bad.numel(), "of", d.shape[0], "first", bad[:12].tolist())
+if bad.numel():
+    r = int(bad[0]); k = (d[r] > 1e-4).nonzero().flatten()
+    print("row", r, "n,s =", r // 8, r % 8, "bad taps", k.numel(), k[:20].tolist(), "coord", c[r].tolist())

@@ -85,16 +85,17 @@ def row_offsets(a):
 
 def setup(a):
     """A[u], in-map bits, zeroed accumulators; the first stage's DMA pieces go out between the units.
-    Temporaries: v[112:119], s[22:31], s[33:35]."""
+    Temporaries: v[112:119], s[22:31], s[34:35]."""
     wi, wj, px, py, rx, ry, t, p = (FA + i for i in range(8))
-    x0, y0, RW, RH, W, H, RWm, RHm, lb = 22, 23, 24, 25, 26, 27, 28, 29, 33
+    x0, y0, RW, RH, W, H, RWm, lb = 22, 23, 24, 25, 26, 27, 28, 29        # (s33 holds the inside-the-map bits)
     a("v_mbcnt_lo_u32_b32 v%d, -1, 0" % t)
     a("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (t, t))                 # lane id
     a("v_and_b32 v%d, 7, v%d" % (wi, t))
     a("v_lshrrev_b32 v%d, 3, v%d" % (wj, t))
     a("v_mov_b32 v%d, 0" % INM)
     a("s_mov_b32 s%d, 0" % S_ALLIN)                                # bit 4k+l: the unit's window lies wholly inside the map
-    pieces = 0
+    dma_piece(a, 0, first=True)
+    pieces = 1
     for l in range(LEVELS):
         # wave-uniform geometry of level l out of the lane-parallel input %[gpk]: lanes l, 4+l, 8+l = x0|y0<<16, RW|RH<<16, W|H<<16
         a("v_readlane_b32 s%d, %%[gpk], %d" % (y0, l))
@@ -107,7 +108,6 @@ def setup(a):
         a("s_and_b32 s%d, s%d, 0xffff" % (W, H))
         a("s_lshr_b32 s%d, s%d, 16" % (H, H))
         a("s_sub_u32 s%d, s%d, 1" % (RWm, RW))
-        a("s_sub_u32 s%d, s%d, 1" % (RHm, RH))
         a("s_add_u32 s%d, %%[ldsb], %d" % (lb, LB[l]))             # LDS address of the level's stage pair
         nextl = a.label()
         for k in range(SLOTS):
@@ -119,11 +119,15 @@ def setup(a):
             a("v_readlane_b32 s%d, %%[bx], %d" % (S_U, bit))
             a("v_readlane_b32 s%d, %%[by], %d" % (S_U + 1, bit))
             # ---- window wholly inside the map (then also inside the staged region): no clamps, no per-lane mask
-            a("s_sub_u32 s%d, s%d, 8" % (S_T, W))
-            a("s_cmp_le_u32 s%d, s%d" % (S_U, S_T))                # 0 <= bx <= W - 8  (unsigned)
+            a("s_sub_i32 s%d, s%d, 8" % (S_T, W))                  # 0 <= bx <= W - 8 (signed: W - 8 may be negative)
+            a("s_cmp_le_i32 s%d, s%d" % (S_U, S_T))
             a("s_cbranch_scc0 %df" % slow)
-            a("s_sub_u32 s%d, s%d, 8" % (S_T, H))
-            a("s_cmp_le_u32 s%d, s%d" % (S_U + 1, S_T))
+            a("s_cmp_ge_i32 s%d, 0" % S_U)
+            a("s_cbranch_scc0 %df" % slow)
+            a("s_sub_i32 s%d, s%d, 8" % (S_T, H))
+            a("s_cmp_le_i32 s%d, s%d" % (S_U + 1, S_T))
+            a("s_cbranch_scc0 %df" % slow)
+            a("s_cmp_ge_i32 s%d, 0" % (S_U + 1))
             a("s_cbranch_scc0 %df" % slow)
             a("s_bitset1_b32 s%d, %d" % (S_ALLIN, bit))
             a("s_sub_u32 s%d, s%d, s%d" % (S_T, S_U, x0))          # dx = bx - x0
@@ -147,16 +151,16 @@ def setup(a):
             a("v_subrev_u32 v%d, s%d, v%d" % (rx, x0, px))         # px - x0, clamped into the staged region
             a("v_med3_i32 v%d, v%d, 0, s%d" % (rx, rx, RWm))
             a("v_subrev_u32 v%d, s%d, v%d" % (ry, y0, py))
-            a("v_med3_i32 v%d, v%d, 0, s%d" % (ry, ry, RHm))
+            a("s_sub_u32 s%d, s%d, 1" % (S_T, RH))
+            a("v_med3_i32 v%d, v%d, 0, s%d" % (ry, ry, S_T))
             a("v_mad_u32_u24 v%d, v%d, s%d, v%d" % (p, ry, RW, rx))
             a("v_and_b32 v%d, 3, v%d" % (t, ry))                    # swizzle key
             a("v_lshl_add_u32 v%d, v%d, 6, s%d" % (adr(l, k), p, lb))
             a("v_lshl_or_b32 v%d, v%d, 4, v%d" % (adr(l, k), t, adr(l, k)))
             a("%d:" % done)
-            if k == 0 or (k == 1 and l == 0):                      # (units every wave with particles runs)
-                if pieces < 5:
-                    dma_piece(a, pieces, first=True)               # the first stage (chunk 0 -> parity 0) goes out between the units
-                    pieces += 1
+            if k == 0:                                             # (units every wave runs, whatever its particle count)
+                dma_piece(a, pieces, first=True)                   # the first stage (chunk 0 -> parity 0) goes out between the units
+                pieces += 1
         a("%d:" % nextl)
     while pieces < 5:
         dma_piece(a, pieces, first=True)
