@@ -28,17 +28,25 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def headers():
+    """Files every translation unit depends on (beyond its own source)."""
+    return [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tail.h"), os.path.join(CSRC, "gather_item_asm.inc"),
+            os.path.join(HERE, "..", "include", "pips_hip.h")]
+
+
 def build_library(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tail.h"), os.path.join(CSRC, "gather_item_asm.inc"),
-               os.path.join(HERE, "..", "include", "pips_hip.h")]
+    headers_ = headers()
+    missing = [h for h in headers_ if not os.path.exists(h)]
+    if missing:
+        raise RuntimeError("pips_amd._build: dependency list names files that do not exist: " + ", ".join(missing))
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
+        if force or _stale(o, [s] + headers_):
             cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -109,3 +109,19 @@ def test_packed_weights_follow_parameter_changes():
     m.invalidate_weights()
     m2 = m.float()                                             # _apply path
     assert m2 is m and m._arena is None
+
+
+def test_build_script_dependencies_exist_and_asm_is_current(tmp_path):
+    """The build script's dependency list names real files (a stale name makes every rebuild fail), and the committed
+    generated assembly is what tools/gen_gather_asm.py emits today."""
+    import subprocess, sys
+    from pips_amd import _build
+    for h in _build.headers():
+        assert os.path.exists(h), h
+    out = tmp_path / "gather_item_asm.inc"
+    env = dict(os.environ, PIPS_GEN_OUT=str(out))
+    for k in ("PIPS_GEN_ABLATE", "PIPS_GEN_TRACE"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_gather_asm.py")], env=env, stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(root, "pips_amd", "csrc", "gather_item_asm.inc")).read()
