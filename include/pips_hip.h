@@ -229,6 +229,33 @@ int    pips_conv_nhwc_f32x3(const float* in, int F, int H, int W, int Cin,
                             const void* wgt3, const float* bias, int Cout, int ksize, int cstride, int pad,
                             float* out, float* stats, int* tiles_m_host, void* stream);
 
+/* Score-map loss terms of nets/pips.py:501-511 + score_map_loss :58-92 (evaluation: test_on_flt.py:87 and
+ * test_on_crohd.py:133 pass trajs_g / vis_g / valids).  pips_forward_ce / pips_track_ce are pips_forward / pips_track
+ * plus: ce_tgt (B*N*S,3) = per mixer row m=(b*N+n)*S+s {x, y, use}: the rounded target pixel in map coordinates
+ * (trajs_g/stride rounded half-to-even) and use = 1 when that heat map enters the loss (target inside the map,
+ * valids > 0, vis_g > 0), else 0;  ce_terms (iters, B*N*S, 2) receives per iteration and row {loss at the target
+ * pixel, sum of the losses of all other pixels} (balanced_ce_loss's stable softplus, :26-29) -- the caller divides
+ * the two totals by (#used rows * iters) and (#used rows * iters * (H8*W8 - 1)) (+1e-6, utils.basic.reduce_masked_mean)
+ * and adds them;  ce_ws: pips_score_map_workspace_bytes(B,S,H8,W8) of scratch (the four pyramid levels upsampled and
+ * summed once: the (B,S,N,H8,W8) volume itself is never formed).  ce_tgt == NULL: exactly pips_forward / pips_track.
+ * pips_score_map_prepare / _terms are the two stages on their own. */
+size_t pips_score_map_workspace_bytes(int B, int S, int H8, int W8);
+int    pips_score_map_prepare(const float* pyramid, int B, int S, int H8, int W8, float* U, void* stream);
+int    pips_score_map_terms(const float* U, int B, int S, int H8, int W8, const float* ffeats, int N,
+                            const float* tgt, float* out, void* stream);
+int    pips_forward_ce(const void* arena, const float* rgbs, const float* xys,
+                       const float* coords_init, const float* feat_init, const float* times,
+                       int B, int S, int H, int W, int N, int stride, int iters, int flags,
+                       void* workspace, size_t workspace_bytes,
+                       float* out_trajs, float* out_vis, float* out_ffeat0,
+                       const float* ce_tgt, float* ce_terms, void* ce_ws, size_t ce_ws_bytes, void* stream);
+int    pips_track_ce(const void* arena, const float* pyramid, int B, int T, int H8, int W8,
+                     const float* xys, const float* coords_init, const float* feat_init,
+                     const int* win_start, const float* times, int N, int stride, int iters, int flags,
+                     void* workspace, size_t workspace_bytes,
+                     float* out_trajs, float* out_vis, float* out_ffeat0,
+                     const float* ce_tgt, float* ce_terms, void* ce_ws, size_t ce_ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

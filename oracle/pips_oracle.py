@@ -276,3 +276,72 @@ def forward(sd, xys, rgbs, iters=3, stride=8, coords_init=None, feat_init=None, 
 
 def to_dtype(sd, dtype):
     return {k: v.to(dtype) for k, v in sd.items()}
+
+
+# ------------------------------------------------------------------ evaluation losses (nets/pips.py:14-92, 501-511, 600-606)
+def dense_score_maps(pyramid, ffeats):
+    """The per-iteration dense score map of nets/pips.py:501-511: every level's correlation volume (CorrBlock.corr,
+    :384-398) upsampled to the level-0 size (bilinear, align_corners=True) and summed.  ffeats (B,S,N,C) -> (B,S,N,H8,W8)."""
+    B, S, N, C = ffeats.shape
+    H8, W8 = pyramid[0].shape[-2:]
+    fcp = torch.zeros(B, S, N, H8, W8, dtype=ffeats.dtype, device=ffeats.device)                      # :503
+    for fm in pyramid:
+        _, _, _, H, W = fm.shape
+        corr = torch.matmul(ffeats, fm.reshape(B, S, C, H * W))                                        # :394-395
+        corr = corr / torch.sqrt(torch.tensor(float(C), dtype=corr.dtype, device=corr.device))       # :397
+        up = F.interpolate(corr.reshape(B * S, N, H, W), (H8, W8), mode="bilinear", align_corners=True)   # :508
+        fcp = fcp + up.reshape(B, S, N, H8, W8)                                                        # :509
+    return fcp
+
+
+def _masked_mean(x, mask):
+    return (x * mask).sum() / (1e-6 + mask.sum())                      # utils.basic.reduce_masked_mean
+
+
+def balanced_ce_loss(pred, gt, valid=None):
+    """nets/pips.py:14-37."""
+    if valid is None:
+        valid = torch.ones_like(gt)
+    pos = (gt > 0.95).to(pred.dtype)
+    neg = (gt < 0.05).to(pred.dtype)
+    label = pos * 2.0 - 1.0
+    a = -label * pred
+    b = F.relu(a)
+    loss = b + torch.log(torch.exp(-b) + torch.exp(a - b))
+    return _masked_mean(loss, pos * valid) + _masked_mean(loss, neg * valid), loss
+
+
+def score_map_loss(fcps, trajs_g, vis_g, valids):
+    """nets/pips.py:58-92.  fcps (B,S,I,N,H8,W8), trajs_g (B,S,N,2) in map pixels."""
+    B, S, I, N, H8, W8 = fcps.shape
+    fcp_ = fcps.permute(0, 1, 3, 2, 4, 5).reshape(B * S * N, I, H8, W8)
+    xy_ = trajs_g.reshape(B * S * N, 2).round().long()
+    vis_ = vis_g.reshape(B * S * N)
+    valid_ = valids.reshape(B * S * N)
+    x_, y_ = xy_[:, 0], xy_[:, 1]
+    ind = (x_ >= 0) & (x_ <= (W8 - 1)) & (y_ >= 0) & (y_ <= (H8 - 1)) & (valid_ > 0) & (vis_ > 0)
+    fcp_ = fcp_[ind]
+    xy_ = xy_[ind]
+    gt_ = torch.zeros_like(fcp_)
+    for n in range(fcp_.shape[0]):
+        gt_[n, :, xy_[n, 1], xy_[n, 0]] = 1
+    return balanced_ce_loss(fcp_.reshape(-1), gt_.reshape(-1))[0]
+
+
+def sequence_loss(flow_preds, flow_gt, vis, valids, gamma=0.8):
+    """nets/pips.py:39-56."""
+    n = len(flow_preds)
+    loss = 0.0
+    for i, p in enumerate(flow_preds):
+        loss = loss + gamma ** (n - i - 1) * _masked_mean((p - flow_gt).abs().mean(dim=3), valids)
+    return loss / n
+
+
+def losses(sd, xys, rgbs, trajs_g, vis_g, valids, iters=3, stride=8, coords_init=None, feat_init=None):
+    """(seq_loss, vis_loss, ce_loss) of nets/pips.py:600-606 for the forward above."""
+    taps = {}
+    preds, _, vis, _ = forward(sd, xys, rgbs, iters=iters, stride=stride, coords_init=coords_init, feat_init=feat_init,
+                               taps=taps)
+    fcps = torch.stack([dense_score_maps(taps["pyramid"], it["ffeats_in"]) for it in taps["iters"]], dim=2)
+    return (sequence_loss(preds, trajs_g, vis_g, valids), balanced_ce_loss(vis, vis_g, valids)[0],
+            score_map_loss(fcps, trajs_g / float(stride), vis_g, valids))

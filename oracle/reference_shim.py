@@ -17,8 +17,13 @@ def available() -> bool:
     return os.path.isfile(os.path.join(REFERENCE_ROOT, "nets", "pips.py"))
 
 
-def load_reference_pips(sd, stride=8, S=8):
-    """Instantiate ``nets.pips.Pips`` and load ``sd`` into it (strict)."""
+def reference_module():
+    """The unmodified ``nets/pips.py`` as a module (its functions: score_map_loss, balanced_ce_loss, ...)."""
+    load = load_reference_pips.__globals__["_load_module"]
+    return load()
+
+
+def _load_module():
     import torch
 
     sys.dont_write_bytecode = True            # the mount is read-only by contract
@@ -37,8 +42,12 @@ def load_reference_pips(sd, stride=8, S=8):
         mod = importlib.util.module_from_spec(spec)
         sys.modules[name] = mod
         spec.loader.exec_module(mod)
-    Pips = sys.modules[name].Pips
+    return sys.modules[name]
 
+
+def load_reference_pips(sd, stride=8, S=8):
+    """Instantiate ``nets.pips.Pips`` and load ``sd`` into it (strict)."""
+    Pips = _load_module().Pips
     m = Pips(S=S, stride=stride).eval()
     missing = m.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys

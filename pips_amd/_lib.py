@@ -24,6 +24,13 @@ SIGNATURES = {
     "pips_workspace_bytes": (c_size_t, [c_int] * 6),
     "pips_forward": (c_int, [c_void_p, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_void_p, c_size_t, fp, fp, fp, c_void_p]),
+    "pips_forward_ce": (c_int, [c_void_p, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_void_p, c_size_t, fp, fp, fp, fp, fp, c_void_p, c_size_t, c_void_p]),
+    "pips_track_ce": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p, fp, c_int, c_int, c_int,
+                              c_int, c_void_p, c_size_t, fp, fp, fp, fp, fp, c_void_p, c_size_t, c_void_p]),
+    "pips_score_map_workspace_bytes": (c_size_t, [c_int] * 4),
+    "pips_score_map_prepare": (c_int, [fp, c_int, c_int, c_int, c_int, fp, c_void_p]),
+    "pips_score_map_terms": (c_int, [fp, c_int, c_int, c_int, c_int, fp, c_int, fp, fp, c_void_p]),
     "pips_track_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pips_track": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p, fp, c_int, c_int, c_int,
                            c_int, c_void_p, c_size_t, fp, fp, fp, c_void_p]),

@@ -745,10 +745,49 @@ size_t pips_track_workspace_bytes(int B, int N) {
     return plan_track(B, N).total * sizeof(float);
 }
 
+// level table of a pyramid with frames*H8*W8 level-0 pixels (pips_pyramid_offset's packing)
+static void pyramid_table(int frames, int H8, int W8, size_t* off, int* lh, int* lw) {
+    lh[0] = H8; lw[0] = W8;
+    for (int l = 1; l < PIPS_LEVELS; ++l) { lh[l] = lh[l - 1] / 2; lw[l] = lw[l - 1] / 2; }
+    size_t o = 0;
+    for (int l = 0; l < PIPS_LEVELS; ++l) {
+        off[l] = o;
+        o += ((size_t)frames * lh[l] * lw[l] * PIPS_C + 63) / 64 * 64;
+    }
+}
+
+size_t pips_score_map_workspace_bytes(int B, int S, int H8, int W8) {
+    if (B <= 0 || S <= 0 || H8 <= 0 || W8 <= 0) return 0;
+    return (size_t)B * S * H8 * W8 * PIPS_C * sizeof(float);
+}
+
+int pips_score_map_prepare(const float* pyramid, int B, int S, int H8, int W8, float* U, void* stream) {
+    PIPS_CHECK_ARG(pyramid && U && B > 0 && S > 0 && H8 >= 8 && W8 >= 8, "score_map_prepare: bad argument");
+    size_t off[PIPS_LEVELS]; int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
+    pyramid_table(B * S, H8, W8, off, lh, lw);
+    return launch_score_upsum(pyramid, off, lh, lw, B * S, U, (hipStream_t)stream);
+}
+
+int pips_score_map_terms(const float* U, int B, int S, int H8, int W8, const float* ffeats, int N, const float* tgt,
+                         float* out, void* stream) {
+    PIPS_CHECK_ARG(U && ffeats && tgt && out && B > 0 && S > 0 && N > 0, "score_map_terms: bad argument");
+    return launch_score_terms(U, B, S, H8, W8, ffeats, N, tgt, out, (hipStream_t)stream);
+}
+
 int pips_track(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
                const float* coords_init, const float* feat_init, const int* win_start, const float* times, int N,
                int stride, int iters, int flags, void* workspace, size_t workspace_bytes, float* out_trajs,
                float* out_vis, float* out_ffeat0, void* stream) {
+    return pips_track_ce(arena, pyramid, B, T, H8, W8, xys, coords_init, feat_init, win_start, times, N, stride, iters,
+                         flags, workspace, workspace_bytes, out_trajs, out_vis, out_ffeat0, nullptr, nullptr, nullptr, 0,
+                         stream);
+}
+
+int pips_track_ce(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
+                  const float* coords_init, const float* feat_init, const int* win_start, const float* times, int N,
+                  int stride, int iters, int flags, void* workspace, size_t workspace_bytes, float* out_trajs,
+                  float* out_vis, float* out_ffeat0, const float* ce_tgt, float* ce_terms, void* ce_ws,
+                  size_t ce_ws_bytes, void* stream) {
     PIPS_CHECK_ARG(arena && pyramid && xys && times && workspace && out_trajs && out_vis, "track: null pointer");
     PIPS_CHECK_ARG(B > 0 && N > 0 && T >= 1 && iters >= 0 && stride >= 1, "track: need B,N,T,stride >= 1 and iters >= 0");
     PIPS_CHECK_ARG(H8 >= 8 && W8 >= 8, "track: map %dx%d too small for a 4-level pyramid", H8, W8);
@@ -771,9 +810,20 @@ int pips_track(const void* arena, const float* pyramid, int B, int T, int H8, in
         RUN(launch_point_sample_strided(pyramid, B, T, H8, W8, coords, S * 2, N, win_start, ffeat0, st));   // :463
     }
     RUN(launch_init_ffeats(ffeat0, B * N, ffeats, st));                                                      // :466
+    if (ce_tgt != nullptr) {            // score-map loss terms of every iteration (:501-511, 58-92): evaluation only
+        PIPS_CHECK_ARG(ce_terms && ce_ws && win_start == nullptr && T == PIPS_S,
+                       "track: score-map terms need their output and workspace, 8 frames per clip and no windows");
+        if (ce_ws_bytes < pips_score_map_workspace_bytes(B, T, H8, W8)) {
+            set_error("track: score-map workspace %zu < %zu bytes", ce_ws_bytes, pips_score_map_workspace_bytes(B, T, H8, W8));
+            return PIPS_E_WORKSPACE;
+        }
+        RUN(pips_score_map_prepare(pyramid, B, T, H8, W8, (float*)ce_ws, stream));
+    }
     if (iters == 0)       // the loop body never runs: vis_e comes from the initial features (:559)
         RUN(launch_vis_head((const float*)arena, ffeats, B, N, out_vis, st));
     for (int it = 0; it < iters; ++it) {                                                                     // :499
+        if (ce_tgt != nullptr)           // fcorr_fn.corr(ffeats) of this iteration (:501), before the update
+            RUN(launch_score_terms((const float*)ce_ws, B, S, H8, W8, ffeats, N, ce_tgt, ce_terms + (size_t)it * M * 2, st));
         // the mixer workspace is idle while the gather runs: it doubles as the binning scratch
         RUN(mixer_input(pyramid, B, T, H8, W8, ffeats, coords, times, N, win_start, ws + P.X, st, ws + P.mixer,
                         pips_mixer_workspace_bytes(M)));
@@ -795,6 +845,15 @@ int pips_forward(const void* arena, const float* rgbs, const float* xys, const f
                  const float* feat_init, const float* times, int B, int S, int H, int W, int N, int stride,
                  int iters, int flags, void* workspace, size_t workspace_bytes, float* out_trajs, float* out_vis,
                  float* out_ffeat0, void* stream) {
+    return pips_forward_ce(arena, rgbs, xys, coords_init, feat_init, times, B, S, H, W, N, stride, iters, flags, workspace,
+                           workspace_bytes, out_trajs, out_vis, out_ffeat0, nullptr, nullptr, nullptr, 0, stream);
+}
+
+int pips_forward_ce(const void* arena, const float* rgbs, const float* xys, const float* coords_init,
+                    const float* feat_init, const float* times, int B, int S, int H, int W, int N, int stride,
+                    int iters, int flags, void* workspace, size_t workspace_bytes, float* out_trajs, float* out_vis,
+                    float* out_ffeat0, const float* ce_tgt, float* ce_terms, void* ce_ws, size_t ce_ws_bytes,
+                    void* stream) {
     PIPS_CHECK_ARG(arena && xys && times && workspace && out_trajs && out_vis, "forward: null pointer");
     PIPS_CHECK_ARG((flags & PIPS_FLAG_REUSE_MAPS) || rgbs != nullptr, "forward: rgbs is null");
     PIPS_CHECK_ARG(S == PIPS_S, "forward: S=%d, the mixer weights fix S=%d (nets/pips.py:295-301)", S, PIPS_S);
@@ -812,9 +871,9 @@ int pips_forward(const void* arena, const float* rgbs, const float* xys, const f
                          pips_encoder_workspace_bytes(B * S, H, W, stride), stream,
                          ((flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0) | ((flags & PIPS_FLAG_RGB_U8) ? 2 : 0) |
                              ((flags & PIPS_FLAG_SPLIT_BF16) ? 4 : 0)));
-    return pips_track(arena, pyramid, B, S, H / stride, W / stride, xys, coords_init, feat_init, nullptr, times, N,
-                      stride, iters, flags, ws + P.track, plan_track(B, N).total * sizeof(float), out_trajs, out_vis,
-                      out_ffeat0, stream);
+    return pips_track_ce(arena, pyramid, B, S, H / stride, W / stride, xys, coords_init, feat_init, nullptr, times, N,
+                         stride, iters, flags, ws + P.track, plan_track(B, N).total * sizeof(float), out_trajs, out_vis,
+                         out_ffeat0, ce_tgt, ce_terms, ce_ws, ce_ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -234,6 +234,10 @@ int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn
                      hipStream_t st);
 int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,
                    hipStream_t st);
+int launch_score_upsum(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int F, float* U,
+                       hipStream_t st);
+int launch_score_terms(const float* U, int B, int S, int H8, int W8, const float* ffeats, int N, const float* tgt,
+                       float* out, hipStream_t st);
 int launch_vis_head(const float* arena, const float* ffeats, int B, int N, float* out_vis, hipStream_t st);
 int launch_state_update(const float* arena, const float* delta, float* ffeats, float* coords,
                         const float* coords0, int B, int N, float stride, float* out_traj,

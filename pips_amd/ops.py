@@ -155,6 +155,22 @@ def mixer_input_build_tiled_timed(pyr, B, H8, W8, ffeats, coords):
     return X, {"bin": ms[0], "embed": ms[1], "gather": ms[2]}
 
 
+def score_map_terms(pyr, B, H8, W8, ffeats, tgt):
+    """Per mixer row {loss at the target pixel, sum of the losses of the other pixels} of the dense score map
+    (nets/pips.py:501-511 + score_map_loss :58-92).  ffeats (B*N*S,128), tgt (B*N*S,3) = {x, y, use}."""
+    lib = _lib.load()
+    ffeats, tgt = _f32(ffeats), _f32(tgt)
+    M = ffeats.shape[0]
+    N = M // (B * S)
+    U = torch.empty(lib.pips_score_map_workspace_bytes(B, S, H8, W8) // 4, dtype=torch.float32, device=ffeats.device)
+    out = torch.empty(M, 2, dtype=torch.float32, device=ffeats.device)
+    with torch.cuda.device(ffeats.device):
+        _lib.check(lib.pips_score_map_prepare(_lib.ptr(pyr), B, S, H8, W8, _lib.ptr(U), _stream()), "pips_score_map_prepare")
+        _lib.check(lib.pips_score_map_terms(_lib.ptr(U), B, S, H8, W8, _lib.ptr(ffeats), N, _lib.ptr(tgt), _lib.ptr(out),
+                                            _stream()), "pips_score_map_terms")
+    return out
+
+
 def mixer_fwd(arena, X, bf16=False, split=False):
     """X (M,544) -> delta (M/8, 1040).  bf16: bf16 MFMA operands in the channel-mix/head GEMMs;
     split: every GEMM on the fp32-grade split-bf16 path."""

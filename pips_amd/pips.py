@@ -10,8 +10,8 @@ losses)`` or, with ``return_feat=True``, ``(..., vis_e, ffeat (B,N,128), losses)
 
 Inference only: ``is_train=True`` raises; a summary writer whose ``save_this`` is set raises
 (the tensorboard drawings of nets/pips.py:477-497,541-557,564-598 need the dense score maps this
-path never forms); ``losses`` carries ``(seq_loss, vis_loss, None)`` when ``trajs_g`` is given
-(the score-map loss needs the same volume, nets/pips.py:504-511,603).  ``S`` must be 8 (the HIP
+path never stores); ``losses`` carries the reference's ``(seq_loss, vis_loss, ce_loss)`` when ``trajs_g`` is given
+(nets/pips.py:600-606; the score-map loss is reduced on the fly by ``pips_forward_ce``).  ``S`` must be 8 (the HIP
 kernels are specialised for the window every shipped checkpoint and caller uses).  There is no
 PyTorch fallback: without the HIP library or a GPU the forward raises.
 
@@ -165,18 +165,29 @@ class Pips(nn.Module):
             trajs = torch.empty(iters + 1, B, S, N, 2, dtype=f32, device=dev)
             vis_e = torch.empty(B, S, N, dtype=f32, device=dev)
             ffeat = torch.empty(B, N, self.latent_dim, dtype=f32, device=dev)
-            rc = lib.pips_forward(_lib.ptr(arena), _lib.ptr(rgbs_c), _lib.ptr(xys_c), _lib.ptr(ci), _lib.ptr(fi),
-                                  _lib.ptr(self._times), B, S, H, W, N, int(self.stride), int(iters),
-                                  self._flags() | (8 if u8 else 0),
-                                  _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
-                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            # evaluation call (test_on_flt.py:87): the score-map loss terms of every iteration come out of the same
+            # forward -- heat maps are correlated and reduced on the fly, the (B,S,N,H8,W8) volume is never stored
+            ce_tgt = ce_terms = ce_ws = None
+            H8, W8 = H // int(self.stride), W // int(self.stride)
+            if trajs_g is not None and iters > 0:
+                ce_tgt = _score_map_targets(trajs_g.to(dev), vis_g.to(dev), valids.to(dev), float(self.stride), H8, W8)
+                ce_terms = torch.empty(iters, B * N * S, 2, dtype=f32, device=dev)
+                ce_ws = torch.empty(lib.pips_score_map_workspace_bytes(B, S, H8, W8) // 4, dtype=f32, device=dev)
+            rc = lib.pips_forward_ce(_lib.ptr(arena), _lib.ptr(rgbs_c), _lib.ptr(xys_c), _lib.ptr(ci), _lib.ptr(fi),
+                                     _lib.ptr(self._times), B, S, H, W, N, int(self.stride), int(iters),
+                                     self._flags() | (8 if u8 else 0),
+                                     _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
+                                     _lib.ptr(ce_tgt), _lib.ptr(ce_terms), _lib.ptr(ce_ws),
+                                     0 if ce_ws is None else ce_ws.numel() * 4,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "pips_forward")
         coord_predictions = [trajs[i + 1] for i in range(iters)]
         # nets/pips.py:474-475,539,562-563: two copies of the start, every iterate, two of the end
         coord_predictions2 = [trajs[0], trajs[0]] + coord_predictions + [trajs[iters], trajs[iters]]
         losses = None
         if trajs_g is not None:
-            losses = _inference_losses(coord_predictions, vis_e, trajs_g, vis_g, valids)
+            losses = _inference_losses(coord_predictions, vis_e, trajs_g, vis_g, valids, ce_tgt=ce_tgt, ce_terms=ce_terms,
+                                       npix=H8 * W8)
         if return_feat:
             return coord_predictions, coord_predictions2, vis_e, ffeat, losses
         return coord_predictions, coord_predictions2, vis_e, losses
@@ -286,9 +297,28 @@ def sequence_loss(flow_preds, flow_gt, vis, valids, gamma=0.8):
     return loss / n
 
 
-def _inference_losses(preds, vis_e, trajs_g, vis_g, valids, gamma=0.8):
-    """The losses tuple of nets/pips.py:600-606 on the outputs (evaluation scripts pass trajs_g but discard the
-    result, test_on_flt.py:87-100): (seq_loss, vis_loss, None) -- the score-map loss needs the dense volume."""
+def _score_map_targets(trajs_g, vis_g, valids, stride, H8, W8):
+    """score_map_loss's target selection (nets/pips.py:62-69) as the (B*N*S, 3) table pips_forward_ce takes: rounded
+    target pixel (torch.round: half to even) in map coordinates and whether the heat map is used."""
+    B, S, N, _ = trajs_g.shape
+    xy = (trajs_g.float() / stride).round()
+    x, y = xy[..., 0], xy[..., 1]
+    use = (x >= 0) & (x <= W8 - 1) & (y >= 0) & (y <= H8 - 1) & (valids > 0) & (vis_g > 0)
+    t = torch.stack([x.clamp(0, W8 - 1), y.clamp(0, H8 - 1), use.float()], dim=-1)              # (B,S,N,3)
+    return t.permute(0, 2, 1, 3).reshape(B * N * S, 3).contiguous()
+
+
+def _inference_losses(preds, vis_e, trajs_g, vis_g, valids, gamma=0.8, ce_tgt=None, ce_terms=None, npix=0):
+    """The losses tuple of nets/pips.py:600-606 on the outputs (evaluation scripts pass trajs_g, test_on_flt.py:87):
+    (seq_loss, vis_loss, ce_loss).  ce_loss = score_map_loss (:58-92) from the per-row terms of pips_forward_ce: the
+    balanced cross-entropy's two masked means (utils.basic.reduce_masked_mean, EPS 1e-6) over the used heat maps of all
+    iterations -- one positive pixel each, npix - 1 negatives."""
+    vis_loss = balanced_ce_loss(vis_e, vis_g, valids)[0]
     if len(preds) == 0:
-        return torch.zeros((), device=vis_e.device), balanced_ce_loss(vis_e, vis_g, valids)[0], None
-    return sequence_loss(preds, trajs_g, vis_g, valids, gamma), balanced_ce_loss(vis_e, vis_g, valids)[0], None
+        return torch.zeros((), device=vis_e.device), vis_loss, None
+    ce_loss = None
+    if ce_terms is not None:
+        n_maps = ce_tgt[:, 2].sum() * ce_terms.shape[0]
+        t = ce_terms.double().sum(dim=(0, 1))
+        ce_loss = (t[0] / (n_maps + 1e-6) + t[1] / (n_maps * (npix - 1) + 1e-6)).float()
+    return sequence_loss(preds, trajs_g, vis_g, valids, gamma), vis_loss, ce_loss

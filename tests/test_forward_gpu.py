@@ -230,8 +230,8 @@ def test_errors_and_signature(weights_tamed):
 # ------------------------------------------------------------------ round-2 boundary additions
 @pytest.mark.parametrize("name,rtol", [("s8_tamed_i6", 2e-4), ("s8_raw_i3", 2e-2)])
 def test_inference_losses_match_reference(name, rtol, weights_raw, weights_tamed):
-    """(seq_loss, vis_loss) of the forward called with trajs_g / vis_g / valids (test_on_flt.py:87) against the values
-    the unmodified reference returned for the same inputs (tests/golden/<case>_losses.npz, make_golden.py).  On raw
+    """(seq_loss, vis_loss, ce_loss) of the forward called with trajs_g / vis_g / valids (test_on_flt.py:87) against the
+    values the unmodified reference returned for the same inputs (tests/golden/<case>_losses.npz, make_golden.py).  On raw
     weights the third iterate is already in the chaotic regime (see the module docstring): looser gate."""
     case = G.CASES[name]
     gold = np.load(os.path.join(GOLD, name + "_losses.npz"))
@@ -241,10 +241,12 @@ def test_inference_losses_match_reference(name, rtol, weights_raw, weights_tamed
     m = _model(sd, case["stride"])
     out = m(xys.to(DEV), rgbs.to(DEV), iters=case["iters"], trajs_g=tg.to(DEV), vis_g=vg.to(DEV), valids=va.to(DEV))
     seq, vis, ce = out[3]
-    print(name, "seq", float(seq), float(gold["seq_loss"]), "vis", float(vis), float(gold["vis_loss"]))
+    print(name, "seq", float(seq), float(gold["seq_loss"]), "vis", float(vis), float(gold["vis_loss"]), "ce", float(ce),
+          float(gold["ce_loss"]))
     assert abs(float(seq) - float(gold["seq_loss"])) <= rtol * abs(float(gold["seq_loss"]))
     assert abs(float(vis) - float(gold["vis_loss"])) <= rtol * abs(float(gold["vis_loss"]))
-    assert ce is None                       # the score-map loss needs the dense volume (documented gap)
+    # score_map_loss (nets/pips.py:58-92): dense heat maps of every iteration, reduced on the fly by pips_forward_ce
+    assert abs(float(ce) - float(gold["ce_loss"])) <= rtol * abs(float(gold["ce_loss"]))
 
 
 def test_iters_zero_returns_initial_state(weights_tamed):

@@ -270,6 +270,42 @@ def _pm(t):
     return t.permute(0, 2, 1, 3).reshape(B * N * S, X).contiguous()
 
 
+@pytest.mark.parametrize("B,N,H8,W8", [(1, 33, 46, 62), (2, 7, 17, 25)])
+def test_score_map_terms(B, N, H8, W8):
+    """The dense score maps of nets/pips.py:501-511 (four levels upsampled with align_corners=True and summed) and the two
+    sums score_map_loss (:58-92) takes from each: HIP (levels summed once, heat maps never stored) against the oracle's
+    (B,S,N,H8,W8) volume, incl. odd level sizes and targets on the map border."""
+    from pips_amd import ops, _lib
+    O = _oracle()
+    lib = _lib.load()
+    fmaps, ffeats, _ = _random_state(B, N, H8, W8, seed=13)
+    g = torch.Generator().manual_seed(14)
+    tx = torch.randint(0, W8, (B, 8, N), generator=g).float()
+    ty = torch.randint(0, H8, (B, 8, N), generator=g).float()
+    tx[0, 0, 0], ty[0, 0, 0] = 0.0, 0.0
+    tx[0, 1, 0], ty[0, 1, 0] = W8 - 1.0, H8 - 1.0
+    use = (torch.rand(B, 8, N, generator=g) > 0.25).float()
+    pyr_ref = O.build_pyramid(fmaps)
+    fcp = O.dense_score_maps(pyr_ref, ffeats)                                        # (B,S,N,H8,W8)
+    a_pos = -fcp[torch.arange(B)[:, None, None], torch.arange(8)[None, :, None], torch.arange(N)[None, None, :],
+                 ty.long(), tx.long()]
+    sp = lambda a: torch.relu(a) + torch.log(torch.exp(-torch.relu(a)) + torch.exp(a - torch.relu(a)))
+    pos_ref = sp(a_pos)
+    neg_ref = sp(fcp).sum(dim=(-1, -2)) - sp(-a_pos)
+    buf = torch.zeros(lib.pips_pyramid_floats(B * 8, H8 * 8, W8 * 8, 8))
+    for l, p in enumerate(pyr_ref):
+        off = lib.pips_pyramid_offset(B * 8, H8 * 8, W8 * 8, 8, l)
+        flat = p.reshape(B * 8, 128, p.shape[-2], p.shape[-1]).permute(0, 2, 3, 1).reshape(-1)
+        buf[off:off + flat.numel()] = flat
+    tgt = _pm(torch.stack([tx, ty, use], dim=-1))
+    out = ops.score_map_terms(buf.to(DEV), B, H8, W8, _pm(ffeats).to(DEV), tgt.to(DEV)).cpu()
+    u = _pm(use.unsqueeze(-1))[:, 0] > 0
+    assert torch.equal(out[~u], torch.zeros_like(out[~u]))
+    pos_pm, neg_pm = _pm(pos_ref.unsqueeze(-1))[:, 0], _pm(neg_ref.unsqueeze(-1))[:, 0]
+    assert float((out[u, 0] - pos_pm[u]).abs().max()) < 1e-4 * max(1.0, float(pos_pm.abs().max()))
+    assert float(((out[u, 1] - neg_pm[u]) / neg_pm[u]).abs().max()) < 2e-5
+
+
 def test_point_sample():
     from pips_amd import ops
     O = _oracle()

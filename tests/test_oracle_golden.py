@@ -69,3 +69,30 @@ def test_chain_oracle_frame_cache_equals_faithful_loop(weights_tamed):
     b, hb = chain_oracle.chain(weights_tamed, video, xy0, iters=3, stride=8, cache_frames=True)
     assert ha == hb
     assert float((a - b).abs().max()) < 1e-4
+
+
+def test_oracle_losses_match_reference_golden(weights_raw, weights_tamed):
+    """(seq_loss, vis_loss, ce_loss) of the oracle against the values the unmodified reference returned (make_golden.py
+    --losses): pins the restated score maps (nets/pips.py:501-511) and score_map_loss (:58-92)."""
+    for name in ("s8_raw_i3", "s8_tamed_i6"):
+        case = G.CASES[name]
+        gold = np.load(os.path.join(GOLD, name + "_losses.npz"))
+        sd = weights_tamed if case["tamed"] else weights_raw
+        xys, rgbs, ci, fi = G.make_inputs(case)
+        tg, vg, va = G.make_targets(case)
+        seq, vis, ce = O.losses(sd, xys, rgbs, tg, vg, va, iters=case["iters"], stride=case["stride"], coords_init=ci,
+                                feat_init=fi)
+        for got, key in ((seq, "seq_loss"), (vis, "vis_loss"), (ce, "ce_loss")):
+            assert float(got) == pytest.approx(float(gold[key]), rel=1e-6), (name, key)
+
+
+@pytest.mark.skipif(not R.available(), reason="reference not mounted")
+def test_oracle_score_map_loss_equals_live_reference_function():
+    """oracle.score_map_loss against nets.pips.score_map_loss itself on random heat maps (bit-equal)."""
+    ref_mod = R.reference_module()
+    g = torch.Generator().manual_seed(4)
+    fcps = torch.randn(2, 8, 3, 5, 12, 16, generator=g) * 3
+    tg = torch.rand(2, 8, 5, 2, generator=g) * torch.tensor([18.0, 14.0]) - 1.0          # some targets outside the map
+    vg = (torch.rand(2, 8, 5, generator=g) > 0.3).float()
+    va = (torch.rand(2, 8, 5, generator=g) > 0.1).float()
+    assert torch.equal(O.score_map_loss(fcps, tg, vg, va), ref_mod.score_map_loss(fcps, tg, vg, va))
