@@ -319,8 +319,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
                                                                   const int* __restrict__ nitems,
                                                                   float* __restrict__ X) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int xcd = blockIdx.x & 7, J = gridDim.x >> 3;
     const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
     u4v rs;                                                        // the same descriptor as `map`, as plain SGPR values
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
     // Records of item (first, count) this wave needs, by LDS-DMA into buffer p (no VGPRs: the copy is in flight across
     // the asm statement of the item before): the wave's six slots (16 B each, lanes 0-5) and, in waves 0-1, the mixer
     // row of particle tid (4 B) for the L2 touches of the features
-    auto prefetch_records = [&](int f_, int first, int count, int p) {
+    auto prefetch_records = [&](int f_, int first, int count, int p, int lane, int tid) {
         const int base_n = count / NW, rem = count - base_n * NW;
         const int nslot = base_n + (wave < rem ? 1 : 0), start = wave * base_n + min(wave, rem);
         const unsigned o0 = (unsigned)(((size_t)f_ * N + first) * sizeof(int4));
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
         //      xcd, xcd + 8, ... one after another); lane-parallel look-up, entries {tile, first, count, frame} in LDS
         __syncthreads();
         if (wave == 0) {
-            int gi = (blockIdx.x >> 3) + (base + lane) * J, fr = xcd;
+            int gi = (blockIdx.x >> 3) + (base + lane0) * J, fr = xcd;
             int4 e = make_int4(0, 0, 0, -1);
             for (; fr < F; fr += 8) {
                 const int n = nitems[fr];
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
                 gi -= n;
             }
             if (fr < F) { e = items[(size_t)fr * max_items + gi]; e.w = fr; }
-            ent[lane] = e;
+            ent[lane0] = e;
         }
         __syncthreads();
         // (entries travel as scalars: an int4 held in vector registers across the asm statement costs spills)
@@ -370,11 +370,16 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
         PIPS_ENT(c0, 0);
         if (c0_f < 0) break;
         int tile = c0_tile, count = c0_count, f = c0_f;
-        prefetch_records(c0_f, c0_first, c0_count, 0);
+        prefetch_records(c0_f, c0_first, c0_count, 0, lane0, tid0);
         __builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
         bool more = true;
         for (int i = 0; i < 64; ++i) {
             if (f < 0) { more = false; break; }
+            // per-iteration copies the compiler cannot see through: lane-dependent addresses are otherwise hoisted out of
+            // the loop and, with only v0-v22 live across the asm statement, spilled -- and a scratch reload travels the
+            // vector-memory pipe behind 72 KiB of stage DMA
+            int lane = lane0, tid = tid0;
+            asm volatile("" : "+v"(lane), "+v"(tid));
 #ifdef PIPS_TILED_TRACE
             const int t = base + i;
 #endif
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
             //      stage pieces, issued from the asm, are 72 KiB)
             PIPS_ENT(nx, min(i + 1, 63));
             const int nf = i + 1 < 64 ? nx_f : -1;
-            if (nf >= 0) prefetch_records(nf, nx_first, nx_count, p ^ 1);
+            if (nf >= 0) prefetch_records(nf, nx_first, nx_count, p ^ 1, lane, tid);
             PIPS_TR(13);
             // ---- staged regions and the wave's DMA pieces (the asm issues them, the first stage between its address
             //      set-up: no barrier needed -- a wave gets here only after the barrier of the previous item's last
