@@ -621,10 +621,10 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
                         EPI_BIAS, nullptr, 0, stream));
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
-        RUN(launch_token_mix(arena, L, x, xn, P, st));
+        RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1));
         if (bf16) {
             const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
-            TIMED(gemm_h(xn, 0, PIPS_DMIX, hw + A.h_w1[d], arena + L.b1, h, 1, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX,
+            TIMED(gemm_h(xn, 1, PIPS_DMIX, hw + A.h_w1[d], arena + L.b1, h, 1, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX,
                          PIPS_DMIX, EPI_GELU, nullptr, 0, st));
             TIMED(gemm_h(h, 1, 4 * PIPS_DMIX, hw + A.h_w2[d], arena + L.b2, x, 0, PIPS_DMIX, M, PIPS_DMIX,
                          4 * PIPS_DMIX, EPI_RESIDUAL, x, PIPS_DMIX, st));

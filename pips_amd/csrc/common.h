@@ -231,7 +231,7 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
                              int S, const float* ffeats, const float* coords, const float* times, int N,
                              float* X, void* scratch, size_t scratch_bytes, hipStream_t st, hipEvent_t* ev = nullptr);
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
-                     hipStream_t st);
+                     hipStream_t st, int xn_bf16 = 0);
 int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,
                    hipStream_t st);
 int launch_score_upsum(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int F, float* U,

@@ -358,6 +358,10 @@ __device__ __forceinline__ void ln_stats2(const f2 (&x)[S], float (&mean)[S], fl
     for (int t = 0; t < S; ++t) rstd[t] = 1.0f / sqrtf(a[t] * (1.0f / PIPS_DMIX) + 1e-5f);
 }
 
+// XN_BF16: the LayerNorm-2 output only feeds the up-projection; in the bf16-operand mode that GEMM rounds it to bf16
+// while staging it, so it is stored as bf16 here (same hardware round-to-nearest-even: identical operands, half the
+// bytes the 16 column tiles of the GEMM re-read)
+template <bool XN_BF16>
 __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict__ arena, MixLayerW L,
                                                         float* __restrict__ x, float* __restrict__ xn) {
     __shared__ __attribute__((aligned(16))) float red[S][4];
@@ -402,13 +406,23 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < S; ++t) {
         *reinterpret_cast<f2*>(xp + t * PIPS_DMIX) = y[t];
-        *reinterpret_cast<f2*>(xnp + t * PIPS_DMIX) = (y[t] - mean[t]) * rstd[t] * g2 + be2;
+        const f2 o = (y[t] - mean[t]) * rstd[t] * g2 + be2;
+        if (XN_BF16) {
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t ob = __builtin_convertvector(o, bf16x2_t);
+            reinterpret_cast<unsigned*>(xn)[((size_t)blockIdx.x * S + t) * (PIPS_DMIX / 2) + tid] = *reinterpret_cast<const unsigned*>(&ob);
+        } else {
+            *reinterpret_cast<f2*>(xnp + t * PIPS_DMIX) = o;
+        }
     }
 }
 
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
-                     hipStream_t st) {
-    hipLaunchKernelGGL(token_mix_kernel, dim3(particles), dim3(256), 0, st, arena, L, x, xn);
+                     hipStream_t st, int xn_bf16) {
+    if (xn_bf16)
+        hipLaunchKernelGGL(token_mix_kernel<true>, dim3(particles), dim3(256), 0, st, arena, L, x, xn);
+    else
+        hipLaunchKernelGGL(token_mix_kernel<false>, dim3(particles), dim3(256), 0, st, arena, L, x, xn);
     PIPS_CHECK_LAUNCH("token_mix_kernel");
     return PIPS_OK;
 }
