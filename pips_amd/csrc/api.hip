@@ -303,6 +303,10 @@ EncPlan plan_encoder(int F, int H, int W, int stride) {
         size_t t = (size_t)F * (cdiv(P.Hs[l] * P.Ws[l], 64)) * ch[l] * 2;
         pmax = pmax > t ? pmax : t;
     }
+    {
+        const size_t ts = (size_t)F * stem_tiles_m(P.Hs[0], P.Ws[0]) * 64 * 4;        // the stem's partials are float4
+        pmax = pmax > ts ? pmax : ts;
+    }
     size_t t2 = (size_t)F * cdiv(P.Hs[4] * P.Ws[4], 64) * 256 * 2;
     pmax = pmax > t2 ? pmax : t2;
     P.partial = b.take(pmax); P.partial2 = b.take(pmax);
@@ -441,7 +445,7 @@ static int encoder_impl(const void* arena_v, const void* rgbs, int F, int H, int
     int tiles = 0;
     RUN(launch_stem(rgbs, (mode & 2) ? 1 : 0, arena + A.conv[0].w, arena + A.conv[0].b, ws + P.raw, ws + P.partial, F, H, W, P.Hs[0],
                     P.Ws[0], &tiles, st));
-    RUN(launch_inorm_finalize(ws + P.partial, F, tiles, 64, P.Hs[0] * P.Ws[0], ws + P.st_a, st));
+    RUN(launch_inorm_finalize_pivot(ws + P.partial, F, tiles, ws + P.st_a, st));
     RUN(launch_inorm_apply(ws + P.raw, ws + P.st_a, nullptr, nullptr, ws + P.xa, F, P.Hs[0] * P.Ws[0], 64, st));
 
     // layer1..4 (:265-268)

@@ -199,7 +199,8 @@ inline int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1
 
 int launch_stem(const void* rgbs, int rgb_u8, const float* w, const float* bias, float* out, float* stats,
                 int F, int H, int W, int Ho, int Wo, int* tiles_m, hipStream_t st);
-int stem_tiles_m(int rows_per_frame);
+int stem_tiles_m(int Ho, int Wo);
+int launch_inorm_finalize_pivot(const float* partial, int F, int tiles, float* mean_rstd, hipStream_t st);   // the stem's
 int launch_inorm_finalize(const float* partial, int F, int tiles, int C, int count, float* mean_rstd,
                           hipStream_t st);
 // y = relu((x-m)*r)                               (res == null)

@@ -8,100 +8,145 @@
 namespace pips {
 
 // ------------------------------------------------------------------------------ stem
-// conv1 7x7 stride 2 pad 3, 3 -> 64 (nets/pips.py:206,251) reading the caller's NCHW
-// 0..255 frames with the 2*(x/255)-1 scaling of :436 applied on load (zero padding is in
-// the scaled domain).  A block = 64 output pixels x 64 channels: each of the 4 waves owns
-// 16 output channels (weights are wave-uniform -> scalar loads, [147][64] layout) and
-// every lane one pixel.  Also emits per-(frame, tile, channel) {sum, sumsq} partials.
-constexpr int STEM_TILE = 64;
+// conv1 7x7 stride 2 pad 3, 3 -> 64 (nets/pips.py:206,251) reading the caller's NCHW 0..255 frames with the
+// 2*(x/255)-1 scaling of :436 applied on load (zero padding is in the scaled domain), on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulation).  K = (ci, kh, kw) with kw padded 7 -> 8 (zero
+// weights): an MFMA step takes the tap pair (kw = 2j, 2j+1), so a lane's two K values are NEIGHBOURING input
+// pixels and every LDS address of the loop is lane base + immediate.  A block (4 waves) = 4 output rows x 64
+// output columns x 64 channels; wave w owns row w: two 32-pixel M tiles x two 32-channel N tiles.  LDS: the scaled
+// input tile [3][13][136] fp32 (stride-2 reads: even banks for the first tap of a pair, odd for the second) and the
+// weights [84 steps][64 ch][2 taps] (pair-interleaved: conflict-free for both lane halves), 64 KiB: two persistent
+// blocks per CU, each stages the weights once and walks tiles.  Also emits per-(frame, tile, wave, channel)
+// statistics partials about a pivot (see the epilogue).  (The VALU form this replaces ran at 31 TFLOP/s.)
+constexpr int STEM_ROWS = 4, STEM_COLS = 64;
+constexpr int STEM_TH = 2 * STEM_ROWS + 5, STEM_TW = 136;          // input tile: 13 x (2*64 + 5 -> 136) per channel
+constexpr int STEM_STEPS = 3 * 7 * 4;                              // (ci, kh, kw pair)
+constexpr int STEM_LDS = (3 * STEM_TH * STEM_TW + STEM_STEPS * 64 * 2) * 4;
 
 // RGB = float (0..255 values, what the reference's callers pass after .float()) or unsigned char
 // (the decoded frames themselves: a quarter of the bytes, bit-identical results).
 template <typename RGB>
-__global__ __launch_bounds__(256) void stem_conv_kernel(const RGB* __restrict__ rgbs,
-                                                        const float* __restrict__ w,
-                                                        const float* __restrict__ bias,
-                                                        float* __restrict__ out,
-                                                        float* __restrict__ stats, int H, int W,
-                                                        int Ho, int Wo) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int frame = blockIdx.z;
-    const int M = Ho * Wo;
-    const int m = blockIdx.x * STEM_TILE + lane;
-    const bool ok = m < M;
-    const int ho = ok ? m / Wo : 0, wo = ok ? m - (m / Wo) * Wo : 0;
-    const int hi0 = ho * 2 - 3, wi0 = wo * 2 - 3;
+__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const RGB* __restrict__ rgbs,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           float* __restrict__ out,
+                                                           float* __restrict__ stats, int H, int W,
+                                                           int Ho, int Wo, int tiles_x, int tiles, int F) {
+    extern __shared__ __attribute__((aligned(16))) float stem_sm[];
+    float* tile = stem_sm;                                  // [3][STEM_TH][STEM_TW]
+    float* wl = stem_sm + 3 * STEM_TH * STEM_TW;            // [STEM_STEPS][64][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    // ---- the weights once per (persistent) block
+    for (int i = tid; i < STEM_STEPS * 64 * 2; i += 256) {
+        const int h = i & 1, n = (i >> 1) & 63, s = i >> 7;          // step s = (ci*7 + kh)*4 + j
+        const int j = s & 3, ck = s >> 2, kw = 2 * j + h;
+        wl[i] = kw < 7 ? w[(ck * 7 + kw) * 64 + n] : 0.f;
+    }
+  for (int work = blockIdx.x; work < tiles * F; work += gridDim.x) {
+    const int frame = work / tiles, tile_id = work - frame * tiles;
+    const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
+    const int row0 = ty * STEM_ROWS, col0 = tx * STEM_COLS;
+    // ---- stage the scaled input tile
     const RGB* src = rgbs + (size_t)frame * 3 * H * W;
-    const float* wv = w + wave * 16;
-
-    float acc[16];
+    const int hi0 = 2 * row0 - 3, wi0 = 2 * col0 - 3;
+    for (int r = wave; r < 3 * STEM_TH; r += 4) {                     // one (channel, row) of the tile per wave and step
+        const int c = r / STEM_TH, y = r - c * STEM_TH;
+        const int hi = hi0 + y;
+        const bool hok = (unsigned)hi < (unsigned)H;
+        const RGB* row = src + ((size_t)c * H + (hok ? hi : 0)) * W;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-
-    for (int ci = 0; ci < 3; ++ci) {
-        for (int kh = 0; kh < 7; ++kh) {
-            const int hi = hi0 + kh;
-            const bool hok = ok && (unsigned)hi < (unsigned)H;
-            const RGB* row = src + ((size_t)ci * H + (hok ? hi : 0)) * W;
-            // unconditional (clamped) loads of the 7 taps first, select the zero padding after:
-            // a branch per tap would serialise the loads behind their own FMAs
-            float xr[7];
+        for (int x = lane; x < STEM_TW; x += 64) {
+            const int wi = wi0 + x;
+            const bool in = hok && (unsigned)wi < (unsigned)W;
+            const float v = (float)row[in ? wi : 0];
+            tile[r * STEM_TW + x] = in ? 2.0f * (v / 255.0f) - 1.0f : 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- 84 steps x (2 x 2) MFMAs per wave
+    f32x16 acc[2][2];
 #pragma unroll
-            for (int kw = 0; kw < 7; ++kw) xr[kw] = (float)row[min(max(wi0 + kw, 0), W - 1)];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int kw = 0; kw < 7; ++kw) {
-                const int wi = wi0 + kw;
-                const float x = (hok && (unsigned)wi < (unsigned)W) ? 2.0f * (xr[kw] / 255.0f) - 1.0f : 0.f;
-                const float* wk = wv + ((ci * 7 + kh) * 7 + kw) * 64;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int c = 0; c < 16; ++c) acc[c] = fmaf(x, wk[c], acc[c]);
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* a_base = tile + (2 * wave) * STEM_TW + 2 * l31 + half;        // + mt*64 + ((ci*TH + kh)*TW + 2j)
+    const float* b_base = wl + l31 * 2 + half;                                  // + s*128 + nt*64
+#pragma unroll 1
+    for (int ck = 0; ck < 21; ++ck) {
+        const int ci = ck / 7, kh = ck - ci * 7;
+        const float* ap = a_base + (ci * STEM_TH + kh) * STEM_TW;
+        const float* bp = b_base + ck * 4 * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a0 = ap[2 * j], a1 = ap[2 * j + 64];
+            const float b0 = bp[j * 128], b1 = bp[j * 128 + 64];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col (channel) = lane&31, row (pixel) = (r&3) + 8*(r>>2) + 4*(lane>>5):
+    //      a lane holds ONE channel of 16 pixels per tile, so the column sums of the statistics stay in-lane and a
+    //      store instruction writes two 128-byte runs (32 channels of two pixels)
+    const int orow = row0 + wave;
+    const bool row_ok = orow < Ho;
+    // Statistics about a PIVOT (the wave's first pixel, per channel): on flat frames a channel is the same number at
+    // every pixel and E[x^2] - mean^2 of the raw values would be all cancellation; sums of (x - pivot) are exact zeros
+    // there.  Partial = {sum(x-p), sum((x-p)^2), p, count}, combined Chan-style in inorm_finalize_pivot_kernel.
+    const int nvalid = row_ok ? min(STEM_COLS, Wo - col0) : 0;            // the wave's valid pixels (col0 < Wo always)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 32 + l31;
+        const float bv = bias[n];
+        const float pivot = __shfl(acc[0][nt][0] + bv, l31);              // pixel 0 of the row segment: lanes of half 0, r = 0
+        float cs = 0.f, cq = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = col0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v = acc[mt][nt][r] + bv;
+                if (row_ok && col < Wo) {
+                    out[(((size_t)frame * Ho + orow) * Wo + col) * 64 + n] = v;
+                    const float d = v - pivot;
+                    cs += d;
+                    cq += d * d;
+                }
             }
-        }
+        cs += __shfl_xor(cs, 32);
+        cq += __shfl_xor(cq, 32);
+        if (half == 0)
+            reinterpret_cast<float4*>(stats)[(((size_t)frame * tiles + tile_id) * 4 + wave) * 64 + n] =
+                make_float4(cs, cq, pivot, (float)nvalid);
     }
-    float s[16], q[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        acc[c] += bias[wave * 16 + c];
-        s[c] = ok ? acc[c] : 0.f;
-        q[c] = ok ? acc[c] * acc[c] : 0.f;
-    }
-    if (ok) {
-        float4* dst = reinterpret_cast<float4*>(out + ((size_t)frame * M + m) * 64 + wave * 16);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dst[c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            s[c] += __shfl_xor(s[c], off);
-            q[c] += __shfl_xor(q[c], off);
-        }
-    }
-    if (lane < 16) {
-        float sv = 0.f, qv = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (lane == c) { sv = s[c]; qv = q[c]; }
-        float* dst = stats + (((size_t)frame * gridDim.x + blockIdx.x) * 64 + wave * 16 + lane) * 2;
-        dst[0] = sv;
-        dst[1] = qv;
-    }
+    __syncthreads();                                      // before the next tile is staged over this one
+  }
 }
 
-int stem_tiles_m(int rows_per_frame) { return cdiv(rows_per_frame, STEM_TILE); }
+int stem_tiles_m(int Ho, int Wo) { return cdiv(Ho, STEM_ROWS) * cdiv(Wo, STEM_COLS) * 4; }   // partials per frame
 
 int launch_stem(const void* rgbs, int rgb_u8, const float* w, const float* bias, float* out, float* stats,
                 int F, int H, int W, int Ho, int Wo, int* tiles_m, hipStream_t st) {
-    const int tiles = stem_tiles_m(Ho * Wo);
-    if (tiles_m) *tiles_m = tiles;
-    if (rgb_u8)
-        hipLaunchKernelGGL(stem_conv_kernel<unsigned char>, dim3(tiles, 1, F), dim3(256), 0, st,
-                           (const unsigned char*)rgbs, w, bias, out, stats, H, W, Ho, Wo);
-    else
-        hipLaunchKernelGGL(stem_conv_kernel<float>, dim3(tiles, 1, F), dim3(256), 0, st, (const float*)rgbs, w, bias,
-                           out, stats, H, W, Ho, Wo);
+    const int tiles_x = cdiv(Wo, STEM_COLS), tiles = cdiv(Ho, STEM_ROWS) * tiles_x;
+    if (tiles_m) *tiles_m = stem_tiles_m(Ho, Wo);
+    // persistent blocks (two per CU: 64 KiB of LDS each), each stages the weights once and walks tiles
+    const int grid = tiles * F < 512 ? tiles * F : 512;
+    static std::atomic<unsigned long long> raised_f{0}, raised_u{0};
+    if (rgb_u8) {
+        const int rc = ensure_dynamic_lds(raised_u, (const void*)stem_conv_kernel<unsigned char>, STEM_LDS);
+        if (rc != PIPS_OK) return rc;
+        hipLaunchKernelGGL(stem_conv_kernel<unsigned char>, dim3(grid), dim3(256), STEM_LDS, st,
+                           (const unsigned char*)rgbs, w, bias, out, stats, H, W, Ho, Wo, tiles_x, tiles, F);
+    } else {
+        const int rc = ensure_dynamic_lds(raised_f, (const void*)stem_conv_kernel<float>, STEM_LDS);
+        if (rc != PIPS_OK) return rc;
+        hipLaunchKernelGGL(stem_conv_kernel<float>, dim3(grid), dim3(256), STEM_LDS, st, (const float*)rgbs, w, bias,
+                           out, stats, H, W, Ho, Wo, tiles_x, tiles, F);
+    }
     PIPS_CHECK_LAUNCH("stem_conv_kernel");
     return PIPS_OK;
 }
@@ -141,6 +186,58 @@ __global__ __launch_bounds__(1024) void inorm_finalize_kernel(const float* __res
         dst[0] = (float)mean;
         dst[1] = (float)(1.0 / sqrt(var + 1e-5));
     }
+}
+
+// The stem's partials {sum(x-p), sum((x-p)^2), p, n} -> {mean, rstd} in fp64: mean = sum(n_t p_t + s_t) / N, then
+// M2 = sum [ q_t - s_t^2 / n_t + n_t (mean_t - mean)^2 ] with mean_t = p_t + s_t / n_t (the pairwise update of Chan et
+// al., summed).  Block = (frame, 16 channels) x 64 partial subsets.
+__global__ __launch_bounds__(1024) void inorm_finalize_pivot_kernel(const float4* __restrict__ partial, int tiles, int C,
+                                                                    float* __restrict__ mean_rstd) {
+    __shared__ double red[2][64][16];
+    __shared__ double mean_s[16], n_s[16];
+    const int f = blockIdx.x, cl = threadIdx.x & 15, c = blockIdx.y * 16 + cl, sub = threadIdx.x >> 4;
+    const float4* p = partial + (size_t)f * tiles * C + c;
+    double n = 0.0, sx = 0.0;
+    for (int t = sub; t < tiles; t += 64) {
+        const float4 v = p[(size_t)t * C];
+        n += (double)v.w;
+        sx += (double)v.w * (double)v.z + (double)v.x;
+    }
+    red[0][sub][cl] = n; red[1][sub][cl] = sx;
+    __syncthreads();
+    if (sub == 0) {
+        n = 0.0; sx = 0.0;
+        for (int i = 0; i < 64; ++i) { n += red[0][i][cl]; sx += red[1][i][cl]; }
+        n_s[cl] = n; mean_s[cl] = n > 0.0 ? sx / n : 0.0;
+    }
+    __syncthreads();
+    const double mean = mean_s[cl];
+    double m2 = 0.0;
+    for (int t = sub; t < tiles; t += 64) {
+        const float4 v = p[(size_t)t * C];
+        if (v.w > 0.f) {
+            const double nt = v.w, st = v.x, mt = (double)v.z + st / nt;
+            m2 += (double)v.y - st * st / nt + nt * (mt - mean) * (mt - mean);
+        }
+    }
+    __syncthreads();
+    red[0][sub][cl] = m2;
+    __syncthreads();
+    if (sub == 0) {
+        m2 = 0.0;
+        for (int i = 0; i < 64; ++i) m2 += red[0][i][cl];
+        double var = n_s[cl] > 0.0 ? m2 / n_s[cl] : 0.0;     // biased variance (InstanceNorm2d)
+        if (var < 0.0) var = 0.0;
+        mean_rstd[((size_t)f * C + c) * 2 + 0] = (float)mean;
+        mean_rstd[((size_t)f * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+int launch_inorm_finalize_pivot(const float* partial, int F, int tiles, float* mean_rstd, hipStream_t st) {
+    hipLaunchKernelGGL(inorm_finalize_pivot_kernel, dim3(F, 4), dim3(1024), 0, st, reinterpret_cast<const float4*>(partial), tiles,
+                       64, mean_rstd);
+    PIPS_CHECK_LAUNCH("inorm_finalize_pivot_kernel");
+    return PIPS_OK;
 }
 
 int launch_inorm_finalize(const float* partial, int F, int tiles, int C, int count, float* mean_rstd,
