@@ -229,7 +229,8 @@ def gemm(A, W, bias=None, epi=0, R=None):
 
 
 def split_bf16x3(w):
-    """fp32 tensor -> its three bf16 planes, int16 tensor of shape (3, *w.shape) (exact truncation split)."""
+    """fp32 tensor -> its three bf16 planes, int16 tensor of shape (3, *w.shape) (exact split: each plane is the round-to-nearest-even bf16 of the
+    remainder, so the three sum to w and the dropped cross terms are zero-mean; gemm_x3.hip)."""
     lib = _lib.load()
     w = _f32(w)
     out = torch.empty((3,) + tuple(w.shape), dtype=torch.int16, device=w.device)

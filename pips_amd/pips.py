@@ -83,6 +83,7 @@ class Pips(nn.Module):
         self.matmul = os.environ.get("PIPS_MATMUL", "exact")      # process-wide default, e.g. for unmodified callers
         self._names = list(param_table(S).keys())
         self._plist = None
+        self._warned_precedence = False
         self._arena = None
         self._arena_key = None
         self._ws = {}
@@ -115,6 +116,12 @@ class Pips(nn.Module):
             raise ValueError(f"Pips.matmul must be 'exact' or 'split', not {self.matmul!r}")
         bf = (2 if ac or self.mixer_dtype == torch.bfloat16 else 0) | \
              (4 if ac or self.encoder_dtype == torch.bfloat16 else 0)     # PIPS_FLAG_BF16_MIXER | _ENCODER
+        if bf and self.matmul == "split" and not self._warned_precedence:
+            # a bf16 request (autocast or mixer_dtype / encoder_dtype) wins over matmul="split": say so once
+            import warnings
+            warnings.warn("pips_amd.Pips: bf16 operands requested (autocast or *_dtype = bfloat16): matmul='split' is "
+                          "ignored for those stages", stacklevel=3)
+            self._warned_precedence = True
         return bf if bf or self.matmul == "exact" else 16                 # PIPS_FLAG_SPLIT_BF16
 
     def _workspace(self, lib, dims, device):
