@@ -70,6 +70,7 @@ static ArenaLayout build_layout() {
     A.h_head = take_h((size_t)PIPS_NOUT * PIPS_DMIX);
     A.h_conv[0] = 0;                                   // the 7x7 stem stays fp32 (VALU kernel)
     for (int i = 1; i < 22; ++i) A.h_conv[i] = take_h((size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
+    A.h_in = take_h((size_t)PIPS_DMIX * PIPS_KIN_PAD);
     A.total_h = hoff;
     size_t toff = 0;
     auto take_t = [&](size_t n) { size_t o = toff; toff += (3 * n + 127) / 128 * 128; return o; };
@@ -190,6 +191,7 @@ int pips_repack_weights(const void* const* params, int nparams, void* arena_v, v
         to_h(A.mix[d].w2, A.h_w2[d], (size_t)4 * PIPS_DMIX * PIPS_DMIX);
     }
     to_h(A.w_head, A.h_head, (size_t)PIPS_NOUT * PIPS_DMIX);
+    to_h(A.w_in, A.h_in, (size_t)PIPS_DMIX * PIPS_KIN_PAD);
     for (int i = 1; i < 22; ++i)
         to_h(A.conv[i].w, A.h_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
     // split-bf16 planes of the same weights (fp32-grade matrix path on the bf16 cores)
@@ -574,9 +576,9 @@ static int gemm_h(const float* A, int a_bf16, int lda, const unsigned short* W, 
     return launch_gemm_bf16(g, a_bf16, out_bf16, st);
 }
 
-// bf16 != 0: bf16 MFMA operands for the channel-mix and head GEMMs (weights pre-converted, the
-// 2048-wide hidden activation stored as bf16, everything else fp32); the 544-wide input
-// projection stays on the fp32 path (K is not a multiple of 64).
+// bf16 == 1: bf16 MFMA operands for every Linear of the mixer (weights pre-converted; the LayerNorm-2 output and the
+// 2048-wide hidden activation stored as bf16, everything else fp32); the 544-wide input projection rides
+// 32-element K blocks (544 = 17 x 32).
 static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                       size_t workspace_bytes, void* stream, hipEvent_t* ev, int bf16 = 0) {
     PIPS_CHECK_ARG(arena_v && X && delta && workspace, "mixer: null pointer");
@@ -621,8 +623,14 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
                               PIPS_DMIX, EPI_BIAS, nullptr, 0, stream));
         return PIPS_OK;
     }
-    TIMED(pips_gemm_f32(X, PIPS_KIN_PAD, arena + A.w_in, arena + A.b_in, x, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
-                        EPI_BIAS, nullptr, 0, stream));
+    if (bf16) {
+        const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
+        TIMED(gemm_h(X, 0, PIPS_KIN_PAD, hw + A.h_in, arena + A.b_in, x, 0, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
+                     EPI_BIAS, nullptr, 0, st));
+    } else {
+        TIMED(pips_gemm_f32(X, PIPS_KIN_PAD, arena + A.w_in, arena + A.b_in, x, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
+                            EPI_BIAS, nullptr, 0, stream));
+    }
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
         RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1));

@@ -187,7 +187,7 @@ struct ArenaLayout {
     size_t total;            // floats (fp32 section)
     // bf16 copies of the big Linear weights for the bf16-operand mixer, in ushort units from
     // the end of the fp32 section (arena + total)
-    size_t h_w1[PIPS_DEPTH], h_w2[PIPS_DEPTH], h_head, h_conv[22], total_h;
+    size_t h_w1[PIPS_DEPTH], h_w2[PIPS_DEPTH], h_head, h_conv[22], h_in, total_h;
     // split-bf16 planes [3][N][K] of every matrix-core weight (gemm_x3.hip), in ushort units from
     // the end of the bf16 section
     size_t t_in, t_w1[PIPS_DEPTH], t_w2[PIPS_DEPTH], t_head, t_conv[22], total_t;

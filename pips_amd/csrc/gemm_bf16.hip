@@ -316,12 +316,12 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool A_BF16, bool OUT_BF16>
+template <int BM, int BN, int WGM, int WGN, int KS, bool A_BF16, bool OUT_BF16, int BKE = 64>
 static int launch_bf16_tile(const GemmArgs& a, hipStream_t st) {
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), 1);
     dim3 block(WGM * WGN * KS * 64);
-    const size_t lds = (size_t)2 * (BM + BN) * (64 * KS * 2 + 16);
-    auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, KS, A_BF16, OUT_BF16>;
+    const size_t lds = (size_t)2 * (BM + BN) * (BKE * KS * 2 + 16);
+    auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, KS, A_BF16, OUT_BF16, BKE>;
     if (lds > 64 * 1024) {
         static std::atomic<unsigned long long> raised{0};      // per instantiation, one bit per device
         const int rc = ensure_dynamic_lds(raised, (const void*)kern, lds);
@@ -336,8 +336,20 @@ template <bool A_BF16, bool OUT_BF16>
 static int pick_tile(const GemmArgs& a, hipStream_t st) {
     const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const long b64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
-    static int big = -1;                        // tuning hook: PIPS_BF16_BIG=0 disables the 256x128 tile
-    if (big < 0) { const char* e = getenv("PIPS_BF16_BIG"); big = e ? atoi(e) : 1; }
+    if (a.K % 64 != 0) {                        // K % 32 == 0: the 544-wide input projection, 32-element K blocks
+        if constexpr (!A_BF16 && !OUT_BF16) {
+            if (b128 >= 400) return launch_bf16_tile<128, 128, 2, 2, 1, false, false, 32>(a, st);
+            return launch_bf16_tile<64, 64, 2, 2, 1, false, false, 32>(a, st);
+        } else {
+            set_error("gemm_bf16: K=%d needs fp32 A and fp32 C (32-element K blocks)", a.K);
+            return PIPS_E_ARG;
+        }
+    }
+    // tuning hook PIPS_BF16_BIG: 0 = no tile above 128x128, 1 = 256x128 only, 2 (default) = 256x256 where it still
+    // gives every CU a tile (config 3 up-projection: 60.7 vs 67.7 us), 256x128 below that
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("PIPS_BF16_BIG"); big = e ? atoi(e) : 2; }
+    if (big >= 2 && (long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 256) return launch_bf16_tile<256, 256, 4, 2, 1, A_BF16, OUT_BF16>(a, st);
     if (big && (long)cdiv(a.M, 256) * cdiv(a.N, 128) >= 256) return launch_bf16_tile<256, 128, 4, 2, 1, A_BF16, OUT_BF16>(a, st);
     if (b128 >= 400) return launch_bf16_tile<128, 128, 2, 2, 1, A_BF16, OUT_BF16>(a, st);
     if (b64 >= 800 || a.K % 128 != 0) return launch_bf16_tile<64, 64, 2, 2, 1, A_BF16, OUT_BF16>(a, st);
@@ -375,7 +387,7 @@ int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st
 // A: fp32 [M][lda] (a_bf16 = 0) or bf16 [M][lda]; W: bf16 [N][K]; C: fp32 or bf16 [M][ldc]
 int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st) {
     PIPS_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm_bf16: empty problem");
-    PIPS_CHECK_ARG(a.K % 64 == 0, "gemm_bf16: K=%d must be a multiple of 64", a.K);
+    PIPS_CHECK_ARG(a.K % 32 == 0, "gemm_bf16: K=%d must be a multiple of 32", a.K);
     PIPS_CHECK_ARG(a.N % 4 == 0 && a.ldc % 4 == 0 && a.lda % 8 == 0, "gemm_bf16: N, ldc %% 4 and lda %% 8 required");
     PIPS_CHECK_ARG((unsigned long long)a.M * (unsigned long long)a.lda < (1ull << 32) &&
                        (unsigned long long)a.N * (unsigned long long)a.K < (1ull << 32),
