@@ -25,48 +25,46 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------- exact-form GELU
-// nn.GELU() default = 0.5*x*(1+erf(x/sqrt(2))) (nets/pips.py:105,419).  erf is ONE branch-free
-// fp32 form fitted for this path: erf(x) = sign(x) * (1 - exp(-t*Q8(t))), t = min(|x|, 4)
-// (erf(4) rounds to 1.0f), Q8 a weighted minimax fit of -ln(erfc(t))/t on [0, 4].  Max abs error
-// 1.15e-7 (~2 ulp at 1.0; checked over 12 M points against double erf), below the 4.5e-7 the fp32
-// GELU formula itself carries.  Its relative error near 0 is irrelevant to GELU: the result is
-// added to 1.0f.  11 instructions per value (8 FMAs + one v_exp), against ~40 for OCML's erff --
-// it runs on 64 values per lane in the GEMM epilogues and 64 per thread in the token-mix kernel.
-#define PIPS_ERF_Q8(q, t, C)                                              \
-    q = C(-5.031980891e-06f);                                             \
-    q = q * t + C(7.671763160e-05f);                                      \
-    q = q * t + C(-4.737728159e-04f);                                     \
-    q = q * t + C(1.346567064e-03f);                                      \
-    q = q * t + C(2.001843532e-04f);                                      \
-    q = q * t + C(-1.938028634e-02f);                                     \
-    q = q * t + C(1.028537750e-01f);                                      \
-    q = q * t + C(6.366076469e-01f);                                      \
-    q = q * t + C(1.128379703e+00f);
-__device__ __forceinline__ float fast_erf(float x) {
-    const float t = fminf(fabsf(x), 4.0f);
+// nn.GELU() default = 0.5*x*(1+erf(x/sqrt(2))) (nets/pips.py:105,419), evaluated branch-free as
+//     gelu(x) = max(x, 0) - 0.5 * t * erfc(t / sqrt(2)),   t = min(|x|, 4*sqrt(2)),
+//     erfc(t / sqrt(2)) = exp2(t * A8(t))
+// (erf(x) = sign(x)(1 - erfc(|x|)), so 0.5 x (1 + erf) = x - 0.5 x erfc for x > 0 and 0.5 x erfc(|.|) for x < 0; beyond
+// the clamp erfc < 1.6e-8).  A8 = -log2(e)/sqrt(2) * Q8(t/sqrt(2)) with Q8 a weighted minimax fit of -ln(erfc(u))/u
+// on [0, 4].  Max abs error of the GELU 4.8e-7 over [-8, 8] (numpy fp32 emulation against double, 6 M points),
+// as much as the fp32 rounding of the textbook formula itself carries.  Per PAIR of values: 2 min, 2 max, 9 packed
+// FMA/mul for the polynomial, 2 v_exp, 2 packed ops for the result -- it runs on 64 values per lane in the GEMM
+// epilogues and 64 per thread in the token-mix kernel.
+#define PIPS_GELU_TMAX 5.65685425f
+#define PIPS_GELU_A8(q, t, C)                                             \
+    q = C(3.208326405e-07f);                                              \
+    q = q * t + C(-6.917509381e-06f);                                     \
+    q = q * t + C(6.041429151e-05f);                                      \
+    q = q * t + C(-2.428356966e-04f);                                     \
+    q = q * t + C(-5.105399032e-05f);                                     \
+    q = q * t + C(6.989960559e-03f);                                      \
+    q = q * t + C(-5.246259645e-02f);                                     \
+    q = q * t + C(-4.592153430e-01f);                                     \
+    q = q * t + C(-1.151104689e+00f);
+__device__ __forceinline__ float gelu_exact(float x) {
+    const float t = fminf(fabsf(x), PIPS_GELU_TMAX);
     float q;
 #define PIPS_C1(v) v
-    PIPS_ERF_Q8(q, t, PIPS_C1)
+    PIPS_GELU_A8(q, t, PIPS_C1)
 #undef PIPS_C1
-    return copysignf(1.0f - __builtin_amdgcn_exp2f((q * t) * -1.44269504088896340736f), x);
-}
-__device__ __forceinline__ float gelu_exact(float x) {
-    return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+    return fmaf(t * __builtin_amdgcn_exp2f(q * t), -0.5f, fmaxf(x, 0.0f));
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 // the same on two values at once: the polynomial runs as packed FMAs (v_pk_fma_f32)
-__device__ __forceinline__ f2 gelu_exact2(f2 v) {
-    const f2 x = v * 0.70710678118654752440f;
-    const f2 t = __builtin_elementwise_min(__builtin_elementwise_abs(x), (f2){4.0f, 4.0f});
+__device__ __forceinline__ f2 gelu_exact2(f2 x) {
+    const f2 t = __builtin_elementwise_min(__builtin_elementwise_abs(x), (f2){PIPS_GELU_TMAX, PIPS_GELU_TMAX});
     f2 q;
 #define PIPS_C2(v) ((f2){v, v})
-    PIPS_ERF_Q8(q, t, PIPS_C2)
+    PIPS_GELU_A8(q, t, PIPS_C2)
 #undef PIPS_C2
-    const f2 a = (q * t) * -1.44269504088896340736f;
-    const f2 om = 1.0f - (f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-    const f2 erf = (f2){copysignf(om.x, x.x), copysignf(om.y, x.y)};
-    return (v * 0.5f) * (erf + 1.0f);
+    const f2 a = q * t;
+    const f2 w = t * (f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    return w * -0.5f + __builtin_elementwise_max(x, (f2){0.0f, 0.0f});
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
