@@ -326,18 +326,27 @@ __device__ __forceinline__ float wave_sum8(const float (&v)[S]) {
     return y;
 }
 
-// sums of 8 per-token values over the 256 threads of the block; red is [S][4 waves]
-__device__ __forceinline__ void block_sum8_dpp(float (&v)[S], float (*red)[4]) {
+// sums of 8 per-token values over the 256 threads of the block; red is [S][4 waves].  Lane l returns the block total of
+// token l & 7 (one 16-byte LDS read per lane instead of eight; the callers finish the statistic in that lane and hand
+// it to the wave with v_readlane, which also leaves means and scales in scalar registers)
+__device__ __forceinline__ float block_sum8_dpp(const float (&v)[S], float (*red)[4]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float w = wave_sum8(v);
     __syncthreads();                                   // previous readers of red are done
     if (lane < S) red[lane][wave] = w;
     __syncthreads();
-#pragma unroll
-    for (int t = 0; t < S; ++t) {
-        const float4 r = *reinterpret_cast<const float4*>(red[t]);
-        v[t] = (r.x + r.y) + (r.z + r.w);
-    }
+    const float4 r = *reinterpret_cast<const float4*>(red[lane & 7]);
+    return (r.x + r.y) + (r.z + r.w);
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// 1/sqrt(v) for v >= eps: v_rsq_f32 (1 ulp) + one Newton step -- 5 instructions where the IEEE 1.0f / sqrtf(v) of the
+// compiler is ~30 (denormal scaling, div_scale / div_fmas / div_fixup); every thread needs it 16 times per launch
+__device__ __forceinline__ float rsqrt_nr(float v) {
+    const float r = __builtin_amdgcn_rsqf(v);
+    return r * fmaf(-0.5f * v * r, r, 1.5f);
 }
 
 // two-pass LayerNorm statistics (mean, then centred squares) of 8 tokens x 512 channels, 2 channels per thread
@@ -345,17 +354,17 @@ __device__ __forceinline__ void ln_stats2(const f2 (&x)[S], float (&mean)[S], fl
     float a[S];
 #pragma unroll
     for (int t = 0; t < S; ++t) a[t] = x[t].x + x[t].y;
-    block_sum8_dpp(a, red);
+    const float m = block_sum8_dpp(a, red) * (1.0f / PIPS_DMIX);
 #pragma unroll
-    for (int t = 0; t < S; ++t) mean[t] = a[t] * (1.0f / PIPS_DMIX);
+    for (int t = 0; t < S; ++t) mean[t] = lane_bcast(m, t);
 #pragma unroll
     for (int t = 0; t < S; ++t) {
-        const f2 d = x[t] - mean[t];
+        const f2 d = x[t] - (f2){mean[t], mean[t]};
         a[t] = d.x * d.x + d.y * d.y;
     }
-    block_sum8_dpp(a, red);
+    const float r = rsqrt_nr(block_sum8_dpp(a, red) * (1.0f / PIPS_DMIX) + 1e-5f);
 #pragma unroll
-    for (int t = 0; t < S; ++t) rstd[t] = 1.0f / sqrtf(a[t] * (1.0f / PIPS_DMIX) + 1e-5f);
+    for (int t = 0; t < S; ++t) rstd[t] = lane_bcast(r, t);
 }
 
 // XN_BF16: the LayerNorm-2 output only feeds the up-projection; in the bf16-operand mode that GEMM rounds it to bf16
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
     f2 h[S], y[S];
 #pragma unroll
     for (int t = 0; t < S; ++t) {
-        h[t] = (xv[t] - mean[t]) * rstd[t] * g1 + be1;
+        h[t] = (xv[t] - (f2){mean[t], mean[t]}) * (g1 * (f2){rstd[t], rstd[t]}) + be1;
         y[t] = (f2){wsm[544 + t], wsm[544 + t]};
     }
 #pragma unroll 4
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < S; ++t) {
         *reinterpret_cast<f2*>(xp + t * PIPS_DMIX) = y[t];
-        const f2 o = (y[t] - mean[t]) * rstd[t] * g2 + be2;
+        const f2 o = (y[t] - (f2){mean[t], mean[t]}) * (g2 * (f2){rstd[t], rstd[t]}) + be2;
         if (XN_BF16) {
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             const bf16x2_t ob = __builtin_convertvector(o, bf16x2_t);
