@@ -210,8 +210,9 @@ int    pips_gemm_f32(const float* A, int lda, const float* W, const float* bias,
                      float* C, int ldc, int M, int N, int K, int epi,
                      const float* R, int ldr, void* stream);
 /* NHWC convolution as implicit GEMM, weights [Cout][kh][kw][Cin], Cin % 32 == 0.
- * stats (optional) receives per-(frame, m-tile, channel) {sum, sumsq} partials of the
- * output; returns the number of m-tiles per frame through *tiles_m_host. */
+ * stats (optional) receives InstanceNorm partials of the output about a pivot, float4 {sum(x-p), sum((x-p)^2), p, n}
+ * per (frame, part, channel), part = m-tile x wave row: room for F * (2*ceil(Ho*Wo/64) + 4) * Cout * 4 floats;
+ * returns the number of parts per frame through *tiles_m_host. */
 int    pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin,
                           const float* wgt, const float* bias, int Cout, int ksize, int cstride, int pad,
                           float* out, float* stats, int* tiles_m_host, void* stream);

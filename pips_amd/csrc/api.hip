@@ -299,17 +299,17 @@ EncPlan plan_encoder(int F, int H, int W, int stride) {
     P.raw = b.take(big); P.mid = b.take(big); P.xa = b.take(big); P.xb = b.take(big); P.ds = b.take(big);
     for (int l = 0; l < 4; ++l) P.outs[l] = b.take((size_t)F * P.Hs[l] * P.Ws[l] * ch[l]);
     P.cat = b.take(tgt * 416);
-    // partial statistics: [F][tiles][C][2]; tiles <= rows/64 + 1
+    // partial statistics: float4 [F][parts][C]; parts <= 2 wave rows x (rows/64 + 1) m tiles
     size_t pmax = 0;
     for (int l = 0; l < 4; ++l) {
-        size_t t = (size_t)F * (cdiv(P.Hs[l] * P.Ws[l], 64)) * ch[l] * 2;
+        size_t t = (size_t)F * (2 * cdiv(P.Hs[l] * P.Ws[l], 64) + 4) * ch[l] * 4;
         pmax = pmax > t ? pmax : t;
     }
     {
         const size_t ts = (size_t)F * stem_tiles_m(P.Hs[0], P.Ws[0]) * 64 * 4;        // the stem's partials are float4
         pmax = pmax > ts ? pmax : ts;
     }
-    size_t t2 = (size_t)F * cdiv(P.Hs[4] * P.Ws[4], 64) * 256 * 2;
+    size_t t2 = (size_t)F * (2 * cdiv(P.Hs[4] * P.Ws[4], 64) + 4) * 256 * 4;
     pmax = pmax > t2 ? pmax : t2;
     P.partial = b.take(pmax); P.partial2 = b.take(pmax);
     P.st_a = b.take((size_t)F * 256 * 2); P.st_b = b.take((size_t)F * 256 * 2);
@@ -356,8 +356,7 @@ int conv_stats(const float* arena, const ArenaLayout& A, int ci, const float* in
     int tiles = 0;
     RUN(conv_nhwc(in, F, H, W, c.cin, conv_w(arena, A, ci, lm), arena + c.b, c.cout, c.k, c.stride, c.pad, out, partial,
                   &tiles, st, lm));
-    const int Ho = conv_out(H, c.k, c.stride, c.pad), Wo = conv_out(W, c.k, c.stride, c.pad);
-    return launch_inorm_finalize(partial, F, tiles, c.cout, Ho * Wo, mean_rstd, st);
+    return launch_inorm_finalize_pivot(partial, F, tiles, c.cout, mean_rstd, st);
 }
 
 // ResidualBlock.forward, nets/pips.py:173-181
@@ -447,7 +446,7 @@ static int encoder_impl(const void* arena_v, const void* rgbs, int F, int H, int
     int tiles = 0;
     RUN(launch_stem(rgbs, (mode & 2) ? 1 : 0, arena + A.conv[0].w, arena + A.conv[0].b, ws + P.raw, ws + P.partial, F, H, W, P.Hs[0],
                     P.Ws[0], &tiles, st));
-    RUN(launch_inorm_finalize_pivot(ws + P.partial, F, tiles, ws + P.st_a, st));
+    RUN(launch_inorm_finalize_pivot(ws + P.partial, F, tiles, 64, ws + P.st_a, st));
     RUN(launch_inorm_apply(ws + P.raw, ws + P.st_a, nullptr, nullptr, ws + P.xa, F, P.Hs[0] * P.Ws[0], 64, st));
 
     // layer1..4 (:265-268)

@@ -71,6 +71,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// InstanceNorm partials of a convolution tile, one per WAVE ROW (m tile, wm) and channel, about a PIVOT -- the value of
+// the wave's first output row in that channel: {sum(x-p), sum((x-p)^2), p, n}.  E[x^2] - mean^2 of raw fp32 sums loses
+// digits where |mean| >> std (flat or letterboxed frames, large biases); sums about a value of the data do not, and
+// the partials are combined in fp64 (inorm_finalize_pivot_kernel).  csum / csq: the lane's sums over its rows of column
+// col (lanes l and l+32 hold the same column); no LDS, no barrier, bitwise deterministic.
+__device__ __forceinline__ void store_conv_partial(float* stats, int frame, int parts, int part, int N, int col, int half,
+                                                   float csum, float csq, float pivot, int nvalid) {
+    const float s = csum + __shfl_xor(csum, 32);
+    const float q = csq + __shfl_xor(csq, 32);
+    if (half == 0 && col < N)
+        reinterpret_cast<float4*>(stats)[((size_t)frame * parts + part) * N + col] = make_float4(s, q, pivot, (float)nvalid);
+}
+
 // Dynamic-LDS limit of one kernel instantiation, raised once per (instantiation, device).  The only state
 // the launchers keep: an idempotent attribute, tracked per device, safe from several host threads.
 inline int ensure_dynamic_lds(std::atomic<unsigned long long>& done, const void* kern, size_t bytes) {
@@ -97,7 +110,7 @@ struct GemmArgs {
     const float* bias;   // [N] or null
     float* C;            // [M][ldc] (conv: output of frame 0, ldc = N)
     const float* R;      // residual [M][ldr] (EPI_RESIDUAL)
-    float* stats;        // optional partial {sum,sumsq}: [frame][tiles_m][N][2]
+    float* stats;        // optional pivoted partials {sum(x-p), sum((x-p)^2), p, n} (float4): [frame][parts][N], parts = m tiles x wave rows
     int M, N, K;
     int lda, ldc, ldr;
     int epi;
@@ -198,9 +211,7 @@ inline int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1
 int launch_stem(const void* rgbs, int rgb_u8, const float* w, const float* bias, float* out, float* stats,
                 int F, int H, int W, int Ho, int Wo, int* tiles_m, hipStream_t st);
 int stem_tiles_m(int Ho, int Wo);
-int launch_inorm_finalize_pivot(const float* partial, int F, int tiles, float* mean_rstd, hipStream_t st);   // the stem's
-int launch_inorm_finalize(const float* partial, int F, int tiles, int C, int count, float* mean_rstd,
-                          hipStream_t st);
+int launch_inorm_finalize_pivot(const float* partial, int F, int parts, int C, float* mean_rstd, hipStream_t st);
 // y = relu((x-m)*r)                               (res == null)
 // y = relu(res + relu((x-m)*r))                   (res != null, res_stats == null)
 // y = relu((res-m2)*r2 + relu((x-m)*r))           (res_stats != null)

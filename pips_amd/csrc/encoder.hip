@@ -152,99 +152,53 @@ int launch_stem(const void* rgbs, int rgb_u8, const float* w, const float* bias,
 }
 
 // ------------------------------------------------------------------ instance-norm stats
-// partial [F][tiles][C][2] fp32 -> mean_rstd [F][C][2]; accumulation in fp64.
 // InstanceNorm2d(affine=False, eps=1e-5), biased variance (nets/pips.py:153-157,199-201).
-// (a handful of blocks per launch: 32 channels x 32 tile-subsets per block keep the serial
-// part of the tile loop short)
-__global__ __launch_bounds__(1024) void inorm_finalize_kernel(const float* __restrict__ partial,
-                                                              int tiles, int C, int count,
-                                                              float* __restrict__ mean_rstd) {
-    __shared__ double red[2][32][32];
-    const int f = blockIdx.y;
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int sub = threadIdx.x >> 5;
-    double s = 0.0, q = 0.0;
-    if (c < C) {
-        const float* p = partial + ((size_t)f * tiles * C + c) * 2;
-        for (int t = sub; t < tiles; t += 32) {
-            const float2 v = *reinterpret_cast<const float2*>(p + (size_t)t * C * 2);
-            s += (double)v.x;
-            q += (double)v.y;
-        }
-    }
-    red[0][sub][threadIdx.x & 31] = s;
-    red[1][sub][threadIdx.x & 31] = q;
-    __syncthreads();
-    if (threadIdx.x < 32 && c < C) {
-        s = 0.0; q = 0.0;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) { s += red[0][i][threadIdx.x]; q += red[1][i][threadIdx.x]; }
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        float* dst = mean_rstd + ((size_t)f * C + c) * 2;
-        dst[0] = (float)mean;
-        dst[1] = (float)(1.0 / sqrt(var + 1e-5));
-    }
-}
-
-// The stem's partials {sum(x-p), sum((x-p)^2), p, n} -> {mean, rstd} in fp64: mean = sum(n_t p_t + s_t) / N, then
-// M2 = sum [ q_t - s_t^2 / n_t + n_t (mean_t - mean)^2 ] with mean_t = p_t + s_t / n_t (the pairwise update of Chan et
-// al., summed).  Block = (frame, 16 channels) x 64 partial subsets.
-__global__ __launch_bounds__(1024) void inorm_finalize_pivot_kernel(const float4* __restrict__ partial, int tiles, int C,
+// Pivoted partials {sum(x-p), sum((x-p)^2), p, n} [F][parts][C] (the stem's, and store_conv_partial's of every conv
+// kernel) -> mean_rstd [F][C][2].  All partials of a channel are re-based in fp64 on ONE reference r (the first partial's
+// pivot, a value of the data): with d = p - r,  sum(x-r) = sum_t [s_t + n_t d_t],  sum(x-r)^2 = sum_t [q_t + 2 d_t s_t +
+// n_t d_t^2];  mean = r + S1/N,  var = S2/N - (S1/N)^2 -- one pass, and what cancellation is left happens in fp64 about
+// a value within the data's range.  Block = (frame, 16 channels) x 64 partial subsets.
+__global__ __launch_bounds__(1024) void inorm_finalize_pivot_kernel(const float4* __restrict__ partial, int parts, int C,
                                                                     float* __restrict__ mean_rstd) {
-    __shared__ double red[2][64][16];
-    __shared__ double mean_s[16], n_s[16];
+    __shared__ double red[3][64][16];
     const int f = blockIdx.x, cl = threadIdx.x & 15, c = blockIdx.y * 16 + cl, sub = threadIdx.x >> 4;
-    const float4* p = partial + (size_t)f * tiles * C + c;
-    double n = 0.0, sx = 0.0;
-    for (int t = sub; t < tiles; t += 64) {
-        const float4 v = p[(size_t)t * C];
-        n += (double)v.w;
-        sx += (double)v.w * (double)v.z + (double)v.x;
-    }
-    red[0][sub][cl] = n; red[1][sub][cl] = sx;
-    __syncthreads();
-    if (sub == 0) {
-        n = 0.0; sx = 0.0;
-        for (int i = 0; i < 64; ++i) { n += red[0][i][cl]; sx += red[1][i][cl]; }
-        n_s[cl] = n; mean_s[cl] = n > 0.0 ? sx / n : 0.0;
-    }
-    __syncthreads();
-    const double mean = mean_s[cl];
-    double m2 = 0.0;
-    for (int t = sub; t < tiles; t += 64) {
-        const float4 v = p[(size_t)t * C];
-        if (v.w > 0.f) {
-            const double nt = v.w, st = v.x, mt = (double)v.z + st / nt;
-            m2 += (double)v.y - st * st / nt + nt * (mt - mean) * (mt - mean);
+    const float4* p = partial + (size_t)f * parts * C + c;
+    const double r = (double)p[0].z;
+    double n = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int t0 = sub; t0 < parts; t0 += 256) {        // four loads in flight per thread (the loop is latency-bound)
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 64 * u;
+            v[u] = t < parts ? p[(size_t)t * C] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (v[u].w > 0.f) {
+                const double nt = v[u].w, d = (double)v[u].z - r;
+                n += nt;
+                s1 += (double)v[u].x + nt * d;
+                s2 += (double)v[u].y + d * (2.0 * (double)v[u].x + nt * d);
+            }
     }
-    __syncthreads();
-    red[0][sub][cl] = m2;
+    red[0][sub][cl] = n; red[1][sub][cl] = s1; red[2][sub][cl] = s2;
     __syncthreads();
     if (sub == 0) {
-        m2 = 0.0;
-        for (int i = 0; i < 64; ++i) m2 += red[0][i][cl];
-        double var = n_s[cl] > 0.0 ? m2 / n_s[cl] : 0.0;     // biased variance (InstanceNorm2d)
+        n = 0.0; s1 = 0.0; s2 = 0.0;
+        for (int i = 0; i < 64; ++i) { n += red[0][i][cl]; s1 += red[1][i][cl]; s2 += red[2][i][cl]; }
+        const double m1 = n > 0.0 ? s1 / n : 0.0;
+        double var = n > 0.0 ? s2 / n - m1 * m1 : 0.0;
         if (var < 0.0) var = 0.0;
-        mean_rstd[((size_t)f * C + c) * 2 + 0] = (float)mean;
+        mean_rstd[((size_t)f * C + c) * 2 + 0] = (float)(r + m1);
         mean_rstd[((size_t)f * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
     }
 }
 
-int launch_inorm_finalize_pivot(const float* partial, int F, int tiles, float* mean_rstd, hipStream_t st) {
-    hipLaunchKernelGGL(inorm_finalize_pivot_kernel, dim3(F, 4), dim3(1024), 0, st, reinterpret_cast<const float4*>(partial), tiles,
-                       64, mean_rstd);
+int launch_inorm_finalize_pivot(const float* partial, int F, int parts, int C, float* mean_rstd, hipStream_t st) {
+    PIPS_CHECK_ARG(C % 16 == 0, "inorm_finalize: C=%d must be a multiple of 16", C);
+    hipLaunchKernelGGL(inorm_finalize_pivot_kernel, dim3(F, C / 16), dim3(1024), 0, st, reinterpret_cast<const float4*>(partial),
+                       parts, C, mean_rstd);
     PIPS_CHECK_LAUNCH("inorm_finalize_pivot_kernel");
-    return PIPS_OK;
-}
-
-int launch_inorm_finalize(const float* partial, int F, int tiles, int C, int count, float* mean_rstd,
-                          hipStream_t st) {
-    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(cdiv(C, 32), F), dim3(1024), 0, st, partial, tiles, C,
-                       count, mean_rstd);
-    PIPS_CHECK_LAUNCH("inorm_finalize_kernel");
     return PIPS_OK;
 }
 

@@ -291,9 +291,9 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
 
     PIPS_T(3)
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float csum[TN], csq[TN];
+    float csum[TN], csq[TN], piv[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
+    for (int j = 0; j < TN; ++j) csum[j] = csq[j] = piv[j] = 0.f;
     const int epi = p.epi & 0xff;
 
     if (!CONV) {
@@ -358,6 +358,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
         const int col = n0 + wn * WTN + j * 32 + l31;
         const bool col_ok = col < p.N;
         const float bv = p.bias != nullptr ? p.bias[col_ok ? col : p.N - 1] : 0.f;
+        piv[j] = __shfl(acc[0][j][0] + bv, l31);      // the wave's first row in this column (lanes of half 0, r = 0)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float v[16];
@@ -369,8 +370,9 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
-                    csum[j] += v[r];
-                    csq[j] += v[r] * v[r];
+                    const float d = v[r] - piv[j];
+                    csum[j] += d;
+                    csq[j] += d * d;
                 }
             } else {
 #pragma unroll
@@ -378,8 +380,9 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
                     const int row = rbase + (r & 3) + 8 * (r >> 2);
                     if (row < p.M && col_ok) {
                         cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
-                        csum[j] += v[r];
-                        csq[j] += v[r] * v[r];
+                        const float d = v[r] - piv[j];
+                        csum[j] += d;
+                        csq[j] += d * d;
                     }
                 }
             }
@@ -387,35 +390,11 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
     }
 
     if (CONV && p.stats != nullptr) {
-        // per-column partial sums of this m-tile: lanes l and l+32 hold the same column.
-        // (CONV instantiations use KS == 1, so every wave of the block reaches this point.)
-        __syncthreads();                      // every wave is done with the LDS stages
-        float* red = smem;                    // [WGM][BN][2]
+        const int left = p.M - (m0 + wm * WTM), nvalid = left < 0 ? 0 : (left > WTM ? WTM : left);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s = csum[j] + __shfl_xor(csum[j], 32);
-            float q = csq[j] + __shfl_xor(csq[j], 32);
-            if (half == 0) {
-                const int c = wn * WTN + j * 32 + l31;
-                red[(wm * BN + c) * 2 + 0] = s;
-                red[(wm * BN + c) * 2 + 1] = q;
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < BN; c += NT) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WGM; ++w) {
-                s += red[(w * BN + c) * 2 + 0];
-                q += red[(w * BN + c) * 2 + 1];
-            }
-            const int col = n0 + c;
-            if (col < p.N) {
-                float* dst = p.stats + (((size_t)frame * gridDim.x + bx) * p.N + col) * 2;
-                dst[0] = s;
-                dst[1] = q;
-            }
-        }
+        for (int j = 0; j < TN; ++j)
+            store_conv_partial(p.stats, frame, (int)gridDim.x * WGM, bx * WGM + wm, p.N, n0 + wn * WTN + j * 32 + l31, half,
+                               csum[j], csq[j], piv[j], nvalid);
     }
     PIPS_T(4)
 }
@@ -535,7 +514,8 @@ int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) {
     PIPS_CHECK_ARG(a.K == a.KH * a.KW * a.Cin, "conv: K mismatch");
     int bm, bn;
     conv_tile(a.M, a.N, frames, &bm, &bn);
-    if (tiles_m) *tiles_m = cdiv(a.M, bm);
+    // partials per frame: m tiles x wave rows (WGM = 4 for the 128x96 tile, 2 elsewhere)
+    if (tiles_m) *tiles_m = cdiv(a.M, bm) * ((bn == 96 && bm == 128) ? 4 : 2);
     if (bn == 128) {
         return bm == 128 ? launch_tile<128, 128, 2, 2, 1, true>(a, frames, st)
                          : launch_tile<64, 128, 2, 2, 1, true>(a, frames, st);

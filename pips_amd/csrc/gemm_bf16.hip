@@ -205,7 +205,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
     if (CONV) {
         // C orientation: col = lane&31, row = (r&3) + 8*(r>>2) + 4*half; fp32 output + column partials
         float* __restrict__ Cc = p.C + (size_t)frame * p.M * p.ldc;
-        float csum[TN], csq[TN];
+        float csum[TN], csq[TN], piv[TN];
         // bias added before the predicated stores, full tiles unpredicated (see gemm.hip)
         const bool full_tile = m0 + BM <= p.M && n0 + BN <= p.N;
 #pragma unroll
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
             const int col = n0 + wn * WTN + j * 32 + l31;
             const bool col_ok = col < p.N;
             const float bv = p.bias != nullptr ? p.bias[col_ok ? col : p.N - 1] : 0.f;
+            piv[j] = __shfl(acc[0][j][0] + bv, l31);  // the wave's first row in this column (lanes of half 0, r = 0)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 float v[16];
@@ -225,8 +226,9 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
-                        csum[j] += v[r];
-                        csq[j] += v[r] * v[r];
+                        const float d = v[r] - piv[j];
+                        csum[j] += d;
+                        csq[j] += d * d;
                     }
                 } else {
 #pragma unroll
@@ -234,38 +236,20 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
                         const int row = rbase + (r & 3) + 8 * (r >> 2);
                         if (row < p.M && col_ok) {
                             cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
-                            csum[j] += v[r];
-                            csq[j] += v[r] * v[r];
+                            const float d = v[r] - piv[j];
+                            csum[j] += d;
+                            csq[j] += d * d;
                         }
                     }
                 }
             }
         }
         if (p.stats != nullptr) {
-            __syncthreads();
-            float* red = reinterpret_cast<float*>(smem);        // [WGM][BN][2]
+            const int left = p.M - (m0 + wm * WTM), nvalid = left < 0 ? 0 : (left > WTM ? WTM : left);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float s_ = csum[j] + __shfl_xor(csum[j], 32);
-                const float q_ = csq[j] + __shfl_xor(csq[j], 32);
-                if (half == 0) {
-                    const int c = wn * WTN + j * 32 + l31;
-                    red[(wm * BN + c) * 2 + 0] = s_;
-                    red[(wm * BN + c) * 2 + 1] = q_;
-                }
-            }
-            __syncthreads();
-            for (int c = tid; c < BN; c += NT) {
-                float s_ = 0.f, q_ = 0.f;
-#pragma unroll
-                for (int w = 0; w < WGM; ++w) { s_ += red[(w * BN + c) * 2 + 0]; q_ += red[(w * BN + c) * 2 + 1]; }
-                const int col = n0 + c;
-                if (col < p.N) {
-                    float* dst = p.stats + (((size_t)frame * gridDim.x + blockIdx.x) * p.N + col) * 2;
-                    dst[0] = s_;
-                    dst[1] = q_;
-                }
-            }
+            for (int j = 0; j < TN; ++j)
+                store_conv_partial(p.stats, frame, (int)gridDim.x * WGM, (int)blockIdx.x * WGM + wm, p.N, n0 + wn * WTN + j * 32 + l31,
+                                   half, csum[j], csq[j], piv[j], nvalid);
         }
         return;
     }
@@ -375,7 +359,7 @@ int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st
     const int bn = a.N <= 64 ? 64 : 128;
     const long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.N, bn) * frames;
     const int bm = blocks128 >= 512 ? 128 : 64;
-    if (tiles_m) *tiles_m = cdiv(a.M, bm);
+    if (tiles_m) *tiles_m = cdiv(a.M, bm) * 2;       // partials per frame: m tiles x wave rows (WGM = 2)
     if (bm == 128) {
         if (bn == 128) return k64 ? launch_conv_tile<128, 128, 64>(a, frames, st) : launch_conv_tile<128, 128, 32>(a, frames, st);
         return k64 ? launch_conv_tile<128, 64, 64>(a, frames, st) : launch_conv_tile<128, 64, 32>(a, frames, st);

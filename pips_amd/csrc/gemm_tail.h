@@ -75,15 +75,15 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const
     }
 }
 
-// Convolution, C accumulators: raw output + bias, per-(frame, m-tile, channel) partial {sum, sumsq}
-// from the stored values (no atomics: bitwise deterministic).  red: >= WGM*BN*2 floats of LDS.
+// Convolution, C accumulators: raw output + bias, per-(frame, m-tile x wave row, channel) pivoted partials
+// (store_conv_partial, common.h) from the stored values (no atomics, no LDS: bitwise deterministic).
 // Bias is added to every accumulator BEFORE the (predicated) stores: a load first used inside a
 // predicated block makes hipcc wait for the previous store's acknowledgement in front of each store.
 template <int BM, int BN, int WGM, int WTM, int WTN, int NT, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const GemmArgs& p, float* Cframe,
                                               float* red, int frame, int m_tile, int m0, int n0, int wm, int wn,
                                               int l31, int half, int tid) {
-    float csum[TN], csq[TN];
+    float csum[TN], csq[TN], piv[TN];
     const bool full_tile = m0 + BM <= p.M && n0 + BN <= p.N;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -91,6 +91,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
         const int col = n0 + wn * WTN + j * 32 + l31;
         const bool col_ok = col < p.N;
         const float bv = p.bias != nullptr ? p.bias[col_ok ? col : p.N - 1] : 0.f;
+        piv[j] = __shfl(acc[0][j][0] + bv, l31);      // the wave's first row in this column (lanes of half 0, r = 0)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float v[16];
@@ -102,8 +103,9 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
-                    csum[j] += v[r];
-                    csq[j] += v[r] * v[r];
+                    const float d = v[r] - piv[j];
+                    csum[j] += d;
+                    csq[j] += d * d;
                 }
             } else {
 #pragma unroll
@@ -111,40 +113,20 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
                     const int row = rbase + (r & 3) + 8 * (r >> 2);
                     if (row < p.M && col_ok) {
                         cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
-                        csum[j] += v[r];
-                        csq[j] += v[r] * v[r];
+                        const float d = v[r] - piv[j];
+                        csum[j] += d;
+                        csq[j] += d * d;
                     }
                 }
             }
         }
     }
     if (p.stats == nullptr) return;
-    __syncthreads();                          // every wave is done with the LDS stages
+    const int left = p.M - (m0 + wm * WTM), nvalid = left < 0 ? 0 : (left > WTM ? WTM : left);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const float s = csum[j] + __shfl_xor(csum[j], 32);     // lanes l and l+32 hold the same column
-        const float q = csq[j] + __shfl_xor(csq[j], 32);
-        if (half == 0) {
-            const int c = wn * WTN + j * 32 + l31;
-            red[(wm * BN + c) * 2 + 0] = s;
-            red[(wm * BN + c) * 2 + 1] = q;
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < BN; c += NT) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int w = 0; w < WGM; ++w) {
-            s += red[(w * BN + c) * 2 + 0];
-            q += red[(w * BN + c) * 2 + 1];
-        }
-        const int col = n0 + c;
-        if (col < p.N) {
-            float* dst = p.stats + (((size_t)frame * gridDim.x + m_tile) * p.N + col) * 2;
-            dst[0] = s;
-            dst[1] = q;
-        }
-    }
+    for (int j = 0; j < TN; ++j)
+        store_conv_partial(p.stats, frame, (int)gridDim.x * WGM, m_tile * WGM + wm, p.N, n0 + wn * WTN + j * 32 + l31, half, csum[j],
+                           csq[j], piv[j], nvalid);
 }
 
 }  // namespace pips

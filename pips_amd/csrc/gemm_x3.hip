@@ -402,7 +402,7 @@ int launch_conv_x3(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) 
     // the 96-tile layers (46x62, Cout 128) lose with them (69 -> 91 us)
     if (bn == 128 && (long)cdiv(a.M, 256) * cdiv(a.N, 128) * frames >= 160) bm = 256;
     if (force_bm == 64 || force_bm == 128 || (force_bm == 256 && bn == 128)) bm = force_bm;
-    if (tiles_m) *tiles_m = cdiv(a.M, bm);
+    if (tiles_m) *tiles_m = cdiv(a.M, bm) * (bm == 256 ? 4 : 2);     // partials per frame: m tiles x wave rows
     if (bm == 256) return launch_x3_tile<256, 128, 4, 2, 1, true>(a, frames, st);
     if (bm == 128) {
         if (bn == 128) return launch_x3_tile<128, 128, 2, 2, 1, true>(a, frames, st);

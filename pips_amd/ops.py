@@ -252,8 +252,17 @@ def gemm_x3(A, W3, bias=None, epi=0, R=None):
     return Cm
 
 
+def partial_sums(stats):
+    """Pivoted InstanceNorm partials (F, parts, C, 4) = {sum(x-p), sum((x-p)^2), p, n} -> fp64 (sum x, sum x^2) per (F, C)."""
+    st = stats.double()
+    s, q, p, n = st[..., 0], st[..., 1], st[..., 2], st[..., 3]
+    p = torch.where(n > 0, p, torch.zeros_like(p))
+    return (n * p + s).sum(dim=1), (q + 2 * p * s + n * p * p).sum(dim=1)
+
+
 def conv_nhwc(x, w_packed, bias, ksize, stride, pad, want_stats=False):
-    """x (F,H,W,Cin) NHWC, w_packed (Cout, k, k, Cin) -> (F,Ho,Wo,Cout) [+ partial stats]."""
+    """x (F,H,W,Cin) NHWC, w_packed (Cout, k, k, Cin) -> (F,Ho,Wo,Cout) [+ pivoted partial stats (F, parts, Cout, 4),
+    parts = m tiles x wave rows: see partial_sums()]."""
     lib = _lib.load()
     x, w_packed = _f32(x), _f32(w_packed)
     F, H, W, Cin = x.shape
@@ -263,14 +272,14 @@ def conv_nhwc(x, w_packed, bias, ksize, stride, pad, want_stats=False):
     out = torch.empty(F, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
     stats = None
     if want_stats:
-        stats = torch.zeros(F, (Ho * Wo + 63) // 64, Cout, 2, dtype=torch.float32, device=x.device)
+        stats = torch.zeros(F, 2 * ((Ho * Wo + 63) // 64) + 4, Cout, 4, dtype=torch.float32, device=x.device)
     tiles = C.c_int(0)
     with torch.cuda.device(x.device):
         _lib.check(lib.pips_conv_nhwc_f32(_lib.ptr(x), F, H, W, Cin, _lib.ptr(w_packed), _lib.ptr(bias), Cout, ksize,
                                           stride, pad, _lib.ptr(out), _lib.ptr(stats), C.byref(tiles), _stream()),
                    "pips_conv_nhwc_f32")
     if want_stats:
-        return out, stats.view(-1)[: F * tiles.value * Cout * 2].view(F, tiles.value, Cout, 2)
+        return out, stats.view(-1)[: F * tiles.value * Cout * 4].view(F, tiles.value, Cout, 4)
     return out
 
 
@@ -285,12 +294,12 @@ def conv_nhwc_x3(x, w3, bias, ksize, stride, pad, want_stats=False):
     out = torch.empty(F, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
     stats = None
     if want_stats:
-        stats = torch.zeros(F, (Ho * Wo + 63) // 64, Cout, 2, dtype=torch.float32, device=x.device)
+        stats = torch.zeros(F, 2 * ((Ho * Wo + 63) // 64) + 4, Cout, 4, dtype=torch.float32, device=x.device)
     tiles = C.c_int(0)
     with torch.cuda.device(x.device):
         _lib.check(lib.pips_conv_nhwc_f32x3(_lib.ptr(x), F, H, W, Cin, _lib.ptr(w3), _lib.ptr(bias), Cout, ksize,
                                             stride, pad, _lib.ptr(out), _lib.ptr(stats), C.byref(tiles), _stream()),
                    "pips_conv_nhwc_f32x3")
     if want_stats:
-        return out, stats.view(-1)[: F * tiles.value * Cout * 2].view(F, tiles.value, Cout, 2)
+        return out, stats.view(-1)[: F * tiles.value * Cout * 4].view(F, tiles.value, Cout, 4)
     return out

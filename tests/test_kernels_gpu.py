@@ -115,9 +115,9 @@ def test_conv_split_bf16(F_, H, W, Cin, Cout, k, s, p):
     w3 = ops.split_bf16x3(w.permute(0, 2, 3, 1).contiguous().to(DEV))
     out, stats = ops.conv_nhwc_x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), w3, b.to(DEV), k, s, p, want_stats=True)
     assert _rel_err(out.cpu().double(), ref) < 2e-6
-    st = stats.cpu().double().sum(dim=1)
-    assert _rel_err(st[..., 0], ref.sum(dim=(1, 2))) < 1e-5
-    assert _rel_err(st[..., 1], (ref * ref).sum(dim=(1, 2))) < 1e-5
+    s1, s2 = ops.partial_sums(stats.cpu())
+    assert _rel_err(s1, ref.sum(dim=(1, 2))) < 1e-5
+    assert _rel_err(s2, (ref * ref).sum(dim=(1, 2))) < 1e-5
 
 
 @pytest.mark.parametrize("F_,H,W,Cin,Cout,k,s,p", [
@@ -135,9 +135,10 @@ def test_conv_split_bf16_256_row_tile(F_, H, W, Cin, Cout, k, s, p):
     b = torch.randn(Cout, generator=g).to(DEV)
     ref, rst = ops.conv_nhwc(x, w, b, k, s, p, want_stats=True)
     out, st = ops.conv_nhwc_x3(x, ops.split_bf16x3(w), b, k, s, p, want_stats=True)
-    assert st.shape[1] == (ref.shape[1] * ref.shape[2] + 255) // 256          # the 256-row tile was taken
+    assert st.shape[1] == 4 * ((ref.shape[1] * ref.shape[2] + 255) // 256)    # the 256-row tile (4 wave rows) was taken
     assert _rel_err(out.double(), ref.double()) < 4e-6
-    assert _rel_err(st.double().sum(dim=1), rst.double().sum(dim=1)) < 1e-5
+    (a1, a2), (b1, b2) = ops.partial_sums(st.cpu()), ops.partial_sums(rst.cpu())
+    assert _rel_err(a1, b1) < 1e-5 and _rel_err(a2, b2) < 1e-5
 
 
 # ----------------------------------------------------------------------------- conv
@@ -162,9 +163,9 @@ def test_conv_nhwc(F_, H, W, Cin, Cout, k, s, p):
                                want_stats=True)
     out = out.cpu()
     assert _rel_err(out.double(), ref) < 2e-6
-    st = stats.cpu().double().sum(dim=1)                       # (F, Cout, 2)
-    assert _rel_err(st[..., 0], ref.sum(dim=(1, 2))) < 1e-5
-    assert _rel_err(st[..., 1], (ref * ref).sum(dim=(1, 2))) < 1e-5
+    s1, s2 = ops.partial_sums(stats.cpu())                     # (F, Cout) each
+    assert _rel_err(s1, ref.sum(dim=(1, 2))) < 1e-5
+    assert _rel_err(s2, (ref * ref).sum(dim=(1, 2))) < 1e-5
 
 
 # ----------------------------------------------------------------------------- encoder
