@@ -1,6 +1,6 @@
 #!/bin/sh
 # The round's rocprofv3 evidence (run on the GPU box through gpurun): kernel-trace summaries of the headline command and
-# of the config-4 leg, and FETCH_SIZE / WRITE_SIZE counter passes of the same two commands (separate runs: counters and
+# of the config-3 / config-4 legs, and FETCH_SIZE / WRITE_SIZE counter passes of the same two commands (separate runs: counters and
 # --stats traces are never combined).  Outputs under gpurun_out/prof_<tag>_*; copy what is to be judged into profiles/.
 # usage: sh tools/profile_round.sh r2
 TAG=${1:-r2}
@@ -9,9 +9,12 @@ export TMPDIR=/tmp
 cd /tmp
 HEAD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-stage-profile --no-extras"
 C4="python $R/bench.py --leg config4"
+C3="python $R/bench.py --leg config3"
 rm -rf /tmp/pr_*
 rocprofv3 --kernel-trace --stats -d /tmp/pr_kt_head -o p -- $HEAD > $R/gpurun_out/prof_${TAG}_head.log 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/pr_kt_c4 -o p -- $C4 > $R/gpurun_out/prof_${TAG}_c4.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/pr_kt_c3 -o p -- $C3 > $R/gpurun_out/prof_${TAG}_c3.log 2>&1
+for f in $(find /tmp/pr_kt_c3 -name "*.db"); do python $R/tools/rocpd_summary.py $f $R/gpurun_out/prof_${TAG}_config3_kernel_stats.txt > /dev/null; done
 for f in $(find /tmp/pr_kt_head -name "*.db"); do python $R/tools/rocpd_summary.py $f $R/gpurun_out/prof_${TAG}_kernel_stats.txt > /dev/null; done
 for f in $(find /tmp/pr_kt_c4 -name "*.db"); do python $R/tools/rocpd_summary.py $f $R/gpurun_out/prof_${TAG}_config4_kernel_stats.txt > /dev/null; done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pr_f_head -o p -- $HEAD > /dev/null 2>&1
