@@ -27,7 +27,7 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float4& lo, const float4& hi)
 }
 
 // CONV: implicit-GEMM convolution on an NHWC fp32 map (zero padding, per-frame m-tiling, the
-// instance-norm {sum,sumsq} partials from the fp32 accumulators) -- same contract as the fp32
+// pivoted instance-norm partials (store_conv_partial) from the fp32 accumulators) -- same contract as the fp32
 // conv of gemm.hip, with bf16 operands.  BKE = K elements per staged block per wave group: 64,
 // or 32 for Cin = 96 / 416 so that a block never straddles a filter tap.
 template <int BM, int BN, int WGM, int WGN, int KS, bool A_BF16, bool OUT_BF16, int BKE = 64, bool CONV = false>

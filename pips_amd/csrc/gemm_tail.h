@@ -1,6 +1,6 @@
 // Tail of a GEMM / implicit-GEMM tile shared by the matrix-core kernels: K-split reduction,
 // plain-GEMM epilogue (C^T accumulators) and convolution epilogue (C accumulators + the
-// instance-norm {sum, sumsq} partials).  Accumulator map of the 32x32 MFMA C/D operand:
+// pivoted instance-norm partials).  Accumulator map of the 32x32 MFMA C/D operand:
 // element r of lane l sits at MFMA row (r&3) + 8*(r>>2) + 4*(l>>5), MFMA column l&31.
 #pragma once
 #include "common.h"

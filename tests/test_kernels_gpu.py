@@ -192,10 +192,10 @@ def test_encoder_pyramid(H, W, stride, split, weights_raw, arenas):
 
 @pytest.mark.parametrize("kind", ["low_contrast", "letterbox", "flat_with_dot"])
 def test_encoder_low_variance_frames(kind, weights_raw, arenas):
-    """Frames whose channels have |mean| >> std (flat video, letterboxing): the stem's InstanceNorm statistics are summed about
-    a pivot and combined Chan-style in fp64 (sum / sum-of-squares partials lose their digits exactly there); the later
-    layers keep E[x^2] - mean^2 partials.  Yardstick: the reference arithmetic's own fp32 error against an fp64 run -- the
-    HIP maps stay within 4x of it (measured 1.0x / 1.5x / 0.9x)."""
+    """Frames whose channels have |mean| >> std (flat video, letterboxing): the InstanceNorm statistics of the stem and of
+    every conv layer are summed about a pivot and combined in fp64 (sum / sum-of-squares partials lose their digits exactly
+    there).  Yardstick: the reference arithmetic's own fp32 error against an fp64 run -- the HIP maps stay within 4x of it
+    (measured 1.0x / 1.6x / 0.9x)."""
     from pips_amd import ops
     O = _oracle()
     g = torch.Generator().manual_seed(3)
