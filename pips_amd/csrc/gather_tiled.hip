@@ -435,8 +435,14 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
                 const unsigned v0 = (unsigned)g.x0 | ((unsigned)g.y0 << 16), v1 = (unsigned)g.RW | ((unsigned)g.RH << 16),
                                v2 = (unsigned)g.W | ((unsigned)g.H << 16);                // (g is lane-parallel by lane & 3)
                 gpk = (int)(lane < 4 ? v0 : (lane < 8 ? v1 : v2));
+                // (v_writelane: the per-lane selects of wave-uniform values compile to one exec-masked branch each)
 #pragma unroll
-                for (int r = 0; r < MAXP; ++r) gpk = lane == 16 + r ? ((PIPS_TILED_ABLATE & 4) ? -1 : wp.lds[r]) : (lane == 24 + r ? wp.par[r] : gpk);
+                for (int r = 0; r < MAXP; ++r) {
+                    const int pl = __builtin_amdgcn_readfirstlane((PIPS_TILED_ABLATE & 4) ? -1 : wp.lds[r]);
+                    const int pp = __builtin_amdgcn_readfirstlane(wp.par[r]);
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(gpk) : "s"(pl), "n"(16 + r));
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(gpk) : "s"(pp), "n"(24 + r));
+                }
             }
             PIPS_TR(1);
 #ifdef PIPS_TILED_TRACE
