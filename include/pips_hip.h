@@ -217,6 +217,12 @@ int    pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin,
                           const float* wgt, const float* bias, int Cout, int ksize, int cstride, int pad,
                           float* out, float* stats, int* tiles_m_host, void* stream);
 
+/* bf16-operand building block (BASELINE config 3): A fp32 (rounded to bf16 while staged) or bf16 [M][lda], W bf16 [N][K]
+ * (round-to-nearest-even of the fp32 weights), fp32 accumulation, C fp32 or bf16 [M][ldc]; epi as pips_gemm_f32.
+ * K % 32 == 0 (K % 64 unless A and C are fp32). */
+int    pips_gemm_bf16(const void* A, int a_bf16, int lda, const void* W, const float* bias, void* C, int out_bf16, int ldc,
+                      int M, int N, int K, int epi, const float* R, int ldr, void* stream);
+
 /* Split-bf16 ("bf16x3") building blocks: fp32-grade results from the bf16 matrix cores.  Every
  * fp32 operand is split exactly into three bf16 terms and each product is formed from six exact
  * bf16 products accumulated in fp32 (same F.linear / F.conv2d contracts as the two calls above).

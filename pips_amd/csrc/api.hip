@@ -575,6 +575,13 @@ static int gemm_h(const float* A, int a_bf16, int lda, const unsigned short* W, 
     return launch_gemm_bf16(g, a_bf16, out_bf16, st);
 }
 
+int pips_gemm_bf16(const void* A, int a_bf16, int lda, const void* W, const float* bias, void* C, int out_bf16, int ldc,
+                   int M, int N, int K, int epi, const float* R, int ldr, void* stream) {
+    PIPS_CHECK_ARG(A && W && C, "gemm_bf16: null pointer");
+    return gemm_h(reinterpret_cast<const float*>(A), a_bf16, lda, reinterpret_cast<const unsigned short*>(W), bias,
+                  reinterpret_cast<float*>(C), out_bf16, ldc, M, N, K, epi, R, ldr, (hipStream_t)stream);
+}
+
 // bf16 == 1: bf16 MFMA operands for every Linear of the mixer (weights pre-converted; the LayerNorm-2 output and the
 // 2048-wide hidden activation stored as bf16, everything else fp32); the 544-wide input projection rides
 // 32-element K blocks (544 = 17 x 32).

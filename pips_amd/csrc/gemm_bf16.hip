@@ -376,6 +376,10 @@ int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st
     PIPS_CHECK_ARG((unsigned long long)a.M * (unsigned long long)a.lda < (1ull << 32) &&
                        (unsigned long long)a.N * (unsigned long long)a.K < (1ull << 32),
                    "gemm_bf16: operand exceeds 2^32 elements");
+    {
+        const int rc = launch_gemm_bf16_asm(a, a_bf16, out_bf16, st);      // the config-3 up-projection
+        if (rc != 1) return rc;
+    }
     if (a_bf16) return out_bf16 ? pick_tile<true, true>(a, st) : pick_tile<true, false>(a, st);
     return out_bf16 ? pick_tile<false, true>(a, st) : pick_tile<false, false>(a, st);
 }

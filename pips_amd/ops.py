@@ -252,6 +252,21 @@ def gemm_x3(A, W3, bias=None, epi=0, R=None):
     return Cm
 
 
+def gemm_bf16(A, W, bias=None, epi=0, R=None, out_bf16=False):
+    """gemm() with bf16 MFMA operands: A fp32 or bfloat16 (M,K), W bfloat16 (N,K); returns fp32 or bfloat16 (M,N)."""
+    lib = _lib.load()
+    assert W.dtype == torch.bfloat16 and A.dtype in (torch.float32, torch.bfloat16)
+    A, W = A.contiguous(), W.contiguous()
+    M, K = A.shape
+    N = W.shape[0]
+    Cm = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        _lib.check(lib.pips_gemm_bf16(_lib.ptr(A), int(A.dtype == torch.bfloat16), K, _lib.ptr(W), _lib.ptr(bias), _lib.ptr(Cm),
+                                      int(out_bf16), N, M, N, K, epi, _lib.ptr(R), N if R is not None else 0, _stream()),
+                   "pips_gemm_bf16")
+    return Cm
+
+
 def partial_sums(stats):
     """Pivoted InstanceNorm partials (F, parts, C, 4) = {sum(x-p), sum((x-p)^2), p, n} -> fp64 (sum x, sum x^2) per (F, C)."""
     st = stats.double()

@@ -1,0 +1,292 @@
+#!/usr/bin/env python
+"""Emit pips_amd/csrc/gemm_bf16_tile_asm.inc: the assembly text of ONE 256x128 TILE (K = 512: eight super-stages of 64 K values) of one
+wave of the persistent bf16 up-projection kernel (gemm_bf16_asm.hip) -- fragment reads, MFMAs, the wave's LDS-DMA
+instructions of the ring three super-stages ahead, and the GELU / bf16 conversion / stores of the PREVIOUS tile (parked
+as bf16 pairs in v[64:95]) between the MFMA pairs.  Straight-line code, fixed registers: the C++ form of the same loop
+(gemm_bf16_dma.hip) either carried ~25 scalar branches per super-stage or, unrolled, spilled (tools/experiments/README.md).
+
+Variants (one text each): GELU of a parked tile on / off  x  the ring runs on into the next tile / stops at this one.
+
+Registers (clobbered by the statement unless noted):
+    v[0:63]      accumulators acc[i][j] -> v[16*(2i+j) : +15]       (C^T: lane = output row, registers = columns)
+    v[64:95]     the parked tile, bf16 pairs: prev[i][j][d] -> v[64 + 8*(2i+j) + d]   (operands, live across statements)
+    v[96:111]    A fragments fa[kk][i] -> v[96 + 4*(2kk+i) : +3];  v[112:127] W fragments fb[kk][j]
+    v[128:139]   GELU: x0 x1 t0 t1 p0 p1 (pairs);  v[140:143] the 8 bf16 of a piece;  v[144:146] fragment addresses
+    v[148:153]   a_off^32, b_off^32 ... scratch;  v[156:157] polynomial constant c4
+    s[40:69]     constants, ring pointer, temporaries
+"""
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "gemm_bf16_tile_asm.inc"))
+
+STAGE = (256 + 128) * 64           # bytes of one 32-K stage
+SUP = 2 * STAGE                    # one super-stage
+NSUP = 3
+ACC, PREV, FA, FB = 0, 64, 96, 112
+X0, X1, T0, T1, P0, P1 = 128, 130, 132, 134, 136, 138
+OUTR = 140
+RA, RB0, RB1 = 144, 145, 146
+AX, B0X, B1X = 148, 149, 150       # the kk = 1 offsets (slot ^ 2 = byte offset ^ 32)
+C4V = 156
+S_C5, S_C3, S_C2, S_C1, S_C0, S_TMAX, S_MH = 40, 42, 44, 46, 48, 50, 52
+S_RD, S_T, S_T2 = 54, 56, 57
+DV = 153                           # lane offset + K offset of a DMA instruction
+# degree-5 exponent polynomial of the bf16-output GELU (gemm_bf16_dma.hip), c0..c5
+COEF = [-1.150685204e+00, -4.602978599e-01, -5.192063601e-02, 7.452824686e-03, -6.529359078e-04, 2.554670494e-05]
+TMAX = 5.65685425
+
+
+def f32(x):
+    import struct
+    return "0x%08x" % struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+class Asm:
+    def __init__(self):
+        self.lines = []
+        self.vm = []            # vector-memory operations in issue order: ("dma", stage) / ("st",) / ("ld",)
+
+    def __call__(self, s):
+        self.lines.append(s)
+
+
+def acc(i, j):
+    return ACC + 16 * (2 * i + j)
+
+
+def prev(hh):
+    i, j, d = hh >> 3, (hh >> 2) & 1, 2 * (hh & 3)
+    return PREV + 8 * (2 * i + j) + d
+
+
+def fa(kk, i):
+    return FA + 4 * (2 * kk + i)
+
+
+def fb(kk, j):
+    return FB + 4 * (2 * kk + j)
+
+
+def reads(a, kk, sbase_expr_reg, stage_off):
+    """4 fragment reads of K half kk from the stage at s[sbase] + stage_off"""
+    a("s_add_u32 s%d, s%d, %d" % (S_T, sbase_expr_reg, stage_off))
+    a("v_add_u32 v%d, s%d, %s" % (RA, S_T, "%[aoff]" if kk == 0 else "v%d" % AX))
+    a("v_add_u32 v%d, s%d, %s" % (RB0, S_T, "%[b0off]" if kk == 0 else "v%d" % B0X))
+    a("v_add_u32 v%d, s%d, %s" % (RB1, S_T, "%[b1off]" if kk == 0 else "v%d" % B1X))
+    a("ds_read_b128 v[%d:%d], v%d" % (fa(kk, 0), fa(kk, 0) + 3, RA))
+    a("ds_read_b128 v[%d:%d], v%d" % (fb(kk, 0), fb(kk, 0) + 3, RB0))
+    a("ds_read_b128 v[%d:%d], v%d offset:2048" % (fa(kk, 1), fa(kk, 1) + 3, RA))
+    a("ds_read_b128 v[%d:%d], v%d" % (fb(kk, 1), fb(kk, 1) + 3, RB1))
+
+
+def mfma2(a, kk, i):
+    for j in range(2):
+        c = acc(i, j)
+        a("v_mfma_f32_32x32x16_bf16 v[%d:%d], v[%d:%d], v[%d:%d], v[%d:%d]" %
+          (c, c + 15, fb(kk, j), fb(kk, j) + 3, fa(kk, i), fa(kk, i) + 3, c, c + 15))
+
+
+def dma(a, X, u, q, nxt):
+    """one LDS-DMA instruction of super-stage X (tile-relative; >= 8: the next tile), half u, piece q of this wave.
+    LDS side: s[S_T2] = the wave's piece 0 of the buffer being refilled.  The
+    instruction's immediate offset would move the LDS destination as well, so the K offset is added to the lane offset."""
+    tile = "n" if X >= 8 else "c"
+    k_off = (X % 8) * 128 + u * 64
+    a("s_add_u32 m0, s%d, %d" % (S_T2, u * STAGE + q * 1024))
+    if k_off:
+        a("v_add_u32 v%d, %d, %%[ro%d]" % (DV, k_off, q))
+        a("global_load_lds_dwordx4 v%d, %%[%sq%d]" % (DV, tile, q))
+    else:
+        a("s_nop 0")
+        a("global_load_lds_dwordx4 %%[ro%d], %%[%sq%d]" % (q, tile, q))
+    a.vm.append(("dma", X))
+
+
+def gelu_load(a, hh):
+    d0, d1 = prev(hh), prev(hh) + 1
+    a("v_lshlrev_b32 v%d, 16, v%d" % (X0, d0))
+    a("v_and_b32 v%d, 0xffff0000, v%d" % (X0 + 1, d0))
+    a("v_lshlrev_b32 v%d, 16, v%d" % (X1, d1))
+    a("v_and_b32 v%d, 0xffff0000, v%d" % (X1 + 1, d1))
+
+
+def gelu_step(a, n):
+    pairs = [(X0, T0, P0), (X1, T1, P1)]
+    if n == 1:
+        for x, t, p in pairs:
+            a("v_min_f32_e64 v%d, |v%d|, s%d" % (t, x, S_TMAX))
+            a("v_min_f32_e64 v%d, |v%d|, s%d" % (t + 1, x + 1, S_TMAX))
+        for x, t, p in pairs:
+            a("v_pk_fma_f32 v[%d:%d], v[%d:%d], s[%d:%d], v[%d:%d] op_sel_hi:[1,0,1]" % (p, p + 1, t, t + 1, S_C5, S_C5 + 1, C4V, C4V + 1))
+        for x, t, p in pairs:
+            a("v_pk_fma_f32 v[%d:%d], v[%d:%d], v[%d:%d], s[%d:%d] op_sel_hi:[1,1,0]" % (p, p + 1, p, p + 1, t, t + 1, S_C3, S_C3 + 1))
+        for x, t, p in pairs:
+            a("v_max_f32_e32 v%d, 0, v%d" % (x, x))
+            a("v_max_f32_e32 v%d, 0, v%d" % (x + 1, x + 1))
+    elif n == 2:
+        for s_c in (S_C2, S_C1, S_C0):
+            for x, t, p in pairs:
+                a("v_pk_fma_f32 v[%d:%d], v[%d:%d], v[%d:%d], s[%d:%d] op_sel_hi:[1,1,0]" % (p, p + 1, p, p + 1, t, t + 1, s_c, s_c + 1))
+        for x, t, p in pairs:
+            a("v_pk_mul_f32 v[%d:%d], v[%d:%d], v[%d:%d]" % (p, p + 1, p, p + 1, t, t + 1))
+    elif n == 3:
+        for x, t, p in pairs:
+            a("v_exp_f32_e32 v%d, v%d" % (p, p))
+            a("v_exp_f32_e32 v%d, v%d" % (p + 1, p + 1))
+        a("s_nop 0")
+        for x, t, p in pairs:
+            a("v_pk_mul_f32 v[%d:%d], v[%d:%d], v[%d:%d]" % (p, p + 1, p, p + 1, t, t + 1))
+    else:
+        for x, t, p in pairs:
+            a("v_pk_fma_f32 v[%d:%d], v[%d:%d], s[%d:%d], v[%d:%d] op_sel_hi:[1,0,1]" % (p, p + 1, p, p + 1, S_MH, S_MH + 1, x, x + 1))
+
+
+def gelu_pack(a, dst):
+    a("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (dst, P0, P0 + 1))
+    a("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (dst + 1, P1, P1 + 1))
+
+
+def vm_wait(a, need_stage):
+    """s_waitcnt vmcnt(N): everything up to the last load of super-stage need_stage has landed"""
+    last = max([k for k, op in enumerate(a.vm) if op == ("dma", need_stage)], default=-1)
+    n = len(a.vm) - 1 - last
+    a("s_waitcnt vmcnt(%d)" % min(n, 63))
+
+
+def tile(gel, runon):
+    """gel: the parked tile's GELU pieces are issued; runon: super-stages 8..10 (next tile) are opened"""
+    a = Asm()
+    # ---- constants
+    for s, v in ((S_C5, COEF[5]), (S_C3, COEF[3]), (S_C2, COEF[2]), (S_C1, COEF[1]), (S_C0, COEF[0]), (S_TMAX, TMAX), (S_MH, -0.5)):
+        a("s_mov_b32 s%d, %s" % (s, f32(v)))
+    a("v_mov_b32 v%d, %s" % (C4V, f32(COEF[4])))
+    a("v_mov_b32 v%d, %s" % (C4V + 1, f32(COEF[4])))
+    a("v_xor_b32 v%d, 32, %%[aoff]" % AX)
+    a("v_xor_b32 v%d, 32, %%[b0off]" % B0X)
+    a("v_xor_b32 v%d, 32, %%[b1off]" % B1X)
+    a("s_mov_b32 s%d, %%[rd]" % S_RD)                 # LDS address of the super-stage this tile starts with
+    # ---- accumulators start from the bias: acc[0][j][4g..] <- bias[cols], copied to acc[1][j]
+    for j in range(2):
+        for g in range(4):
+            off = ((2 * j + (g >> 1)) * 16 + 4 * (g & 1)) * 4
+            r = acc(0, j) + 4 * g
+            a("global_load_dwordx4 v[%d:%d], %%[boff], %%[bias] offset:%d" % (r, r + 3, off))
+    a("s_waitcnt vmcnt(0)")                           # (also: every super-stage issued so far has landed for this wave)
+    for j in range(2):
+        for r in range(16):
+            a("v_mov_b32 v%d, v%d" % (acc(1, j) + r, acc(0, j) + r))
+    # ---- fragments of K block a of super-stage 0 (landed and published by the previous tile's last barrier)
+    reads(a, 0, S_RD, 0)
+    reads(a, 1, S_RD, 0)
+    # the second half of super-stage 2 is still to be issued (its first half went out in the previous statement / the
+    # C++ prologue); its buffer: two ahead of the read buffer
+    for ks in range(8):
+        Xa = ks + 2                                   # block a issues the second half of this stage (opened last iteration)
+        Xb = ks + 3                                   # block b opens this one
+        do_a = Xa <= 7 or runon
+        do_b = Xb <= 7 or runon
+        hh = 2 * ks
+        # ================= K block a
+        if do_a:                                      # LDS base of stage Xa's buffer + this wave's piece: (rd + 2 SUP) mod ring
+            a("s_add_u32 s%d, s%d, %d" % (S_T2, S_RD, 2 * SUP))
+            a("s_sub_u32 s%d, s%d, %d" % (S_T, S_T2, NSUP * SUP))
+            a("s_cmp_ge_u32 s%d, %%[ringend]" % S_T2)
+            a("s_cselect_b32 s%d, s%d, s%d" % (S_T2, S_T, S_T2))
+            a("s_add_u32 s%d, s%d, %%[wvoff]" % (S_T2, S_T2))
+        if gel:
+            gelu_load(a, hh)
+        a("s_waitcnt lgkmcnt(4)")
+        mfma2(a, 0, 0)
+        if do_a:
+            dma(a, Xa, 1, 0, Xa >= 8)
+        if gel:
+            gelu_step(a, 1)
+        mfma2(a, 0, 1)
+        if do_a:
+            dma(a, Xa, 1, 1, Xa >= 8)
+        if gel:
+            gelu_step(a, 2)
+        a("s_waitcnt lgkmcnt(0)")
+        reads(a, 0, S_RD, STAGE)                      # block b, kk = 0
+        mfma2(a, 1, 0)
+        if do_a:
+            dma(a, Xa, 1, 2, Xa >= 8)
+        if gel:
+            gelu_step(a, 3)
+        mfma2(a, 1, 1)
+        if gel:
+            gelu_step(a, 4)
+            gelu_pack(a, OUTR)
+        reads(a, 1, S_RD, STAGE)                      # block b, kk = 1
+        # ================= K block b
+        if gel:
+            gelu_load(a, hh + 1)
+        a("s_waitcnt lgkmcnt(4)")
+        mfma2(a, 0, 0)
+        if gel:
+            gelu_step(a, 1)
+        mfma2(a, 0, 1)
+        if gel:
+            gelu_step(a, 2)
+        a("s_waitcnt lgkmcnt(0)")                     # this wave is done reading super-stage ks
+        if ks < 7 or runon:
+            vm_wait(a, ks + 1)                        # its part of super-stage ks+1 has landed
+        else:
+            a("s_waitcnt vmcnt(0)")
+        a("s_barrier")
+        if do_b:                                      # the buffer super-stage ks just left is refilled with stage ks+3
+            a("s_add_u32 s%d, s%d, %%[wvoff]" % (S_T2, S_RD))
+        # advance the ring pointer
+        a("s_add_u32 s%d, s%d, %d" % (S_RD, S_RD, SUP))
+        a("s_cmp_ge_u32 s%d, %%[ringend]" % S_RD)
+        a("s_cselect_b32 s%d, %%[lds0], s%d" % (S_RD, S_RD))
+        if ks < 7:
+            reads(a, 0, S_RD, 0)                      # next block a, kk = 0
+        mfma2(a, 1, 0)
+        if do_b:
+            dma(a, Xb, 0, 0, Xb >= 8)
+            dma(a, Xb, 0, 1, Xb >= 8)
+        if gel:
+            gelu_step(a, 3)
+        mfma2(a, 1, 1)
+        if do_b:
+            dma(a, Xb, 0, 2, Xb >= 8)
+        if gel:
+            gelu_step(a, 4)
+            gelu_pack(a, OUTR + 2)
+            i, jq = ks >> 2, ks & 3
+            a("global_store_dwordx4 %%[stoff], v[%d:%d], %%[cb%d] offset:%d" % (OUTR, OUTR + 3, i, jq * 32))
+            a.vm.append(("st",))
+        if ks < 7:
+            reads(a, 1, S_RD, 0)                      # next block a, kk = 1
+    # ---- park the tile: prev <- bf16 pairs of the accumulators (the MFMAs have to have written them back)
+    a("s_nop 15")
+    a("s_nop 15")
+    for i in range(2):
+        for j in range(2):
+            for d in range(8):
+                a("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (PREV + 8 * (2 * i + j) + d, acc(i, j) + 2 * d, acc(i, j) + 2 * d + 1))
+    return a
+
+
+def main():
+    out = ["// GENERATED by tools/gen_gemm_bf16_asm.py -- do not edit.", ""]
+    for gel in (0, 1):
+        for runon in (0, 1):
+            a = tile(gel, runon)
+            out.append("#define PIPS_TILE_TEXT_G%d_R%d \\" % (gel, runon))
+            for i, ins in enumerate(a.lines):
+                out.append('    "%s\\n\\t"' % ins + (" \\" if i + 1 < len(a.lines) else ""))
+            out.append("")
+            print("variant gelu=%d runon=%d: %d instructions" % (gel, runon, len(a.lines)))
+    clob = ['"v%d"' % i for i in list(range(0, 64)) + list(range(96, 160))] + ['"s%d"' % i for i in range(40, 62)]
+    out.append('#define PIPS_TILE_CLOBBER "memory", "scc", "vcc", ' + ", ".join(clob))
+    out.append("")
+    with open(OUT, "w") as f:
+        f.write("\n".join(out))
+    print("wrote", os.path.normpath(OUT))
+
+
+if __name__ == "__main__":
+    main()
