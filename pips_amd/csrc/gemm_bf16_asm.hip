@@ -1,15 +1,22 @@
 // bf16 x bf16 up-projection of the large-batch channel mix (BASELINE config 3: M = B*N*8 >= 16384 rows, K = 512,
-// GELU, bf16 output) as PERSISTENT blocks whose tile body is one generated assembly statement
+// GELU, bf16 output): blocks that walk a few tiles each, the tile body ONE generated assembly statement
 // (gemm_bf16_tile_asm.inc <- tools/gen_gemm_bf16_asm.py).
 //
 // C[M,N] = bf16(gelu(bf16(A W^T + bias))): both operands bf16 in memory; fp32 accumulation on
-// v_mfma_f32_32x32x16_bf16; the Linear's output is rounded to bf16 before the GELU, as under autocast.
+// v_mfma_f32_32x32x16_bf16 (AccVGPRs); the Linear's output is rounded to bf16 before the GELU, as under autocast.
 // Block = 8 waves, 256x128 tile, 64x64 per wave.  Operands reach LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
-// wave-instruction) into a ring of three super-stages of 2 x 32 K values that runs three super-stages ahead and across
-// tile boundaries; one s_barrier per 64 K values; one rolling fragment set; the finished tile's accumulators are parked
-// as bf16 pairs (32 registers) and its GELU / conversion / 16-byte stores are issued between the MFMA pairs of the next
-// tile.  Why assembly: see tools/experiments/README.md (gemm_bf16_dma.hip) -- in C++ the same loop either carries ~25
-// scalar branches per 64 K values (as many clocks as the MFMAs) or, written branch-free, spills.
+// wave-instruction, no VGPR round trip) into a ring of three super-stages of 2 x 32 K values that runs three
+// super-stages ahead and across the block's tile boundaries; one s_barrier per 64 K values; one rolling fragment set
+// (the reads of the next K half go out as soon as the MFMAs that used the registers are issued).  A finished tile is
+// parked as bf16 pairs in 32 registers; its GELU (piecewise-linear LDS table) and 16-byte stores follow at once.
+// Why assembly: in C++ the same loop either carries ~25 scalar branches per 64 K values (as many clocks as the MFMAs)
+// or, written branch-free, spills (tools/experiments/README.md, gemm_bf16_dma.hip).  Why the GELU is NOT interleaved
+// with the next tile's MFMAs (the G1 texts of the generator, PIPS_ASM_DEFER=1: measured 22.0 vs 20.7 ms at config 3):
+// VALU work and dense bf16 MFMAs do not overlap on a gfx950 SIMD (tools/mfma_valu_overlap.hip: 8 MFMAs + 64 FMAs per
+// wave take the SUM of their times, from one wave or from two), so hiding one under the other buys nothing and the
+// interleaved form pays arbitration between the two waves of a SIMD on top.
+// Measured (M = 16384, N = 2048): 54.8 us isolated against 59.9 us for gemm_bf16_kernel<256,256>; config 3 21.5 ->
+// 20.7 ms.  Per 64 K values a wave spends ~1750 clocks (trace: tools/bf16_asm_trace.py) where its 16 MFMAs need 600.
 // LDS rows are unpadded (the DMA writes lane-linear), XOR-swizzled: phys slot = slot ^ ((row >> 2) & 3), applied to
 // the per-lane global source address and to the fragment reads (conflict-free 16-lane ds_read_b128 groups).
 // GELU column order: the W rows are fetched from LDS permuted (gelu_col) so that a lane's registers 8q..8q+7 are eight
@@ -18,7 +25,23 @@
 
 #include <cstdlib>
 
-#include "gemm_bf16_tile_asm.inc"
+#ifndef PIPS_ASM_DEFER
+#define PIPS_ASM_DEFER 0     // 1: a tile's GELU / stores ride between the next tile's MFMA pairs (the G1 texts)
+#endif
+#ifndef PIPS_TILE_INC
+#define PIPS_TILE_INC "gemm_bf16_tile_asm.inc"      // tuning builds point this at a traced copy (PIPS_GEN_TRACE=1)
+#endif
+#include PIPS_TILE_INC
+
+#ifdef PIPS_ASM_TRACE        // tools/bf16_asm_trace.py: s_memtime stamps of one wave of block 0, 36 per tile
+namespace pips { __device__ unsigned* g_asm_trace; }
+extern "C" int pips_asm_trace(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(pips::g_asm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#ifndef PIPS_ASM_TRACE_WAVE
+#define PIPS_ASM_TRACE_WAVE 0
+#endif
+#endif
 
 namespace pips {
 
@@ -40,27 +63,24 @@ __device__ __forceinline__ int gelu_col(int j, int rho) {
     return (2 * j + (r >> 3)) * 16 + 8 * h + (r & 7);
 }
 
-// bf16-output GELU on two pairs (degree-5 exponent polynomial, relative error 3.5e-5): the C++ twin of the assembly's,
-// used for the last tile's epilogue, which has no main loop to hide under
-__device__ __forceinline__ uint2 gelu_bf16x4(unsigned d0, unsigned d1) {
-    f2 x[2] = {(f2){__uint_as_float(d0 << 16), __uint_as_float(d0 & 0xffff0000u)},
-               (f2){__uint_as_float(d1 << 16), __uint_as_float(d1 & 0xffff0000u)}};
-    f2 r[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const f2 t = __builtin_elementwise_min(__builtin_elementwise_abs(x[k]), (f2){PIPS_GELU_TMAX, PIPS_GELU_TMAX});
-        f2 p = t * 2.554670494e-05f + -6.529359078e-04f;
-        p = p * t + 7.452824686e-03f;
-        p = p * t + -5.192063601e-02f;
-        p = p * t + -4.602978599e-01f;
-        p = p * t + -1.150685204e+00f;
-        p = p * t;
-        p = t * (f2){__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
-        r[k] = p * -0.5f + __builtin_elementwise_max(x[k], (f2){0.f, 0.f});
-    }
+// GELU of the parked tile by a piecewise-linear table in LDS: 768 intervals of 1/64 on [-6, 6) as {value, slope} pairs
+// built from the exact form (common.h) at kernel start; beyond the table the first / last interval extrapolates (slope
+// 0 / 1: gelu(x) = 0 / x there to 1e-8).  Interpolation error h^2/8 max|gelu''| = 2.4e-5 -- the result is rounded to
+// bf16 (2^-9 relative).  6 VALU instructions + one ds_read_b64 per value where the polynomial-and-exp form needs ~15
+// issue slots: the epilogue is pure VALU time (bf16 MFMAs and VALU work do not overlap on a gfx950 SIMD,
+// tools/mfma_valu_overlap.hip) and the LDS pipe is idle in it.
+constexpr int GELU_TAB_N = 768;
+__device__ __forceinline__ float gelu_tab(const float2* __restrict__ tab, float x) {
+    const float t = fmaf(x, 64.0f, 384.0f);
+    const unsigned i = (unsigned)__builtin_amdgcn_fmed3f(t, 0.0f, (float)(GELU_TAB_N - 1));
+    const float2 e = tab[i];
+    return fmaf(e.y, t - (float)i, e.x);
+}
+__device__ __forceinline__ uint2 gelu_bf16x4(const float2* __restrict__ tab, unsigned d0, unsigned d1) {
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-    const f32x4_ t4 = {r[0].x, r[0].y, r[1].x, r[1].y};
+    const f32x4_ t4 = {gelu_tab(tab, __uint_as_float(d0 << 16)), gelu_tab(tab, __uint_as_float(d0 & 0xffff0000u)),
+                       gelu_tab(tab, __uint_as_float(d1 << 16)), gelu_tab(tab, __uint_as_float(d1 & 0xffff0000u))};
     bf16x4_ ob = __builtin_convertvector(t4, bf16x4_);
     return *reinterpret_cast<uint2*>(&ob);
 }
@@ -77,8 +97,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_gelu_asm_kernel(GemmArgs p, int
     const unsigned short* __restrict__ Ab = reinterpret_cast<const unsigned short*>(p.A);
     const unsigned short* __restrict__ Wb = reinterpret_cast<const unsigned short*>(p.W);
     unsigned short* __restrict__ Cb = reinterpret_cast<unsigned short*>(p.C);
-    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    if (my_tiles == 0) return;
+    // A block walks TPB consecutive tiles (m fastest: they share the W panel).  TPB is small and the grid large: in the
+    // forward the kernel starts while the token-mix kernel before it is still draining, and with one long-lived block per CU
+    // the CU that frees up last decided the kernel's end (73 us in situ against 55 us isolated); with ntiles / TPB blocks
+    // the hardware hands blocks to CUs as they free up.
+    const int tpb = p.swz;                            // tiles per block (set by the launcher)
+    const int tile_first = blockIdx.x * tpb, tile_end = min(tile_first + tpb, ntiles);
+    if (tile_first >= ntiles) return;
 
     // loader: wave w brings rows [(3w + q)*16, +16) of the combined A|W row list; lane -> row lane>>2, physical slot lane&3
     unsigned rowoff[LPW];
@@ -99,8 +124,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_gelu_asm_kernel(GemmArgs p, int
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned wvoff = wave * (LPW * 1024), ringend = lds0 + NSUP * SUP;
 
+    // ---- the GELU table (behind the ring), published by the barrier of the prologue
+    float2* tab = reinterpret_cast<float2*>(smem + NSUP * SUP);
+    for (int k = tid; k < GELU_TAB_N; k += 512) {
+        const float x = (float)(k - GELU_TAB_N / 2) * (1.0f / 64.0f);
+        const float v0 = gelu_exact(x), v1 = gelu_exact(x + 1.0f / 64.0f);
+        tab[k] = make_float2(v0, v1 - v0);
+    }
     // ---- prologue: super-stages 0 and 1 of the first tile in full, the first half of super-stage 2
-    const int tile0 = blockIdx.x;
+    const int tile0 = tile_first;
 #pragma unroll
     for (int X = 0; X < 3; ++X)
 #pragma unroll
@@ -109,7 +141,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_gelu_asm_kernel(GemmArgs p, int
             for (int q = 0; q < LPW; ++q)
                 __builtin_amdgcn_global_load_lds((gptr_t)(tile_base(tile0, q) + rowoff[q] + X * 128 + u * 64),
                                                  (lptr_t)(smem + X * SUP + u * STAGE + wave * (LPW * 1024) + q * 1024), 16, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     // fragment byte offsets inside a stage (kk = 0; the statement derives kk = 1 by ^ 32)
@@ -128,17 +160,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_gelu_asm_kernel(GemmArgs p, int
     const char* cb0 = nullptr;
     const char* cb1 = nullptr;
     int prow0 = 0, pcolh = 0;
-    for (int t = 0; t < my_tiles; ++t) {
-        const int tile = blockIdx.x + t * gridDim.x;
-        const bool last = t + 1 == my_tiles;
-        const int ntile = last ? tile : tile + gridDim.x;
+    for (int tile = tile_first, t = 0; tile < tile_end; ++tile, ++t) {
+        const int nxt = tile + 1;
+        const bool last = nxt >= tile_end;
+        const int ntile = last ? tile : nxt;
         const char* cq0 = tile_base(tile, 0); const char* cq1 = tile_base(tile, 1); const char* cq2 = tile_base(tile, 2);
         const char* nq0 = tile_base(ntile, 0); const char* nq1 = tile_base(ntile, 1); const char* nq2 = tile_base(ntile, 2);
         const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
         const float* bias = p.bias + n0 + wn * 64;
+#ifdef PIPS_ASM_TRACE
+        int trv = 0;
+#define PIPS_TR_OPERAND , [tr] "+v"(trv)
+#else
+#define PIPS_TR_OPERAND
+#endif
 #define PIPS_TILE_ASM(TEXT_)                                                                                              \
         asm volatile(TEXT_                                                                                                \
-                     : [pa] "+{v[64:79]}"(pa), [pb] "+{v[80:95]}"(pb)                                                    \
+                     : [pa] "+{v[64:79]}"(pa), [pb] "+{v[80:95]}"(pb) PIPS_TR_OPERAND                                    \
                      : [ro0] "v"(rowoff[0]), [ro1] "v"(rowoff[1]), [ro2] "v"(rowoff[2]), [aoff] "v"(a_off),               \
                        [b0off] "v"(b_off[0]), [b1off] "v"(b_off[1]), [stoff] "v"(stoff), [boff] "v"(boff), [rd] "s"(sgpr(rd)), \
                        [ringend] "s"(sgpr(ringend)), [lds0] "s"(sgpr(lds0)), [wvoff] "s"(sgpr(wvoff)),                    \
@@ -146,27 +184,34 @@ __global__ __launch_bounds__(512) void gemm_bf16_gelu_asm_kernel(GemmArgs p, int
                        [nq1] "s"(sgpr(nq1)), [nq2] "s"(sgpr(nq2)), [bias] "s"(sgpr(bias)), [cb0] "s"(sgpr(cb0)),          \
                        [cb1] "s"(sgpr(cb1))                                                                               \
                      : PIPS_TILE_CLOBBER)
-        if (t == 0) {
+        if (t == 0 || !PIPS_ASM_DEFER) {
             if (last) PIPS_TILE_ASM(PIPS_TILE_TEXT_G0_R0); else PIPS_TILE_ASM(PIPS_TILE_TEXT_G0_R1);
         } else {
             if (last) PIPS_TILE_ASM(PIPS_TILE_TEXT_G1_R0); else PIPS_TILE_ASM(PIPS_TILE_TEXT_G1_R1);
         }
 #undef PIPS_TILE_ASM
+#ifdef PIPS_ASM_TRACE
+        if (blockIdx.x == 0 && wave == PIPS_ASM_TRACE_WAVE && g_asm_trace && t < 8 && lane < 52) g_asm_trace[t * 64 + lane] = (unsigned)trv;
+#endif
         rd += 2 * SUP; if (rd >= ringend) rd -= NSUP * SUP;           // eight super-stages on: 8 mod 3 = 2 buffers further
         // where the tile just parked goes: per-lane byte offset + scalar bases of its two 32-row halves
         prow0 = m0 + wm * 64 + l31; pcolh = n0 + wn * 64 + 8 * half;
         stoff = (unsigned)(((size_t)(l31)*p.ldc + 8 * half) * 2);
         cb0 = reinterpret_cast<const char*>(Cb) + ((size_t)(m0 + wm * 64) * p.ldc + n0 + wn * 64) * 2;
         cb1 = cb0 + (size_t)32 * p.ldc * 2;
-    }
-    // ---- the last tile's epilogue
+        if (!PIPS_ASM_DEFER || last) {
+            // GELU + stores of the tile just parked.  (Deferred form: only the last tile's -- the others ride between the
+            // next tile's MFMA pairs; measured slower: VALU and bf16 MFMAs do not overlap on a gfx950 SIMD,
+            // tools/mfma_valu_overlap.hip, and the interleaved form pays arbitration on top.)
 #pragma unroll
-    for (int pc = 0; pc < 8; ++pc) {
-        const int i = pc >> 2, jq = pc & 3, j = jq >> 1, q = jq & 1;
-        const u32x16& v = (2 * i + j) < 2 ? pa : pb;
-        const int b = 8 * ((2 * i + j) & 1) + 4 * q;
-        const uint2 lo = gelu_bf16x4(v[b], v[b + 1]), hi = gelu_bf16x4(v[b + 2], v[b + 3]);
-        *reinterpret_cast<uint4*>(Cb + (size_t)(prow0 + i * 32) * p.ldc + pcolh + jq * 16) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            for (int pc = 0; pc < 8; ++pc) {
+                const int i = pc >> 2, jq = pc & 3, j = jq >> 1, q = jq & 1;
+                const u32x16& v = (2 * i + j) < 2 ? pa : pb;
+                const int b = 8 * ((2 * i + j) & 1) + 4 * q;
+                const uint2 lo = gelu_bf16x4(tab, v[b], v[b + 1]), hi = gelu_bf16x4(tab, v[b + 2], v[b + 3]);
+                *reinterpret_cast<uint4*>(Cb + (size_t)(prow0 + i * 32) * p.ldc + pcolh + jq * 16) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
     }
 }
 
@@ -184,13 +229,17 @@ int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_
         set_error("gemm_bf16_asm: cannot query the device");
         return PIPS_E_LAUNCH;
     }
-    int grid = ntiles < cus ? ntiles : cus;
-    if (const char* e = getenv("PIPS_BF16_ASM_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;          // debugging
-    const size_t lds = (size_t)6 * (256 + 128) * 64;
+    (void)cus;
+    static int tpb = -1;                        // tuning hook PIPS_BF16_ASM_TPB: tiles per block (config 3: 1 / 2 / 4 ->
+    if (tpb < 0) { const char* e = getenv("PIPS_BF16_ASM_TPB"); tpb = e ? atoi(e) : 4; if (tpb < 1) tpb = 1; }   // 22.1 / 21.0 / 20.7 ms)
+    GemmArgs b = a;
+    b.swz = tpb;
+    const int grid = (ntiles + tpb - 1) / tpb;
+    const size_t lds = (size_t)6 * (256 + 128) * 64 + GELU_TAB_N * 8;     // the ring + the GELU table
     static std::atomic<unsigned long long> raised{0};
     const int rc = ensure_dynamic_lds(raised, (const void*)gemm_bf16_gelu_asm_kernel, lds);
     if (rc != PIPS_OK) return rc;
-    hipLaunchKernelGGL(gemm_bf16_gelu_asm_kernel, dim3(grid), dim3(512), lds, st, a, tiles_m, ntiles);
+    hipLaunchKernelGGL(gemm_bf16_gelu_asm_kernel, dim3(grid), dim3(512), lds, st, b, tiles_m, ntiles);
     PIPS_CHECK_LAUNCH("gemm_bf16_gelu_asm_kernel");
     return PIPS_OK;
 }

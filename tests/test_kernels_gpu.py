@@ -381,6 +381,37 @@ def test_mixer(P, split, weights_raw, arenas):
     assert float((out - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K,epi,out_bf16", [
+    (16384, 2048, 512, 1, True),       # config-3 up-projection: the generated-assembly kernel (gemm_bf16_asm.hip), 4 tiles per block
+    (1280, 2048, 512, 1, True),        # 80 tiles: below its threshold -> register-staged kernel, same contract
+    (16384, 512, 2048, 2, False),      # config-3 down-projection
+    (4096, 512, 544, 0, False),        # input projection: fp32 A, 32-element K blocks
+])
+def test_gemm_bf16(M, N, K, epi, out_bf16):
+    """pips_gemm_bf16 against torch: bf16 operands, fp32 accumulation, exact GELU, result rounded to the output type.  (The
+    generated-assembly kernel rounds the Linear's output to bf16 before the GELU, as autocast does; the register-staged one
+    feeds the fp32 accumulator to it: one or two bf16 roundings, |gelu'| <= 1.13 -> both within 1.2e-2 of the fp32 GELU of the
+    fp32 pre-activation, relative to max(|gelu|, 0.25).)"""
+    from pips_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a_bf16 = epi != 0
+    A = torch.randn(M, K, generator=g).to(DEV)
+    A = A.bfloat16() if a_bf16 else A
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV).bfloat16()
+    b = torch.randn(N, generator=g).to(DEV)
+    R = torch.randn(M, N, generator=g).to(DEV) if epi == 2 else None
+    out = ops.gemm_bf16(A, W, b, epi=epi, R=R, out_bf16=out_bf16).float()
+    pre = A.bfloat16().float() @ W.float().t() + b
+    if epi == 1:
+        ref = torch.nn.functional.gelu(pre)
+        err = (out - ref).abs() / ref.abs().clamp(min=0.25)
+        print(f"gemm_bf16 GELU M={M}: max rel err {float(err.max()):.3e} mean {float(err.mean()):.3e}")
+        assert float(err.max()) < 1.2e-2 and float(err.mean()) < 2e-3
+    else:
+        ref = pre + (R if R is not None else 0)
+        assert float((out - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("P", [32, 256, 2048])
 def test_mixer_bf16_operands(P, weights_raw, arenas):
     """bf16 MFMA operands (config 3): against the fp32 oracle at bf16-level tolerance, and much

@@ -8,7 +8,8 @@ as bf16 pairs in v[64:95]) between the MFMA pairs.  Straight-line code, fixed re
 Variants (one text each): GELU of a parked tile on / off  x  the ring runs on into the next tile / stops at this one.
 
 Registers (clobbered by the statement unless noted):
-    v[0:63]      accumulators acc[i][j] -> v[16*(2i+j) : +15]       (C^T: lane = output row, registers = columns)
+    a[0:63]      accumulators acc[i][j] -> a[16*(2i+j) : +15]  (C^T: lane = output row, registers = columns) -- AccVGPRs:
+                 with the accumulators in ArchVGPRs the MFMA passes and the GELU's VALU instructions did not overlap
     v[64:95]     the parked tile, bf16 pairs: prev[i][j][d] -> v[64 + 8*(2i+j) + d]   (operands, live across statements)
     v[96:111]    A fragments fa[kk][i] -> v[96 + 4*(2kk+i) : +3];  v[112:127] W fragments fb[kk][j]
     v[128:139]   GELU: x0 x1 t0 t1 p0 p1 (pairs);  v[140:143] the 8 bf16 of a piece;  v[144:146] fragment addresses
@@ -18,6 +19,7 @@ Registers (clobbered by the statement unless noted):
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+TRACE = os.environ.get("PIPS_GEN_TRACE", "") == "1"   # tuning builds: s_memtime stamps in the lanes of %[tr]
 OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "gemm_bf16_tile_asm.inc"))
 
 STAGE = (256 + 128) * 64           # bytes of one 32-K stage
@@ -30,7 +32,7 @@ RA, RB0, RB1 = 144, 145, 146
 AX, B0X, B1X = 148, 149, 150       # the kk = 1 offsets (slot ^ 2 = byte offset ^ 32)
 C4V = 156
 S_C5, S_C3, S_C2, S_C1, S_C0, S_TMAX, S_MH = 40, 42, 44, 46, 48, 50, 52
-S_RD, S_T, S_T2 = 54, 56, 57
+S_RD, S_T, S_T2, S_TR = 54, 56, 57, 58
 DV = 153                           # lane offset + K offset of a DMA instruction
 # degree-5 exponent polynomial of the bf16-output GELU (gemm_bf16_dma.hip), c0..c5
 COEF = [-1.150685204e+00, -4.602978599e-01, -5.192063601e-02, 7.452824686e-03, -6.529359078e-04, 2.554670494e-05]
@@ -49,6 +51,15 @@ class Asm:
 
     def __call__(self, s):
         self.lines.append(s)
+
+
+def probe(a, idx):
+    """trace builds: lane idx of %[tr] = low word of s_memtime (costs an lgkmcnt(0))"""
+    if not TRACE:
+        return
+    a("s_memtime s[%d:%d]" % (S_TR, S_TR + 1))
+    a("s_waitcnt lgkmcnt(0)")
+    a("v_writelane_b32 %%[tr], s%d, %d" % (S_TR, idx))
 
 
 def acc(i, j):
@@ -83,7 +94,7 @@ def reads(a, kk, sbase_expr_reg, stage_off):
 def mfma2(a, kk, i):
     for j in range(2):
         c = acc(i, j)
-        a("v_mfma_f32_32x32x16_bf16 v[%d:%d], v[%d:%d], v[%d:%d], v[%d:%d]" %
+        a("v_mfma_f32_32x32x16_bf16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]" %
           (c, c + 15, fb(kk, j), fb(kk, j) + 3, fa(kk, i), fa(kk, i) + 3, c, c + 15))
 
 
@@ -167,15 +178,17 @@ def tile(gel, runon):
     a("v_xor_b32 v%d, 32, %%[b1off]" % B1X)
     a("s_mov_b32 s%d, %%[rd]" % S_RD)                 # LDS address of the super-stage this tile starts with
     # ---- accumulators start from the bias: acc[0][j][4g..] <- bias[cols], copied to acc[1][j]
+    probe(a, 0)
     for j in range(2):
         for g in range(4):
             off = ((2 * j + (g >> 1)) * 16 + 4 * (g & 1)) * 4
             r = acc(0, j) + 4 * g
-            a("global_load_dwordx4 v[%d:%d], %%[boff], %%[bias] offset:%d" % (r, r + 3, off))
+            a("global_load_dwordx4 a[%d:%d], %%[boff], %%[bias] offset:%d" % (r, r + 3, off))
     a("s_waitcnt vmcnt(0)")                           # (also: every super-stage issued so far has landed for this wave)
+    probe(a, 1)
     for j in range(2):
         for r in range(16):
-            a("v_mov_b32 v%d, v%d" % (acc(1, j) + r, acc(0, j) + r))
+            a("v_accvgpr_mov_b32 a%d, a%d" % (acc(1, j) + r, acc(0, j) + r))
     # ---- fragments of K block a of super-stage 0 (landed and published by the previous tile's last barrier)
     reads(a, 0, S_RD, 0)
     reads(a, 1, S_RD, 0)
@@ -187,6 +200,7 @@ def tile(gel, runon):
         do_a = Xa <= 7 or runon
         do_b = Xb <= 7 or runon
         hh = 2 * ks
+        probe(a, 2 + 4 * ks)
         # ================= K block a
         if do_a:                                      # LDS base of stage Xa's buffer + this wave's piece: (rd + 2 SUP) mod ring
             a("s_add_u32 s%d, s%d, %d" % (S_T2, S_RD, 2 * SUP))
@@ -202,6 +216,7 @@ def tile(gel, runon):
             dma(a, Xa, 1, 0, Xa >= 8)
         if gel:
             gelu_step(a, 1)
+        probe(a, 44 + ks)
         mfma2(a, 0, 1)
         if do_a:
             dma(a, Xa, 1, 1, Xa >= 8)
@@ -220,6 +235,7 @@ def tile(gel, runon):
             gelu_pack(a, OUTR)
         reads(a, 1, S_RD, STAGE)                      # block b, kk = 1
         # ================= K block b
+        probe(a, 3 + 4 * ks)
         if gel:
             gelu_load(a, hh + 1)
         a("s_waitcnt lgkmcnt(4)")
@@ -230,11 +246,14 @@ def tile(gel, runon):
         if gel:
             gelu_step(a, 2)
         a("s_waitcnt lgkmcnt(0)")                     # this wave is done reading super-stage ks
+        probe(a, 4 + 4 * ks)
         if ks < 7 or runon:
             vm_wait(a, ks + 1)                        # its part of super-stage ks+1 has landed
         else:
             a("s_waitcnt vmcnt(0)")
+        probe(a, 36 + ks)
         a("s_barrier")
+        probe(a, 5 + 4 * ks)
         if do_b:                                      # the buffer super-stage ks just left is refilled with stage ks+3
             a("s_add_u32 s%d, s%d, %%[wvoff]" % (S_T2, S_RD))
         # advance the ring pointer
@@ -260,13 +279,18 @@ def tile(gel, runon):
             a.vm.append(("st",))
         if ks < 7:
             reads(a, 1, S_RD, 0)                      # next block a, kk = 1
+    probe(a, 34)
     # ---- park the tile: prev <- bf16 pairs of the accumulators (the MFMAs have to have written them back)
     a("s_nop 15")
     a("s_nop 15")
     for i in range(2):
         for j in range(2):
             for d in range(8):
-                a("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (PREV + 8 * (2 * i + j) + d, acc(i, j) + 2 * d, acc(i, j) + 2 * d + 1))
+                a("v_accvgpr_read_b32 v%d, a%d" % (X0 + 2 * d, acc(i, j) + 2 * d))
+                a("v_accvgpr_read_b32 v%d, a%d" % (X0 + 2 * d + 1, acc(i, j) + 2 * d + 1))
+            for d in range(8):
+                a("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (PREV + 8 * (2 * i + j) + d, X0 + 2 * d, X0 + 2 * d + 1))
+    probe(a, 35)
     return a
 
 
@@ -280,7 +304,7 @@ def main():
                 out.append('    "%s\\n\\t"' % ins + (" \\" if i + 1 < len(a.lines) else ""))
             out.append("")
             print("variant gelu=%d runon=%d: %d instructions" % (gel, runon, len(a.lines)))
-    clob = ['"v%d"' % i for i in list(range(0, 64)) + list(range(96, 160))] + ['"s%d"' % i for i in range(40, 62)]
+    clob = ['"a%d"' % i for i in range(64)] + ['"v%d"' % i for i in range(96, 160)] + ['"s%d"' % i for i in range(40, 62)]
     out.append('#define PIPS_TILE_CLOBBER "memory", "scc", "vcc", ' + ", ".join(clob))
     out.append("")
     with open(OUT, "w") as f:
