@@ -215,27 +215,99 @@ __global__ __launch_bounds__(512) void gemm_bf16_gelu_asm_kernel(GemmArgs p, int
     }
 }
 
+// The down-projection (K = 2048, residual, fp32 output): one 256x128 tile per block, the same ring / fragment / MFMA
+// schedule as a LOOP over the super-stages inside one assembly statement (PIPS_TILE_TEXT_RES); the accumulators start
+// from the residual tile, the bias is added at the end, 16-byte fp32 stores in the natural column order.
+__global__ __launch_bounds__(512) void gemm_bf16_res_asm_kernel(GemmArgs p, int tiles_m, int ntiles) {
+    constexpr int BM = 256, BN = 128, WGN = 2;
+    constexpr int ROWB = 64, STAGE = (BM + BN) * ROWB, SUP = 2 * STAGE, NSUP = 3, LPW = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+
+    unsigned rowoff[LPW];
+    const char* qbase[LPW];
+#pragma unroll
+    for (int q = 0; q < LPW; ++q) {
+        const int g0 = (wave * LPW + q) * 16;
+        const int row = (g0 < BM ? g0 : g0 - BM) + (lane >> 2);
+        const int slot = (lane & 3) ^ ((row >> 2) & 3);
+        rowoff[q] = (unsigned)row * (unsigned)(g0 < BM ? p.lda : p.K) * 2u + slot * 16;
+        qbase[q] = g0 < BM ? Ab + (size_t)m0 * p.lda * 2 : Wb + (size_t)n0 * p.K * 2;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned wvoff = wave * (LPW * 1024), ringend = lds0 + NSUP * SUP;
+#pragma unroll
+    for (int X = 0; X < 3; ++X)
+#pragma unroll
+        for (int u = 0; u < (X < 2 ? 2 : 1); ++u)
+#pragma unroll
+            for (int q = 0; q < LPW; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(qbase[q] + rowoff[q] + X * 128 + u * 64),
+                                                 (lptr_t)(smem + X * SUP + u * STAGE + wave * (LPW * 1024) + q * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const unsigned a_off = (wm * 64 + l31) * ROWB + ((half ^ ((l31 >> 2) & 3)) * 16);
+    unsigned b_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int brow = wn * 64 + j * 32 + l31;
+        b_off[j] = (BM + brow) * ROWB + ((half ^ ((brow >> 2) & 3)) * 16);
+    }
+    const unsigned boff = 4 * half * 4;
+    const unsigned roff = (unsigned)(((size_t)l31 * p.ldr + 4 * half) * 4), soff = (unsigned)(((size_t)l31 * p.ldc + 4 * half) * 4);
+    const float* bias = p.bias + n0 + wn * 64;
+    const char* rb0 = reinterpret_cast<const char*>(p.R) + ((size_t)(m0 + wm * 64) * p.ldr + n0 + wn * 64) * 4;
+    const char* rb1 = rb0 + (size_t)32 * p.ldr * 4;
+    const char* cb0 = reinterpret_cast<const char*>(p.C) + ((size_t)(m0 + wm * 64) * p.ldc + n0 + wn * 64) * 4;
+    const char* cb1 = cb0 + (size_t)32 * p.ldc * 4;
+    const int nks = p.K / 64;
+    asm volatile(PIPS_TILE_TEXT_RES
+                 :
+                 : [ro0] "v"(rowoff[0]), [ro1] "v"(rowoff[1]), [ro2] "v"(rowoff[2]), [aoff] "v"(a_off), [b0off] "v"(b_off[0]),
+                   [b1off] "v"(b_off[1]), [roff] "v"(roff), [soff] "v"(soff), [boff] "v"(boff), [rd] "s"(sgpr(lds0)),
+                   [ringend] "s"(sgpr(ringend)), [lds0] "s"(sgpr(lds0)), [wvoff] "s"(sgpr(wvoff)), [nks] "s"(sgpr((unsigned)nks)),
+                   [cq0] "s"(sgpr(qbase[0])), [cq1] "s"(sgpr(qbase[1])), [cq2] "s"(sgpr(qbase[2])), [bias] "s"(sgpr(bias)),
+                   [rb0] "s"(sgpr(rb0)), [rb1] "s"(sgpr(rb1)), [cb0] "s"(sgpr(cb0)), [cb1] "s"(sgpr(cb1))
+                 : PIPS_TILE_RES_CLOBBER);
+}
+
 // returns PIPS_OK if the problem was taken, 1 if the caller should use the register-staged kernel of gemm_bf16.hip
 int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st) {
-    static int mode = -1;                       // tuning hook PIPS_BF16_ASM: 0 = off, 1 (default) = on
+    static int mode = -1;                       // tuning hook PIPS_BF16_ASM: 0 = off, 1 (default) = on, 2 = on for any tile count
     if (mode < 0) { const char* e = getenv("PIPS_BF16_ASM"); mode = e ? atoi(e) : 1; }
-    if (!mode || !a_bf16 || !out_bf16 || (a.epi & 0xff) != EPI_GELU || a.K != 512 || a.lda % 8 != 0 || a.ldc % 8 != 0 ||
-        a.bias == nullptr)
-        return 1;
+    const int epi = a.epi & 0xff;
+    if (!mode || !a_bf16 || a.lda % 8 != 0 || a.ldc % 8 != 0 || a.bias == nullptr || a.K % 64 != 0) return 1;
     if (a.M % 256 != 0 || a.N % 128 != 0 || (mode != 2 && (long)(a.M / 256) * (a.N / 128) < 256)) return 1;   // (2: debugging)
     const int tiles_m = a.M / 256, ntiles = tiles_m * (a.N / 128);
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-        set_error("gemm_bf16_asm: cannot query the device");
-        return PIPS_E_LAUNCH;
+    const size_t ring = (size_t)6 * (256 + 128) * 64;
+    if (epi == EPI_RESIDUAL && !out_bf16 && a.R != nullptr && a.ldr % 4 == 0 && a.K >= 256 &&
+        (unsigned long long)a.M * a.ldr * 4ull < (1ull << 32) && (unsigned long long)a.M * a.ldc * 4ull < (1ull << 32)) {
+        static int res = -1;                    // tuning hook PIPS_BF16_ASM_RES=0: down-projection on the register-staged kernel
+        if (res < 0) { const char* e = getenv("PIPS_BF16_ASM_RES"); res = e ? atoi(e) : 1; }
+        if (!res) return 1;
+        static std::atomic<unsigned long long> raised_r{0};
+        const int rc = ensure_dynamic_lds(raised_r, (const void*)gemm_bf16_res_asm_kernel, ring);
+        if (rc != PIPS_OK) return rc;
+        hipLaunchKernelGGL(gemm_bf16_res_asm_kernel, dim3(ntiles), dim3(512), ring, st, a, tiles_m, ntiles);
+        PIPS_CHECK_LAUNCH("gemm_bf16_res_asm_kernel");
+        return PIPS_OK;
     }
-    (void)cus;
+    if (!out_bf16 || epi != EPI_GELU || a.K != 512) return 1;
     static int tpb = -1;                        // tuning hook PIPS_BF16_ASM_TPB: tiles per block (config 3: 1 / 2 / 4 ->
     if (tpb < 0) { const char* e = getenv("PIPS_BF16_ASM_TPB"); tpb = e ? atoi(e) : 4; if (tpb < 1) tpb = 1; }   // 22.1 / 21.0 / 20.7 ms)
     GemmArgs b = a;
     b.swz = tpb;
     const int grid = (ntiles + tpb - 1) / tpb;
-    const size_t lds = (size_t)6 * (256 + 128) * 64 + GELU_TAB_N * 8;     // the ring + the GELU table
+    const size_t lds = ring + GELU_TAB_N * 8;     // the ring + the GELU table
     static std::atomic<unsigned long long> raised{0};
     const int rc = ensure_dynamic_lds(raised, (const void*)gemm_bf16_gelu_asm_kernel, lds);
     if (rc != PIPS_OK) return rc;

@@ -33,6 +33,7 @@ AX, B0X, B1X = 148, 149, 150       # the kk = 1 offsets (slot ^ 2 = byte offset 
 C4V = 156
 S_C5, S_C3, S_C2, S_C1, S_C0, S_TMAX, S_MH = 40, 42, 44, 46, 48, 50, 52
 S_RD, S_T, S_T2, S_TR = 54, 56, 57, 58
+S_K, S_CNT = 60, 61                # looped tile: K byte offset of the current super-stage, iterations left
 DV = 153                           # lane offset + K offset of a DMA instruction
 # degree-5 exponent polynomial of the bf16-output GELU (gemm_bf16_dma.hip), c0..c5
 COEF = [-1.150685204e+00, -4.602978599e-01, -5.192063601e-02, 7.452824686e-03, -6.529359078e-04, 2.554670494e-05]
@@ -112,6 +113,14 @@ def dma(a, X, u, q, nxt):
         a("s_nop 0")
         a("global_load_lds_dwordx4 %%[ro%d], %%[%sq%d]" % (q, tile, q))
     a.vm.append(("dma", X))
+
+
+def dma_k(a, ahead, u, q):
+    """the same inside the K loop of the looped tile: super-stage ks + ahead, K byte offset s[S_K] + ahead*128 + u*64"""
+    a("s_add_u32 m0, s%d, %d" % (S_T2, u * STAGE + q * 1024))
+    a("s_add_u32 s%d, s%d, %d" % (S_T, S_K, ahead * 128 + u * 64))
+    a("v_add_u32 v%d, s%d, %%[ro%d]" % (DV, S_T, q))
+    a("global_load_lds_dwordx4 v%d, %%[cq%d]" % (DV, q))
 
 
 def gelu_load(a, hh):
@@ -294,6 +303,100 @@ def tile(gel, runon):
     return a
 
 
+def super_block(a, do_a, do_b, nxt_reads, vmcnt):
+    """one super-stage of the looped tile (no GELU): K blocks a and b"""
+    if do_a:
+        a("s_add_u32 s%d, s%d, %d" % (S_T2, S_RD, 2 * SUP))
+        a("s_sub_u32 s%d, s%d, %d" % (S_T, S_T2, NSUP * SUP))
+        a("s_cmp_ge_u32 s%d, %%[ringend]" % S_T2)
+        a("s_cselect_b32 s%d, s%d, s%d" % (S_T2, S_T, S_T2))
+        a("s_add_u32 s%d, s%d, %%[wvoff]" % (S_T2, S_T2))
+    a("s_waitcnt lgkmcnt(4)")
+    mfma2(a, 0, 0)
+    if do_a:
+        dma_k(a, 2, 1, 0)
+    mfma2(a, 0, 1)
+    if do_a:
+        dma_k(a, 2, 1, 1)
+    a("s_waitcnt lgkmcnt(0)")
+    reads(a, 0, S_RD, STAGE)
+    mfma2(a, 1, 0)
+    if do_a:
+        dma_k(a, 2, 1, 2)
+    mfma2(a, 1, 1)
+    reads(a, 1, S_RD, STAGE)
+    a("s_waitcnt lgkmcnt(4)")
+    mfma2(a, 0, 0)
+    mfma2(a, 0, 1)
+    a("s_waitcnt lgkmcnt(0)")
+    a("s_waitcnt vmcnt(%d)" % vmcnt)
+    a("s_barrier")
+    if do_b:
+        a("s_add_u32 s%d, s%d, %%[wvoff]" % (S_T2, S_RD))
+    a("s_add_u32 s%d, s%d, %d" % (S_RD, S_RD, SUP))
+    a("s_cmp_ge_u32 s%d, %%[ringend]" % S_RD)
+    a("s_cselect_b32 s%d, %%[lds0], s%d" % (S_RD, S_RD))
+    if nxt_reads:
+        reads(a, 0, S_RD, 0)
+    mfma2(a, 1, 0)
+    if do_b:
+        dma_k(a, 3, 0, 0)
+        dma_k(a, 3, 0, 1)
+    mfma2(a, 1, 1)
+    if do_b:
+        dma_k(a, 3, 0, 2)
+    if nxt_reads:
+        reads(a, 1, S_RD, 0)
+
+
+BIASV = 160                        # v[160:191]: the wave's 64 bias values (natural column order), looped tile
+
+
+def tile_res():
+    """ONE 256x128 tile of the down-projection: K loop over %[nks] super-stages (>= 4), accumulators start from the
+    residual tile, bias added at the end, fp32 stores.  Natural column order (lane = row, registers 4g..4g+3 = columns
+    j*32 + 8g + 4*half ..+3): 16-byte stores, 32 contiguous bytes per row."""
+    a = Asm()
+    a("v_xor_b32 v%d, 32, %%[aoff]" % AX)
+    a("v_xor_b32 v%d, 32, %%[b0off]" % B0X)
+    a("v_xor_b32 v%d, 32, %%[b1off]" % B1X)
+    a("s_mov_b32 s%d, %%[rd]" % S_RD)
+    for i in range(2):
+        for j in range(2):
+            for g in range(4):
+                r = acc(i, j) + 4 * g
+                a("global_load_dwordx4 a[%d:%d], %%[roff], %%[rb%d] offset:%d" % (r, r + 3, i, (j * 32 + 8 * g) * 4))
+    for j in range(2):
+        for g in range(4):
+            r = BIASV + 16 * j + 4 * g
+            a("global_load_dwordx4 v[%d:%d], %%[boff], %%[bias] offset:%d" % (r, r + 3, (j * 32 + 8 * g) * 4))
+    a("s_waitcnt vmcnt(0)")
+    reads(a, 0, S_RD, 0)
+    reads(a, 1, S_RD, 0)
+    a("s_mov_b32 s%d, 0" % S_K)
+    a("s_sub_u32 s%d, %%[nks], 3" % S_CNT)
+    a("1:")
+    super_block(a, True, True, True, 2 * 3)
+    a("s_add_u32 s%d, s%d, 128" % (S_K, S_K))
+    a("s_sub_u32 s%d, s%d, 1" % (S_CNT, S_CNT))
+    a("s_cmp_lg_u32 s%d, 0" % S_CNT)
+    a("s_cbranch_scc1 1b")
+    super_block(a, True, False, True, 2 * 3)          # ks = nks-3: the second half of the last super-stage goes out
+    super_block(a, False, False, True, 0)             # ks = nks-2
+    super_block(a, False, False, False, 0)            # ks = nks-1
+    a("s_nop 15")
+    a("s_nop 15")
+    for i in range(2):
+        for j in range(2):
+            for r in range(16):
+                a("v_accvgpr_read_b32 v%d, a%d" % (X0 + r, acc(i, j) + r))
+            for r in range(16):
+                a("v_add_f32 v%d, v%d, v%d" % (X0 + r, X0 + r, BIASV + 16 * j + r))
+            for g in range(4):
+                a("global_store_dwordx4 %%[soff], v[%d:%d], %%[cb%d] offset:%d" % (X0 + 4 * g, X0 + 4 * g + 3, i, (j * 32 + 8 * g) * 4))
+    return a
+
+
 def main():
     out = ["// GENERATED by tools/gen_gemm_bf16_asm.py -- do not edit.", ""]
     for gel in (0, 1):
@@ -306,6 +409,15 @@ def main():
             print("variant gelu=%d runon=%d: %d instructions" % (gel, runon, len(a.lines)))
     clob = ['"a%d"' % i for i in range(64)] + ['"v%d"' % i for i in range(96, 160)] + ['"s%d"' % i for i in range(40, 62)]
     out.append('#define PIPS_TILE_CLOBBER "memory", "scc", "vcc", ' + ", ".join(clob))
+    out.append("")
+    a = tile_res()
+    out.append("#define PIPS_TILE_TEXT_RES \\")
+    for i, ins in enumerate(a.lines):
+        out.append('    "%s\\n\\t"' % ins + (" \\" if i + 1 < len(a.lines) else ""))
+    out.append("")
+    print("looped residual tile: %d instructions" % len(a.lines))
+    clob = ['"a%d"' % i for i in range(64)] + ['"v%d"' % i for i in range(96, 192)] + ['"s%d"' % i for i in range(40, 62)]
+    out.append('#define PIPS_TILE_RES_CLOBBER "memory", "scc", "vcc", ' + ", ".join(clob))
     out.append("")
     with open(OUT, "w") as f:
         f.write("\n".join(out))
