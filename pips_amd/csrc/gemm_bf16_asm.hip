@@ -252,8 +252,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_res_asm_kernel(GemmArgs p, int 
             for (int q = 0; q < LPW; ++q)
                 __builtin_amdgcn_global_load_lds((gptr_t)(qbase[q] + rowoff[q] + X * 128 + u * 64),
                                                  (lptr_t)(smem + X * SUP + u * STAGE + wave * (LPW * 1024) + q * 1024), 16, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // (no wait here: the statement loads the residual tile and the bias first, then waits for everything and barriers)
 
     const unsigned a_off = (wm * 64 + l31) * ROWB + ((half ^ ((l31 >> 2) & 3)) * 16);
     unsigned b_off[2];

@@ -370,7 +370,8 @@ def tile_res():
         for g in range(4):
             r = BIASV + 16 * j + 4 * g
             a("global_load_dwordx4 v[%d:%d], %%[boff], %%[bias] offset:%d" % (r, r + 3, (j * 32 + 8 * g) * 4))
-    a("s_waitcnt vmcnt(0)")
+    a("s_waitcnt vmcnt(0)")                           # the residual tile, the bias AND the C++ prologue's three super-stages
+    a("s_barrier")                                    # (their round trips overlap; the barrier publishes the stages)
     reads(a, 0, S_RD, 0)
     reads(a, 1, S_RD, 0)
     a("s_mov_b32 s%d, 0" % S_K)
