@@ -26,7 +26,11 @@
 #include <cstdlib>
 
 #ifndef PIPS_ASM_DEFER
-#define PIPS_ASM_DEFER 0     // 1: a tile's GELU / stores ride between the next tile's MFMA pairs (the G1 texts)
+#define PIPS_ASM_DEFER 0     // 1: a tile's GELU / stores ride between the next tile's MFMA pairs (the G1 texts: regenerate
+#endif                       // the .inc with PIPS_GEN_DEFER=1)
+#if !PIPS_ASM_DEFER
+#define PIPS_TILE_TEXT_G1_R0 PIPS_TILE_TEXT_G0_R0
+#define PIPS_TILE_TEXT_G1_R1 PIPS_TILE_TEXT_G0_R1
 #endif
 #ifndef PIPS_TILE_INC
 #define PIPS_TILE_INC "gemm_bf16_tile_asm.inc"      // tuning builds point this at a traced copy (PIPS_GEN_TRACE=1)

@@ -5,7 +5,9 @@ instructions of the ring three super-stages ahead, and the GELU / bf16 conversio
 as bf16 pairs in v[64:95]) between the MFMA pairs.  Straight-line code, fixed registers: the C++ form of the same loop
 (gemm_bf16_dma.hip) either carried ~25 scalar branches per super-stage or, unrolled, spilled (tools/experiments/README.md).
 
-Variants (one text each): GELU of a parked tile on / off  x  the ring runs on into the next tile / stops at this one.
+Variants (one text each): the ring runs on into the next tile / stops at this one; with PIPS_GEN_DEFER=1 also the
+forms that carry the GELU of the parked tile (the measured-slower alternative, see gemm_bf16_asm.hip); and the looped
+tile of the down-projection (tile_res).
 
 Registers (clobbered by the statement unless noted):
     a[0:63]      accumulators acc[i][j] -> a[16*(2i+j) : +15]  (C^T: lane = output row, registers = columns) -- AccVGPRs:
@@ -19,6 +21,8 @@ Registers (clobbered by the statement unless noted):
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+DEFER = os.environ.get("PIPS_GEN_DEFER", "") == "1"   # also emit the texts with the parked tile's GELU between the next tile's MFMA
+                                                       # pairs (build gemm_bf16_asm.hip with -DPIPS_ASM_DEFER=1; measured slower)
 TRACE = os.environ.get("PIPS_GEN_TRACE", "") == "1"   # tuning builds: s_memtime stamps in the lanes of %[tr]
 OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "gemm_bf16_tile_asm.inc"))
 
@@ -400,7 +404,7 @@ def tile_res():
 
 def main():
     out = ["// GENERATED by tools/gen_gemm_bf16_asm.py -- do not edit.", ""]
-    for gel in (0, 1):
+    for gel in ((0, 1) if DEFER else (0,)):
         for runon in (0, 1):
             a = tile(gel, runon)
             out.append("#define PIPS_TILE_TEXT_G%d_R%d \\" % (gel, runon))
