@@ -307,9 +307,16 @@ int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_
     if (!out_bf16 || epi != EPI_GELU || a.K != 512) return 1;
     static int tpb = -1;                        // tuning hook PIPS_BF16_ASM_TPB: tiles per block (config 3: 1 / 2 / 4 ->
     if (tpb < 0) { const char* e = getenv("PIPS_BF16_ASM_TPB"); tpb = e ? atoi(e) : 4; if (tpb < 1) tpb = 1; }   // 22.1 / 21.0 / 20.7 ms)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        set_error("gemm_bf16_asm: cannot query the device");
+        return PIPS_E_LAUNCH;
+    }
+    int t = tpb;                                // ... but never fewer blocks than CUs
+    while (t > 1 && (ntiles + t - 1) / t < cus) --t;
     GemmArgs b = a;
-    b.swz = tpb;
-    const int grid = (ntiles + tpb - 1) / tpb;
+    b.swz = t;
+    const int grid = (ntiles + t - 1) / t;
     const size_t lds = ring + GELU_TAB_N * 8;     // the ring + the GELU table
     static std::atomic<unsigned long long> raised{0};
     const int rc = ensure_dynamic_lds(raised, (const void*)gemm_bf16_gelu_asm_kernel, lds);

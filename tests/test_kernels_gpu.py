@@ -383,6 +383,7 @@ def test_mixer(P, split, weights_raw, arenas):
 
 @pytest.mark.parametrize("M,N,K,epi,out_bf16", [
     (16384, 2048, 512, 1, True),       # config-3 up-projection: the generated-assembly kernel (gemm_bf16_asm.hip), 4 tiles per block
+    (8192, 2048, 512, 1, True),        # 512 tiles: the same kernel with 2 tiles per block
     (1280, 2048, 512, 1, True),        # 80 tiles: below its threshold -> register-staged kernel, same contract
     (16384, 512, 2048, 2, False),      # config-3 down-projection
     (4096, 512, 544, 0, False),        # input projection: fp32 A, 32-element K blocks
