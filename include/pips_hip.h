@@ -223,6 +223,12 @@ int    pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin,
 int    pips_gemm_bf16(const void* A, int a_bf16, int lda, const void* W, const float* bias, void* C, int out_bf16, int ldc,
                       int M, int N, int K, int epi, const float* R, int ldr, void* stream);
 
+/* pips_conv_nhwc_f32 with bf16 MFMA operands: the fp32 map is rounded to bf16 while it is staged, wgt_bf16 is the
+ * round-to-nearest-even bf16 copy of the [Cout][kh][kw][Cin] weights; fp32 accumulation and output, same stats. */
+int    pips_conv_nhwc_bf16(const float* in, int F, int H, int W, int Cin,
+                           const void* wgt_bf16, const float* bias, int Cout, int ksize, int cstride, int pad,
+                           float* out, float* stats, int* tiles_m_host, void* stream);
+
 /* Split-bf16 ("bf16x3") building blocks: fp32-grade results from the bf16 matrix cores.  Every
  * fp32 operand is split exactly into three bf16 terms and each product is formed from six exact
  * bf16 products accumulated in fp32 (same F.linear / F.conv2d contracts as the two calls above).

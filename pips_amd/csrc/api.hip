@@ -261,6 +261,14 @@ int pips_conv_nhwc_f32x3(const float* in, int F, int H, int W, int Cin, const vo
                      (hipStream_t)stream, 2);
 }
 
+int pips_conv_nhwc_bf16(const float* in, int F, int H, int W, int Cin, const void* wgt_bf16, const float* bias,
+                        int Cout, int ksize, int cstride, int pad, float* out, float* stats, int* tiles_m_host,
+                        void* stream) {
+    PIPS_CHECK_ARG(in && wgt_bf16 && out, "conv_bf16: null pointer");
+    return conv_nhwc(in, F, H, W, Cin, (const float*)wgt_bf16, bias, Cout, ksize, cstride, pad, out, stats, tiles_m_host,
+                     (hipStream_t)stream, 1);
+}
+
 int pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin, const float* wgt, const float* bias,
                        int Cout, int ksize, int cstride, int pad, float* out, float* stats, int* tiles_m_host,
                        void* stream) {

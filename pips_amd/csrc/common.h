@@ -180,6 +180,8 @@ int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
 // bf16-operand GEMM (gemm_bf16.hip): A fp32 or bf16, W bf16, C fp32 or bf16; pointers passed as float*
 int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
 int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
+// 3x3 / 64 -> 64 channels with the weights of all taps and the tile's halo patch resident in LDS (conv_bf16_c64.hip); 1 = not taken
+int launch_conv3x3_c64_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
 // the config-3 up-projection as persistent blocks with a generated-assembly tile body (gemm_bf16_asm.hip); 1 = not taken
 int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
 // split-bf16 (bf16x3) fp32-grade GEMM / conv (gemm_x3.hip): A fp32, W = three bf16 planes [3][N][K]

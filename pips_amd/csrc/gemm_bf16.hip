@@ -355,6 +355,10 @@ static int launch_conv_tile(const GemmArgs& a, int frames, hipStream_t st) {
 // idle quarter costs nothing at the bf16 matrix rate).
 int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) {
     PIPS_CHECK_ARG(a.Cin % 32 == 0 && a.K == a.KH * a.KW * a.Cin, "conv_bf16: Cin %% 32, K = kh*kw*Cin");
+    {
+        const int rc = launch_conv3x3_c64_bf16(a, frames, tiles_m, st);     // 64 -> 64, 3x3: weights + halo patch in LDS
+        if (rc != 1) return rc;
+    }
     const bool k64 = a.Cin % 64 == 0;
     const int bn = a.N <= 64 ? 64 : 128;
     const long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.N, bn) * frames;

@@ -298,6 +298,30 @@ def conv_nhwc(x, w_packed, bias, ksize, stride, pad, want_stats=False):
     return out
 
 
+def conv_nhwc_bf16(x, w_bf16, bias, ksize, stride, pad, want_stats=False):
+    """conv_nhwc() with bf16 MFMA operands; w_bf16 = w_packed.bfloat16() of shape (Cout, k, k, Cin)."""
+    lib = _lib.load()
+    x = _f32(x)
+    assert w_bf16.dtype == torch.bfloat16
+    w_bf16 = w_bf16.contiguous()
+    F, H, W, Cin = x.shape
+    Cout = w_bf16.shape[0]
+    Ho = (H + 2 * pad - ksize) // stride + 1
+    Wo = (W + 2 * pad - ksize) // stride + 1
+    out = torch.empty(F, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats:
+        stats = torch.zeros(F, 2 * ((Ho * Wo + 63) // 64) + 4, Cout, 4, dtype=torch.float32, device=x.device)
+    tiles = C.c_int(0)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pips_conv_nhwc_bf16(_lib.ptr(x), F, H, W, Cin, _lib.ptr(w_bf16), _lib.ptr(bias), Cout, ksize, stride,
+                                           pad, _lib.ptr(out), _lib.ptr(stats), C.byref(tiles), _stream()),
+                   "pips_conv_nhwc_bf16")
+    if want_stats:
+        return out, stats.view(-1)[: F * tiles.value * Cout * 4].view(F, tiles.value, Cout, 4)
+    return out
+
+
 def conv_nhwc_x3(x, w3, bias, ksize, stride, pad, want_stats=False):
     """conv_nhwc() on the split-bf16 path; w3 = split_bf16x3(w_packed)."""
     lib = _lib.load()

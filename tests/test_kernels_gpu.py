@@ -168,6 +168,30 @@ def test_conv_nhwc(F_, H, W, Cin, Cout, k, s, p):
     assert _rel_err(s2, (ref * ref).sum(dim=(1, 2))) < 1e-5
 
 
+@pytest.mark.parametrize("F_,H,W,Cin,Cout", [
+    (16, 92, 124, 64, 64),       # 23 x 2 tiles per frame, the last column tile 60 wide: the LDS-resident 3x3 kernel (conv_bf16_c64.hip)
+    (4, 186, 250, 64, 64),       # rows and columns ragged (186 = 46*4 + 2, 250 = 3*64 + 58)
+    (2, 46, 62, 64, 64),         # too few tiles: the implicit-GEMM bf16 kernel, same contract
+    (8, 92, 124, 96, 96),        # other channel counts: implicit GEMM
+])
+def test_conv_nhwc_bf16(F_, H, W, Cin, Cout):
+    """3x3 convolution with bf16 MFMA operands against conv2d of the bf16-rounded operands in fp64, and its InstanceNorm
+    partials against the sums of the output it wrote."""
+    from pips_amd import ops
+    g = torch.Generator().manual_seed(F_ + H + Cin)
+    x = torch.randn(F_, H, W, Cin, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    out, stats = ops.conv_nhwc_bf16(x.to(DEV), w.to(DEV).bfloat16(), b.to(DEV), 3, 1, 1, want_stats=True)
+    out = out.cpu()
+    xr, wr = x.bfloat16().double(), w.bfloat16().double()
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), b.double(), stride=1, padding=1).permute(0, 2, 3, 1)
+    assert _rel_err(out.double(), ref) < 2e-6
+    s1, s2 = ops.partial_sums(stats.cpu())
+    assert _rel_err(s1, out.double().sum(dim=(1, 2))) < 1e-5
+    assert _rel_err(s2, (out.double() ** 2).sum(dim=(1, 2))) < 1e-5
+
+
 # ----------------------------------------------------------------------------- encoder
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("H,W,stride", [(128, 160, 8), (96, 128, 4), (136, 200, 8), (368, 496, 8)])
