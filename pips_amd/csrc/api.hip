@@ -570,18 +570,15 @@ size_t pips_mixer_workspace_bytes(int M) {
     Bump b;
     b.take((size_t)M * PIPS_DMIX); b.take((size_t)M * PIPS_DMIX); b.take((size_t)M * 4 * PIPS_DMIX);
     b.take((size_t)(M / PIPS_S) * PIPS_DMIX);
-    b.take(64);                                  // ticket counter of the persistent bf16 up-projection (gemm_bf16_asm.hip)
     return b.off * sizeof(float);
 }
 
 // ev != nullptr: record ev[2g], ev[2g+1] around GEMM g (g = 0 in-proj, 1+2d up, 2+2d down, 25 head)
 static int gemm_h(const float* A, int a_bf16, int lda, const unsigned short* W, const float* bias, float* C,
-                  int out_bf16, int ldc, int M, int N, int K, int epi, const float* R, int ldr, hipStream_t st,
-                  float* ticket = nullptr) {
+                  int out_bf16, int ldc, int M, int N, int K, int epi, const float* R, int ldr, hipStream_t st) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.W = reinterpret_cast<const float*>(W); g.bias = bias; g.C = C; g.R = R;
-    g.stats = ticket;                            // plain GEMMs: a zeroed int for kernels that hand tiles out dynamically
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.epi = epi;
     return launch_gemm_bf16(g, a_bf16, out_bf16, st);
 }
@@ -613,8 +610,6 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
     float* xn = ws + b.take((size_t)M * PIPS_DMIX);
     float* h = ws + b.take((size_t)M * 4 * PIPS_DMIX);
     float* pooled = ws + b.take((size_t)(M / PIPS_S) * PIPS_DMIX);
-    float* ticket = ws + b.take(64);
-    if (bf16 == 1) (void)hipMemsetAsync(ticket, 0, sizeof(int), st);      // every launch that uses it leaves it at zero
     const int P = M / PIPS_S;
     int g = 0;
 #define TIMED(call)                                                        \
@@ -656,7 +651,7 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
         if (bf16) {
             const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
             TIMED(gemm_h(xn, 1, PIPS_DMIX, hw + A.h_w1[d], arena + L.b1, h, 1, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX,
-                         PIPS_DMIX, EPI_GELU, nullptr, 0, st, ticket));
+                         PIPS_DMIX, EPI_GELU, nullptr, 0, st));
             TIMED(gemm_h(h, 1, 4 * PIPS_DMIX, hw + A.h_w2[d], arena + L.b2, x, 0, PIPS_DMIX, M, PIPS_DMIX,
                          4 * PIPS_DMIX, EPI_RESIDUAL, x, PIPS_DMIX, st));
             continue;
