@@ -1,5 +1,5 @@
-// bf16 x bf16 up-projection of the large-batch channel mix (BASELINE config 3: M = B*N*8 >= 16384 rows, K = 512,
-// GELU, bf16 output): blocks that walk a few tiles each, the tile body ONE generated assembly statement
+// bf16 x bf16 up-projection of the large-batch channel mix -- the first Linear + GELU of the MLP-Mixer's channel
+// FeedForward, nets/pips.py:102-107,115-118 (BASELINE config 3: M = B*N*8 >= 16384 rows, K = 512, GELU, bf16 output): blocks that walk a few tiles each, the tile body ONE generated assembly statement
 // (gemm_bf16_tile_asm.inc <- tools/gen_gemm_bf16_asm.py).
 //
 // C[M,N] = bf16(gelu(bf16(A W^T + bias))): both operands bf16 in memory; fp32 accumulation on
