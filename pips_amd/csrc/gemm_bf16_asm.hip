@@ -1,5 +1,5 @@
 // bf16 x bf16 up-projection of the large-batch channel mix -- the first Linear + GELU of the MLP-Mixer's channel
-// FeedForward, nets/pips.py:102-107,115-118 (BASELINE config 3: M = B*N*8 >= 16384 rows, K = 512, GELU, bf16 output): blocks that walk a few tiles each, the tile body ONE generated assembly statement
+// FeedForward, nets/pips.py:104-105 as instantiated at :118 (BASELINE config 3: M = B*N*8 >= 16384 rows, K = 512, GELU, bf16 output): blocks that walk a few tiles each, the tile body ONE generated assembly statement
 // (gemm_bf16_tile_asm.inc <- tools/gen_gemm_bf16_asm.py).
 //
 // C[M,N] = bf16(gelu(bf16(A W^T + bias))): both operands bf16 in memory; fp32 accumulation on
@@ -219,7 +219,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_gelu_asm_kernel(GemmArgs p, int
     }
 }
 
-// The down-projection (K = 2048, residual, fp32 output): one 256x128 tile per block, the same ring / fragment / MFMA
+// The down-projection -- the FeedForward's second Linear, nets/pips.py:107, and the residual of PreNormResidual :100
+// (K = 2048, fp32 output): one 256x128 tile per block, the same ring / fragment / MFMA
 // schedule as a LOOP over the super-stages inside one assembly statement (PIPS_TILE_TEXT_RES); the accumulators start
 // from the residual tile, the bias is added at the end, 16-byte fp32 stores in the natural column order.
 __global__ __launch_bounds__(512) void gemm_bf16_res_asm_kernel(GemmArgs p, int tiles_m, int ntiles) {
