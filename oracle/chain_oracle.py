@@ -16,8 +16,11 @@ from . import pips_oracle as O
 def chain(sd, rgbs, xy0, iters=6, stride=8, cache_frames=False):
     """rgbs (1,T,3,H,W), xy0 (1,N,2) -> trajs_e (1,T,N,2), list of hop sequences per particle.
 
-    The loop is restated statement by statement; it cannot be pinned by running chain_demo.py itself (the script imports
-    cv2 / tensorboardX / imageio, absent here), only by reading it side by side.  ``cache_frames=True`` is a cost
+    The loop is restated statement by statement and PINNED to the reference's own text: chain_demo.py cannot be
+    imported here (cv2 / tensorboardX / imageio are absent), but tests/golden/make_chain_golden.py executes its lines
+    39-83 verbatim (only ``device='cuda'`` -> ``'cpu'``) with the unmodified reference model and stores the result
+    (tests/golden/chain_t13.npz); tests/test_oracle_golden.py::test_chain_oracle_against_reference_loop_text holds this
+    function to it -- trajectories and hop sequence.  ``cache_frames=True`` is a cost
     shortcut for long/large test videos, not part of the reference: every frame goes through the encoder ONCE and the
     windows index the cached maps -- exact in real arithmetic because InstanceNorm is per frame (nets/pips.py:153-157);
     tests/test_oracle_golden.py checks it against the faithful loop."""

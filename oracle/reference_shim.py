@@ -33,8 +33,8 @@ def _load_module():
         # nets/pips.py:429 does torch.tensor(0.0).cuda() (dead value); without a GPU make
         # .cuda() the identity for the duration of this process.
         torch.Tensor.cuda = lambda self, *a, **k: self
-    # by file path: this repository ships its own ``nets`` package (the drop-in import path), which as a regular
-    # package would shadow the reference's namespace package ``nets`` whatever the sys.path order
+    # by file path: this repository ships its own ``nets/pips.py`` (the drop-in import path; ``nets`` is a namespace
+    # package on both sides), which wins the name ``nets.pips`` whenever the repository is ahead on sys.path
     import importlib.util
     name = "_reference_nets_pips"
     if name not in sys.modules:

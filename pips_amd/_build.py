@@ -34,7 +34,9 @@ def headers():
             os.path.join(HERE, "..", "include", "pips_hip.h")]
 
 
-def build_library(force: bool = False, verbose: bool = True) -> str:
+def build_library(force: bool = False, verbose: bool = True, tuning: bool = False) -> str:
+    """tuning=True: libpips_hip_tune.so with -DPIPS_TUNING (the PIPS_* environment hooks of common.h are live); objects
+    go to csrc/*.tune.o.  The product library has no environment hooks."""
     hipcc = _hipcc()
     headers_ = headers()
     missing = [h for h in headers_ if not os.path.exists(h)]
@@ -44,23 +46,24 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", ".tune.o" if tuning else ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers_):
-            cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+            cmd = [hipcc, *FLAGS, *(["-DPIPS_TUNING"] if tuning else []), "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    lib = LIB.replace(".so", "_tune.so") if tuning else LIB
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
+    build_library(force="--force" in sys.argv, tuning="--tuning" in sys.argv)

@@ -62,6 +62,7 @@ SIGNATURES = {
                                    C.POINTER(c_int), c_void_p]),
     "pips_gemm_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, fp, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, fp, c_int,
                        c_void_p]),
+    "pips_gemm_bf16_route": (c_int, [c_int] * 6),
     "pips_conv_nhwc_bf16": (c_int, [fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp,
                                     C.POINTER(c_int), c_void_p]),
     "pips_split_bf16x3": (c_int, [fp, c_size_t, c_void_p, c_void_p]),

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace pips {
@@ -16,6 +17,25 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+#ifdef PIPS_TUNING
+int tune_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#endif
+
+int device_cus() {
+    static std::atomic<int> cache[64];                 // zero-initialised; one slot per device ordinal
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::atomic<int>& slot = cache[dev & 63];
+    int v = slot.load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 0;
+    slot.store(v, std::memory_order_relaxed);
+    return v;
 }
 
 // ------------------------------------------------------------------ arena layout
@@ -519,7 +539,7 @@ static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const
     PIPS_CHECK_ARG(lh[PIPS_LEVELS - 1] >= 1 && lw[PIPS_LEVELS - 1] >= 1, "mixer_input: map too small");
     const bool can_tile = scratch != nullptr && win_start == nullptr && S == PIPS_S &&
                           scratch_bytes >= tiled_gather_scratch_bytes(B, N, H8, W8);
-    const bool tiled = force_tiled >= 0 ? (force_tiled != 0) : tiled_gather_wanted(N, H8, W8);
+    const bool tiled = force_tiled >= 0 ? (force_tiled != 0) : tiled_gather_wanted(B, N, H8, W8);
     if (tiled && can_tile)
         return launch_mixer_input_tiled(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, scratch, scratch_bytes, st, ev);
     PIPS_CHECK_ARG(force_tiled != 1, "tiled gather needs scratch of %zu bytes, no win_start and 8 frames per clip",
@@ -588,6 +608,16 @@ int pips_gemm_bf16(const void* A, int a_bf16, int lda, const void* W, const floa
     PIPS_CHECK_ARG(A && W && C, "gemm_bf16: null pointer");
     return gemm_h(reinterpret_cast<const float*>(A), a_bf16, lda, reinterpret_cast<const unsigned short*>(W), bias,
                   reinterpret_cast<float*>(C), out_bf16, ldc, M, N, K, epi, R, ldr, (hipStream_t)stream);
+}
+
+int pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    static const float dummy = 0.f;                     // only null-ness of bias / R is inspected
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.bias = &dummy; g.R = &dummy;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N; g.epi = epi;
+    return gemm_bf16_asm_route(g, a_bf16, out_bf16);
 }
 
 // bf16 == 1: bf16 MFMA operands for every Linear of the mixer (weights pre-converted; the LayerNorm-2 output and the

@@ -101,6 +101,20 @@ inline int ensure_dynamic_lds(std::atomic<unsigned long long>& done, const void*
 }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Tuning hooks.  The product library is built WITHOUT -DPIPS_TUNING: PIPS_TUNE() is then its compile-time default -- no
+// getenv, no mutable state reachable from the drop-in.  `python -m pips_amd._build --tuning` builds libpips_hip_tune.so
+// (load it through PIPS_LIB_PATH) in which every hook is read from the environment ONCE per call site, in a C++11
+// function-local static initialiser (thread-safe).  The A/B numbers quoted in DESIGN.md come from that build.
+#ifdef PIPS_TUNING
+int tune_env(const char* name, int dflt);
+#define PIPS_TUNE(name, dflt) ([]() -> int { static const int v__ = ::pips::tune_env(name, dflt); return v__; }())
+#else
+#define PIPS_TUNE(name, dflt) (dflt)
+#endif
+
+// Compute units of the current device, queried once per device (persistent kernels size their grid by it).
+int device_cus();
+
 // ---------------------------------------------------------------- GEMM / conv core
 enum Epilogue { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
 
@@ -184,6 +198,7 @@ int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st
 int launch_conv3x3_c64_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
 // the config-3 up-projection as persistent blocks with a generated-assembly tile body (gemm_bf16_asm.hip); 1 = not taken
 int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
+int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16);   // 0 register-staged, 1 / 2 the assembly kernels
 // split-bf16 (bf16x3) fp32-grade GEMM / conv (gemm_x3.hip): A fp32, W = three bf16 planes [3][N][K]
 int launch_split_bf16x3(const float* src, size_t n, void* dst, hipStream_t st);
 int launch_gemm_x3(const GemmArgs& a, hipStream_t st);
@@ -239,7 +254,7 @@ int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* l
                        int N, const int* win_start, float* X, hipStream_t st);
 // LDS-tiled gather for dense query sets (gather_tiled.hip)
 size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8);
-bool tiled_gather_wanted(int N, int H8, int W8);
+bool tiled_gather_wanted(int B, int N, int H8, int W8);
 // ev != null: 4 events recorded around the three launches (bin, embed, gather)
 int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B,
                              int S, const float* ffeats, const float* coords, const float* times, int N,

@@ -153,15 +153,18 @@ __global__ __launch_bounds__(256) void conv3x3_c64_bf16_kernel(const float* __re
 
 // returns PIPS_OK if taken, 1 if the caller should use the implicit-GEMM kernel
 int launch_conv3x3_c64_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) {
-    static int mode = -1;                       // tuning hook PIPS_CONV_C64: 0 = off
-    if (mode < 0) { const char* e = getenv("PIPS_CONV_C64"); mode = e ? atoi(e) : 1; }
+    const int mode = PIPS_TUNE("PIPS_CONV_C64", 1);        // tuning hook: 0 = off
     if (!mode || a.Cin != 64 || a.N != 64 || a.KH != 3 || a.KW != 3 || a.cstride != 1 || a.pad != 1 || a.Ho != a.H ||
         a.Wo != a.Win || a.Wo < 48 || a.ldc != 64)
         return 1;
     const int tiles_x = cdiv(a.Wo, C64_COLS), tiles_y = cdiv(a.Ho, C64_ROWS), tpf = tiles_x * tiles_y;
     if ((long)tpf * frames < 512) return 1;     // small maps: the implicit-GEMM kernel's many small blocks fill the GPU better
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    // the callers size the statistics buffers for 2*ceil(Ho*Wo/64)+4 partials per frame (pips_hip.h); this kernel emits
+    // one per wave of every 4x64 tile -- more than that bound on degenerate shapes (H=1, W=129): leave those to the
+    // implicit-GEMM kernel
+    if (tpf * 4 > 2 * cdiv(a.Ho * a.Wo, 64) + 4) return 1;
+    const int cus = device_cus();
+    if (cus <= 0) {
         set_error("conv3x3_c64: cannot query the device");
         return PIPS_E_LAUNCH;
     }

@@ -482,12 +482,19 @@ size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8) {
 
 // Selection: dense query sets (on average >= 16 particles per 16x16 level-0 tile) take the tiled kernel;
 // PIPS_GATHER_TILED=0/1 forces it off/on.
-bool tiled_gather_wanted(int N, int H8, int W8) {
-    static int force = -2;
-    if (force == -2) { const char* e = getenv("PIPS_GATHER_TILED"); force = e ? atoi(e) : -1; }
-    if (force >= 0) return force > 0;
-    return (long)N >= 16L * cdiv(W8, TS) * cdiv(H8, TS) && N >= 1024 &&
+// The kernel's hard limits (32-bit byte offsets into the maps and into X, the binning histogram in 64 KiB of LDS) are part
+// of the selection: a problem beyond them falls back to the direct kernel instead of failing the forward.
+bool tiled_gather_fits(int B, int N, int H8, int W8) {
+    size_t px = 0;
+    for (int l = 0, h = H8, w = W8; l < PIPS_LEVELS; ++l, h /= 2, w /= 2) px += ((size_t)B * S * h * w * C + 63) / 64 * 64;
+    return px * 4 < (1ull << 32) && (size_t)B * N * S * PIPS_KIN_PAD * 4 < (1ull << 32) &&
            ((size_t)33 * cdiv(W8, TS) * cdiv(H8, TS) + 1) * sizeof(int) <= 64 * 1024;
+}
+bool tiled_gather_wanted(int B, int N, int H8, int W8) {
+    if (!tiled_gather_fits(B, N, H8, W8)) return false;
+    const int force = PIPS_TUNE("PIPS_GATHER_TILED", -1);
+    if (force >= 0) return force > 0;
+    return (long)N >= 16L * cdiv(W8, TS) * cdiv(H8, TS) && N >= 1024;
 }
 
 int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B,
@@ -525,8 +532,8 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
         if (rc != PIPS_OK) return rc;
     }
     // one persistent block per CU, a multiple of 8 so that block id mod 8 stays the XCD
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    const int cus = device_cus();
+    if (cus <= 0) {
         set_error("tiled gather: cannot query the device");
         return PIPS_E_LAUNCH;
     }

@@ -410,14 +410,7 @@ extern "C" int pips_trace_read(void* host, size_t bytes) {
 }
 #endif
 
-static int swizzle_on() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("PIPS_GEMM_SWZ");
-        v = e ? (atoi(e) != 0) : 0;     // measured neutral on MI355X at the mixer/encoder sizes: off
-    }
-    return v;
-}
+static int swizzle_on() { return PIPS_TUNE("PIPS_GEMM_SWZ", 0) != 0; }     // measured neutral at the mixer/encoder sizes: off
 
 template <int BM, int BN, int WGM, int WGN, int KS, bool CONV>
 static int launch_tile(const GemmArgs& a_in, int frames, hipStream_t st) {
@@ -444,17 +437,10 @@ static int launch_tile(const GemmArgs& a_in, int frames, hipStream_t st) {
 // Debug/tuning hooks: PIPS_GEMM_TILE=<id> forces one tile configuration for plain GEMMs;
 // PIPS_GEMM_TILE_UP / PIPS_GEMM_TILE_DOWN do so only for N > K / N < K (the mixer's up- and
 // down-projections), for in-situ A/B runs of tools/mixer_bench.py.
-static int env_int(const char* name) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : -1;
-}
 static int forced_tile(const GemmArgs& a) {
-    static int all = -2, up = -2, down = -2;
-    if (all == -2) {
-        all = env_int("PIPS_GEMM_TILE");
-        up = env_int("PIPS_GEMM_TILE_UP");
-        down = env_int("PIPS_GEMM_TILE_DOWN");
-    }
+    const int all = PIPS_TUNE("PIPS_GEMM_TILE", -1), up = PIPS_TUNE("PIPS_GEMM_TILE_UP", -1),
+              down = PIPS_TUNE("PIPS_GEMM_TILE_DOWN", -1);
+    (void)up; (void)down;
     if (all >= 0) return all;
     if (a.N > a.K && up >= 0) return up;
     if (a.N < a.K && down >= 0) return down;
@@ -503,8 +489,7 @@ static void conv_tile(int rows, int cout, int frames, int* bm, int* bn) {
     // (measured: 104.7 -> 85.8 us and 59 -> 39 us; conv2's 714 blocks and the 96-channel layers prefer the big tile)
     if (*bm == 64 && n == 128 && (long)cdiv(rows, 64) * (cout / 128) * frames < 400) n = 64;
     *bn = n;
-    static int force_bm = -1;                  // tuning hook: PIPS_CONV_BM=64|128
-    if (force_bm < 0) { const char* e = getenv("PIPS_CONV_BM"); force_bm = e ? atoi(e) : 0; }
+    const int force_bm = PIPS_TUNE("PIPS_CONV_BM", 0);      // tuning hook: 64|128
     if (force_bm == 64 || force_bm == 128) *bm = force_bm;
 }
 

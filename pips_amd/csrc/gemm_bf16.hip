@@ -331,8 +331,7 @@ static int pick_tile(const GemmArgs& a, hipStream_t st) {
     }
     // tuning hook PIPS_BF16_BIG: 0 = no tile above 128x128, 1 = 256x128 only, 2 (default) = 256x256 where it still
     // gives every CU a tile (config 3 up-projection: 60.7 vs 67.7 us), 256x128 below that
-    static int big = -1;
-    if (big < 0) { const char* e = getenv("PIPS_BF16_BIG"); big = e ? atoi(e) : 2; }
+    const int big = PIPS_TUNE("PIPS_BF16_BIG", 2);
     if (big >= 2 && (long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 256) return launch_bf16_tile<256, 256, 4, 2, 1, A_BF16, OUT_BF16>(a, st);
     if (big && (long)cdiv(a.M, 256) * cdiv(a.N, 128) >= 256) return launch_bf16_tile<256, 128, 4, 2, 1, A_BF16, OUT_BF16>(a, st);
     if (b128 >= 400) return launch_bf16_tile<128, 128, 2, 2, 1, A_BF16, OUT_BF16>(a, st);

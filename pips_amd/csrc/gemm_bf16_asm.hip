@@ -284,20 +284,28 @@ __global__ __launch_bounds__(512) void gemm_bf16_res_asm_kernel(GemmArgs p, int 
                  : PIPS_TILE_RES_CLOBBER);
 }
 
+// Which kernel a bf16-operand GEMM goes to: 0 = the register-staged gemm_bf16_kernel, 1 = gemm_bf16_res_asm_kernel
+// (down-projection + residual), 2 = gemm_bf16_gelu_asm_kernel (up-projection + GELU).  Pure function of the problem --
+// also behind pips_gemm_bf16_route(), which lets a test assert that a forward's geometry reaches the assembly kernels.
+int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16) {
+    const int mode = PIPS_TUNE("PIPS_BF16_ASM", 1);        // tuning hook: 0 = off, 1 (default) = on, 2 = on for any tile count
+    const int epi = a.epi & 0xff;
+    if (!mode || !a_bf16 || a.lda % 8 != 0 || a.ldc % 8 != 0 || a.bias == nullptr || a.K % 64 != 0) return 0;
+    if (a.M % 256 != 0 || a.N % 128 != 0 || (mode != 2 && (long)(a.M / 256) * (a.N / 128) < 256)) return 0;   // (2: debugging)
+    if (epi == EPI_RESIDUAL && !out_bf16 && a.R != nullptr && a.ldr % 4 == 0 && a.K >= 256 &&
+        (unsigned long long)a.M * a.ldr * 4ull < (1ull << 32) && (unsigned long long)a.M * a.ldc * 4ull < (1ull << 32))
+        return PIPS_TUNE("PIPS_BF16_ASM_RES", 1) ? 1 : 0;   // tuning hook =0: down-projection on the register-staged kernel
+    if (!out_bf16 || epi != EPI_GELU || a.K != 512) return 0;
+    return 2;
+}
+
 // returns PIPS_OK if the problem was taken, 1 if the caller should use the register-staged kernel of gemm_bf16.hip
 int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st) {
-    static int mode = -1;                       // tuning hook PIPS_BF16_ASM: 0 = off, 1 (default) = on, 2 = on for any tile count
-    if (mode < 0) { const char* e = getenv("PIPS_BF16_ASM"); mode = e ? atoi(e) : 1; }
-    const int epi = a.epi & 0xff;
-    if (!mode || !a_bf16 || a.lda % 8 != 0 || a.ldc % 8 != 0 || a.bias == nullptr || a.K % 64 != 0) return 1;
-    if (a.M % 256 != 0 || a.N % 128 != 0 || (mode != 2 && (long)(a.M / 256) * (a.N / 128) < 256)) return 1;   // (2: debugging)
+    const int route = gemm_bf16_asm_route(a, a_bf16, out_bf16);
+    if (route == 0) return 1;
     const int tiles_m = a.M / 256, ntiles = tiles_m * (a.N / 128);
     const size_t ring = (size_t)6 * (256 + 128) * 64;
-    if (epi == EPI_RESIDUAL && !out_bf16 && a.R != nullptr && a.ldr % 4 == 0 && a.K >= 256 &&
-        (unsigned long long)a.M * a.ldr * 4ull < (1ull << 32) && (unsigned long long)a.M * a.ldc * 4ull < (1ull << 32)) {
-        static int res = -1;                    // tuning hook PIPS_BF16_ASM_RES=0: down-projection on the register-staged kernel
-        if (res < 0) { const char* e = getenv("PIPS_BF16_ASM_RES"); res = e ? atoi(e) : 1; }
-        if (!res) return 1;
+    if (route == 1) {
         static std::atomic<unsigned long long> raised_r{0};
         const int rc = ensure_dynamic_lds(raised_r, (const void*)gemm_bf16_res_asm_kernel, ring);
         if (rc != PIPS_OK) return rc;
@@ -305,11 +313,10 @@ int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_
         PIPS_CHECK_LAUNCH("gemm_bf16_res_asm_kernel");
         return PIPS_OK;
     }
-    if (!out_bf16 || epi != EPI_GELU || a.K != 512) return 1;
-    static int tpb = -1;                        // tuning hook PIPS_BF16_ASM_TPB: tiles per block (config 3: 1 / 2 / 4 ->
-    if (tpb < 0) { const char* e = getenv("PIPS_BF16_ASM_TPB"); tpb = e ? atoi(e) : 4; if (tpb < 1) tpb = 1; }   // 22.1 / 21.0 / 20.7 ms)
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    int tpb = PIPS_TUNE("PIPS_BF16_ASM_TPB", 4);  // tuning hook: tiles per block (config 3: 1 / 2 / 4 -> 22.1 / 21.0 / 20.7 ms)
+    if (tpb < 1) tpb = 1;
+    const int cus = device_cus();
+    if (cus <= 0) {
         set_error("gemm_bf16_asm: cannot query the device");
         return PIPS_E_LAUNCH;
     }

@@ -349,11 +349,9 @@ static int launch_x3_tile(const GemmArgs& a, int frames, hipStream_t st) {
 
 // tuning hooks: PIPS_X3_TILE=<id> for every GEMM, PIPS_X3_TILE_UP / _DOWN for N > K / N < K only
 static int x3_forced_tile(const GemmArgs& a) {
-    static int all = -2, up = -2, down = -2;
-    if (all == -2) {
-        auto env = [](const char* n) { const char* e = getenv(n); return e ? atoi(e) : -1; };
-        all = env("PIPS_X3_TILE"); up = env("PIPS_X3_TILE_UP"); down = env("PIPS_X3_TILE_DOWN");
-    }
+    const int all = PIPS_TUNE("PIPS_X3_TILE", -1), up = PIPS_TUNE("PIPS_X3_TILE_UP", -1),
+              down = PIPS_TUNE("PIPS_X3_TILE_DOWN", -1);
+    (void)up; (void)down;
     if (all >= 0) return all;
     if (a.N > a.K && up >= 0) return up;
     if (a.N < a.K && down >= 0) return down;
@@ -394,8 +392,7 @@ int launch_gemm_x3(const GemmArgs& a, hipStream_t st) {
 int launch_conv_x3(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) {
     PIPS_CHECK_ARG(a.Cin % 32 == 0 && a.K == a.KH * a.KW * a.Cin, "conv_x3: Cin %% 32, K = kh*kw*Cin");
     const int bn = a.N <= 64 ? 64 : 128;            // Cout = 96 rides a 128-wide tile
-    static int force_bm = -1;                       // tuning hook: PIPS_X3_CONV_BM=64|128|256
-    if (force_bm < 0) { const char* e = getenv("PIPS_X3_CONV_BM"); force_bm = e ? atoi(e) : 0; }
+    const int force_bm = PIPS_TUNE("PIPS_X3_CONV_BM", 0);       // tuning hook: 64|128|256
     int bm = (long)cdiv(a.M, 128) * cdiv(a.N, bn) * frames >= 256 ? 128 : 64;
     // 256-row tiles (8 waves of 64x64, a quarter fewer staged bytes per MFMA) once they fill 5/8 of the
     // CUs: measured 96->96 164 -> 150 us, 64->96/s2 118 -> 103 us, 416->256 (192 tiles) 435 -> 304 us;

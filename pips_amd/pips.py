@@ -86,6 +86,7 @@ class Pips(nn.Module):
         self._warned_precedence = False
         self._arena = None
         self._arena_key = None
+        self._arena_params = None
         self._ws = {}
         self._times = None
 
@@ -93,7 +94,7 @@ class Pips(nn.Module):
     def invalidate_weights(self):
         """Drop the packed kernel-side copy of the weights; the next forward repacks.  Needed only after
         writes that bypass autograd's version counter (``p.data.copy_()``, ``p.data.mul_()``)."""
-        self._arena = self._arena_key = self._plist = None
+        self._arena = self._arena_key = self._plist = self._arena_params = None
 
     def _apply(self, fn, *a, **kw):                     # .to() / .cuda() / .float(): parameters may be re-created
         out = super()._apply(fn, *a, **kw)
@@ -102,12 +103,22 @@ class Pips(nn.Module):
 
     def _packed(self, device):
         if self._plist is None:
-            sd = dict(self.named_parameters())
-            self._plist = [sd[k] for k in self._names]
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self._plist)
+            # (owning module, leaf name) of every parameter: the LIVE object is looked up on every forward, so a
+            # parameter that was replaced (load_state_dict(assign=True), ``node.weight = nn.Parameter(...)``) is seen
+            # like one that was mutated in place
+            self._plist = []
+            for name in self._names:
+                *path, leaf = name.split(".")
+                node = self
+                for q in path:
+                    node = node._modules[q]
+                self._plist.append((node._parameters, leaf))
+        live = [d[leaf] for d, leaf in self._plist]
+        key = (str(device),) + tuple((id(p), p.data_ptr(), p._version) for p in live)
         if self._arena is None or key != self._arena_key:
-            self._arena = ops.pack_weights(dict(zip(self._names, self._plist)), device)
+            self._arena = ops.pack_weights(dict(zip(self._names, live)), device)
             self._arena_key = key
+            self._arena_params = live          # keeps the ids in the key from being recycled
         return self._arena
 
     def _flags(self):

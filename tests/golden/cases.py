@@ -60,3 +60,18 @@ def make_targets(case: dict, seed: int = 7, S: int = 8):
     vis_g = (torch.rand(B, S, N, generator=g) > 0.3).float()
     valids = (torch.rand(B, S, N, generator=g) > 0.1).float()
     return trajs_g, vis_g, valids
+
+
+# chained long-video case (chain_demo.py:39-83): a slowly changing 13-frame video, three queries
+CHAIN_CASE = dict(T=13, H=128, W=160, N=3, stride=8, iters=6, tamed=True)
+
+
+def make_chain_inputs(case: dict = CHAIN_CASE, seed: int = 11):
+    """(video (1,T,3,H,W) 0..255, xy0 (1,N,2) px).  The level-3 map is 2x2: a 1-pixel level divides by (W-1)=0
+    (nets/pips.py:318) and the reference's threshold scan would never end."""
+    g = torch.Generator().manual_seed(seed)
+    T, H, W, N = case["T"], case["H"], case["W"], case["N"]
+    base = torch.randint(0, 256, (1, 1, 3, H, W), generator=g).float()
+    video = torch.cat([(base * (1 - 0.04 * t) + 9.0 * t).clamp(0, 255).round() for t in range(T)], dim=1)
+    xy0 = torch.rand(1, N, 2, generator=g) * torch.tensor([W - 17.0, H - 17.0]) + 8.0
+    return video, xy0

@@ -77,6 +77,25 @@ def test_reference_import_path_resolves_to_the_hip_model():
     assert nets.pips.Pips is pips_amd.Pips
 
 
+def test_nets_is_a_namespace_package_merged_with_the_reference():
+    """``nets`` ships no __init__.py: with this repository ahead of the reference checkout on sys.path the reference's
+    sibling modules stay importable (``from nets.raftnet import Raftnet`` is line 5 of test_on_flt.py / test_on_crohd.py
+    / test_on_badja.py, ahead of ``from nets.pips import Pips``) while nets.pips resolves to the HIP model."""
+    import subprocess, sys
+    assert not os.path.exists(os.path.join(ROOT, "nets", "__init__.py"))
+    ref_root = "/root/reference"
+    have_ref = os.path.isfile(os.path.join(ref_root, "nets", "raftnet.py"))
+    code = ("import sys, importlib.util\n"
+            f"sys.path[:0] = [{ROOT!r}, {ref_root!r}]\n"
+            "import nets.pips, pips_amd\n"
+            "assert nets.pips.Pips is pips_amd.Pips\n"
+            "assert nets.pips.__file__.startswith(%r)\n" % ROOT +
+            (f"spec = importlib.util.find_spec('nets.raftnet')\nassert spec is not None and spec.origin.startswith({ref_root!r}), spec\n"
+             if have_ref else "") + "print('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/")
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
 def test_reference_saverloader_round_trip(tmp_path, weights_tamed):
     """The reference's own saverloader.save / saverloader.load (saverloader.py:5-69), unmodified, on pips_amd.Pips
     (build container only: needs /root/reference)."""
@@ -109,6 +128,26 @@ def test_packed_weights_follow_parameter_changes():
     m.invalidate_weights()
     m2 = m.float()                                             # _apply path
     assert m2 is m and m._arena is None
+    # a REPLACED parameter (load_state_dict(assign=True), node.weight = nn.Parameter(...)) changes the cache key too:
+    # the key is built from the live objects, not from a list captured at the first forward
+    import pips_amd.ops as ops
+    packed = []
+    orig = ops.pack_weights
+    ops.pack_weights = lambda sd, dev: packed.append({k: v for k, v in sd.items()}) or object()
+    try:
+        m._packed("cpu")
+        m._packed("cpu")
+        assert len(packed) == 1
+        node = m.delta_block.to_delta._modules["15"]
+        node.weight = torch.nn.Parameter(node.weight.detach().clone() * 2, requires_grad=False)
+        m._packed("cpu")
+        assert len(packed) == 2 and packed[1]["delta_block.to_delta.15.weight"] is node.weight
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        m.load_state_dict(sd, assign=True)
+        m._packed("cpu")
+        assert len(packed) == 3
+    finally:
+        ops.pack_weights = orig
 
 
 def test_build_script_dependencies_exist_and_asm_is_current(tmp_path):

@@ -71,6 +71,37 @@ def test_chain_oracle_frame_cache_equals_faithful_loop(weights_tamed):
     assert float((a - b).abs().max()) < 1e-4
 
 
+def test_chain_oracle_against_reference_loop_text(weights_tamed):
+    """oracle/chain_oracle.chain against the output of the reference's OWN loop text (chain_demo.py:39-83 executed
+    verbatim with the unmodified reference model by tests/golden/make_chain_golden.py): same window starts, same hops,
+    same trajectories."""
+    from oracle import chain_oracle
+    case = G.CHAIN_CASE
+    gold = np.load(os.path.join(GOLD, "chain_t13.npz"))
+    video, xy0 = G.make_chain_inputs(case)
+    trajs, hops = chain_oracle.chain(weights_tamed, video, xy0, iters=case["iters"], stride=case["stride"])
+    # the reference text leaves no hop record: the generator logged each window's first frame instead
+    starts = []
+    for seq in hops:
+        cur = 0
+        for si in seq:
+            starts.append(cur)
+            cur += si
+    assert starts == gold["window_starts"].tolist()
+    steps = [si for seq in hops for si in seq[:-1]]
+    assert steps == gold["hop_steps"].tolist() and [len(seq) - 1 for seq in hops] == gold["hops_per_particle"].tolist()
+    err = float((trajs - torch.from_numpy(gold["trajs_e"])).abs().max())
+    print("chain oracle vs reference loop text: max |dtraj| =", err)
+    assert err < 1e-4
+    if R.available():        # build container: the slice is still the loop (the generator asserts its first / last line)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_mk_chain", os.path.join(GOLD, "make_chain_golden.py"))
+        mk = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mk)
+        text = mk.loop_text()
+        assert "while not found_skip:" in text and "thr -= 0.02" in text and "device='cuda'" not in text
+
+
 def test_oracle_losses_match_reference_golden(weights_raw, weights_tamed):
     """(seq_loss, vis_loss, ce_loss) of the oracle against the values the unmodified reference returned (make_golden.py
     --losses): pins the restated score maps (nets/pips.py:501-511) and score_map_loss (:58-92)."""
