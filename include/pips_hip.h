@@ -53,8 +53,10 @@ extern "C" {
 
 /* flags of pips_forward / pips_track */
 #define PIPS_FLAG_REUSE_MAPS  1   /* pips_forward: skip the encoder, the workspace already holds the maps */
-#define PIPS_FLAG_BF16_ENCODER 4  /* bf16 MFMA operands in the encoder's 3x3 / 1x1 convolutions (maps, statistics,
-                                     normalisation, resize and the 7x7 stem stay fp32) */
+#define PIPS_FLAG_BF16_ENCODER 4  /* the encoder the way torch.autocast(bfloat16) runs it: bf16 MFMA operands in all 22
+                                     convolutions (7x7 stem included) and bf16 activation maps between the layers;
+                                     statistics from the fp32 accumulators, normalisation / ReLU / adds / resizes in
+                                     fp32 arithmetic rounded once on store; the pyramid handed to the tracker is fp32 */
 #define PIPS_FLAG_RGB_U8      8   /* rgbs points at uint8 (B,S,3,H,W) frames instead of float: same values, a
                                      quarter of the input bytes (the decoded frames of demo.py:136-144) */
 #define PIPS_FLAG_BF16_MIXER  2   /* bf16 MFMA operands in the channel-mix and head Linear layers (BASELINE
@@ -233,6 +235,15 @@ int    pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf
 int    pips_conv_nhwc_bf16(const float* in, int F, int H, int W, int Cin,
                            const void* wgt_bf16, const float* bias, int Cout, int ksize, int cstride, int pad,
                            float* out, float* stats, int* tiles_m_host, void* stream);
+
+/* The same convolution on bf16 MAPS (what the bf16 encoder mode uses between its layers): in_bf16 is a bf16 NHWC map;
+ * in_norm (optional, 64 -> 64 3x3 stride-1 layers on maps the LDS-resident kernel takes: >= 512 tiles of 4x64 pixels)
+ * holds {mean, rstd} per (frame, input channel) of the layer that produced the map, and relu((x - mean) * rstd) is
+ * applied to it while it is staged (taps outside the image stay zero); out is bf16 (out_is_bf16) or fp32; the
+ * statistics are taken from the fp32 accumulators. */
+int    pips_conv_nhwc_bf16_maps(const void* in_bf16, const float* in_norm, int F, int H, int W, int Cin,
+                                const void* wgt_bf16, const float* bias, int Cout, int ksize, int cstride, int pad,
+                                void* out, int out_is_bf16, float* stats, int* tiles_m_host, void* stream);
 
 /* Split-bf16 ("bf16x3") building blocks: fp32-grade results from the bf16 matrix cores.  Every
  * fp32 operand is split exactly into three bf16 terms and each product is formed from six exact

@@ -65,6 +65,8 @@ SIGNATURES = {
     "pips_gemm_bf16_route": (c_int, [c_int] * 6),
     "pips_conv_nhwc_bf16": (c_int, [fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp,
                                     C.POINTER(c_int), c_void_p]),
+    "pips_conv_nhwc_bf16_maps": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int,
+                                         c_void_p, c_int, fp, C.POINTER(c_int), c_void_p]),
     "pips_split_bf16x3": (c_int, [fp, c_size_t, c_void_p, c_void_p]),
     "pips_gemm_f32x3": (c_int, [fp, c_int, c_void_p, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, c_int, c_void_p]),
     "pips_conv_nhwc_f32x3": (c_int, [fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp,

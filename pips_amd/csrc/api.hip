@@ -260,17 +260,28 @@ int pips_gemm_f32x3(const float* A, int lda, const void* W3, const float* bias, 
 }
 
 // mm: 0 exact-fp32 MFMA, 1 bf16 operands (RNE), 2 split-bf16 (wgt points at the matching weight form)
+// in_bf16 / out_bf16 (mm == 1 only): the NHWC maps themselves are bf16; in_norm: see GemmArgs
 static int conv_nhwc(const float* in, int F, int H, int W, int Cin, const float* wgt, const float* bias, int Cout,
-                     int k, int s, int p, float* out, float* stats, int* tiles, hipStream_t st, int bf16 = 0) {
+                     int k, int s, int p, float* out, float* stats, int* tiles, hipStream_t st, int bf16 = 0,
+                     int in_bf16 = 0, int out_bf16 = 0, const float* in_norm = nullptr) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.A = in; g.W = wgt; g.bias = bias; g.C = out; g.stats = stats;
+    g.A = in; g.W = wgt; g.bias = bias; g.C = out; g.stats = stats; g.in_norm = in_norm;
     g.H = H; g.Win = W; g.Cin = Cin; g.KH = g.KW = k; g.cstride = s; g.pad = p;
     g.Ho = conv_out(H, k, s, p); g.Wo = conv_out(W, k, s, p);
     g.M = g.Ho * g.Wo; g.N = Cout; g.K = k * k * Cin; g.ldc = Cout; g.epi = EPI_BIAS;
     PIPS_CHECK_ARG(g.Ho > 0 && g.Wo > 0, "conv: empty output");
     if (bf16 == 2) return launch_conv_x3(g, F, tiles, st);
-    return bf16 ? launch_conv_bf16(g, F, tiles, st) : launch_conv(g, F, tiles, st);   // bf16: wgt points at bf16 data
+    PIPS_CHECK_ARG(bf16 == 1 || (!in_bf16 && !out_bf16 && !in_norm), "conv: bf16 maps need the bf16-operand kernels");
+    return bf16 ? launch_conv_bf16(g, F, tiles, st, in_bf16, out_bf16) : launch_conv(g, F, tiles, st);   // bf16: wgt points at bf16 data
+}
+
+int pips_conv_nhwc_bf16_maps(const void* in_bf16, const float* in_norm, int F, int H, int W, int Cin, const void* wgt_bf16,
+                             const float* bias, int Cout, int ksize, int cstride, int pad, void* out, int out_is_bf16,
+                             float* stats, int* tiles_m_host, void* stream) {
+    PIPS_CHECK_ARG(in_bf16 && wgt_bf16 && out, "conv_bf16_maps: null pointer");
+    return conv_nhwc((const float*)in_bf16, F, H, W, Cin, (const float*)wgt_bf16, bias, Cout, ksize, cstride, pad, (float*)out,
+                     stats, tiles_m_host, (hipStream_t)stream, 1, 1, out_is_bf16 ? 1 : 0, in_norm);
 }
 
 int pips_conv_nhwc_f32x3(const float* in, int F, int H, int W, int Cin, const void* wgt3, const float* bias,
@@ -408,6 +419,89 @@ int res_block(const float* arena, const ArenaLayout& A, int& ci, bool down, cons
     return PIPS_OK;
 }
 
+// ---- the encoder with every activation in bf16 (PIPS_FLAG_BF16_ENCODER; kernels: encoder_bf16.hip, conv_bf16_c64.hip,
+// gemm_bf16.hip).  Buffers are the fp32 plan's, used as bf16.
+// conv (bf16 map in, optional normalise-on-load) -> bf16 raw map + partials -> {mean, rstd}
+int conv_stats_h(const float* arena, const ArenaLayout& A, int ci, const void* in, const float* in_norm, int F, int H, int W,
+                 void* out, float* partial, float* mean_rstd, hipStream_t st) {
+    const ConvW& c = A.conv[ci];
+    int tiles = 0;
+    RUN(conv_nhwc((const float*)in, F, H, W, c.cin, conv_w(arena, A, ci, 1), arena + c.b, c.cout, c.k, c.stride, c.pad,
+                  (float*)out, partial, &tiles, st, 1, 1, 1, in_norm));
+    return launch_inorm_finalize_pivot(partial, F, tiles, c.cout, mean_rstd, st);
+}
+
+// ResidualBlock.forward (nets/pips.py:173-181), materialised bf16 activations
+int res_block_h(const float* arena, const ArenaLayout& A, int& ci, bool down, const void* x, int F, int H, int W, float* ws,
+                const EncPlan& P, void* out, hipStream_t st) {
+    const int i1 = ci++, i2 = ci++;
+    const ConvW& c1 = A.conv[i1];
+    const ConvW& c2 = A.conv[i2];
+    const int Ho = conv_out(H, 3, c1.stride, 1), Wo = conv_out(W, 3, c1.stride, 1);
+    void* raw = ws + P.raw; void* mid = ws + P.mid;
+    RUN(conv_stats_h(arena, A, i1, x, nullptr, F, H, W, raw, ws + P.partial, ws + P.st_a, st));
+    RUN(launch_inorm_apply_bf16(raw, ws + P.st_a, nullptr, nullptr, 0, mid, F, Ho * Wo, c1.cout, st));
+    RUN(conv_stats_h(arena, A, i2, mid, nullptr, F, Ho, Wo, raw, ws + P.partial, ws + P.st_a, st));
+    if (down) {
+        const int id = ci++;
+        RUN(conv_stats_h(arena, A, id, x, nullptr, F, H, W, ws + P.ds, ws + P.partial2, ws + P.st_b, st));
+        return launch_inorm_apply_bf16(raw, ws + P.st_a, ws + P.ds, ws + P.st_b, 2, out, F, Ho * Wo, c2.cout, st);
+    }
+    return launch_inorm_apply_bf16(raw, ws + P.st_a, x, nullptr, 1, out, F, Ho * Wo, c2.cout, st);
+}
+
+int encoder_bf16_acts(const float* arena, const ArenaLayout& A, const void* rgbs, int rgb_u8, int F, int H, int W, int stride,
+                      float* pyramid, float* ws, const EncPlan& P, hipStream_t st) {
+    const int H0 = P.Hs[0], W0 = P.Ws[0];
+    int tiles = 0, ci = 1;
+    void* xa = ws + P.xa; void* xb = ws + P.xb; void* raw = ws + P.raw; void* mid = ws + P.mid;
+    float* st_a = ws + P.st_a; float* st_b = ws + P.st_b;
+    // stem: conv1 (:251); its norm1 + relu (:252-253) is applied by the consumers
+    RUN(launch_stem_bf16(rgbs, rgb_u8, arena + A.conv[0].w, arena + A.conv[0].b, xa, ws + P.partial, F, H, W, H0, W0, &tiles, st));
+    RUN(launch_inorm_finalize_pivot(ws + P.partial, F, tiles, 64, st_a, st));
+    const void* x;
+    if (conv3x3_c64_takes(H0, W0, F)) {
+        // layer1 on the LDS-resident 64 -> 64 kernel: a convolution normalises its input while staging it, so relu(norm(.))
+        // of the stem and of each block's first convolution never goes to HBM.  xa = raw stem map (statistics st_a).
+        RUN(conv_stats_h(arena, A, ci++, xa, st_a, F, H0, W0, raw, ws + P.partial, st_b, st));          // block 1 conv1
+        RUN(conv_stats_h(arena, A, ci++, raw, st_b, F, H0, W0, mid, ws + P.partial, st_b, st));         // block 1 conv2
+        // relu(x + y), x = relu(norm1(stem)) recomputed from the raw stem map, y = relu(norm2(conv2)) (:176-181)
+        RUN(launch_inorm_apply_bf16(mid, st_b, xa, st_a, 3, xb, F, H0 * W0, 64, st));
+        RUN(conv_stats_h(arena, A, ci++, xb, nullptr, F, H0, W0, raw, ws + P.partial, st_a, st));       // block 2 conv1
+        RUN(conv_stats_h(arena, A, ci++, raw, st_a, F, H0, W0, mid, ws + P.partial, st_b, st));         // block 2 conv2
+        RUN(launch_inorm_apply_bf16(mid, st_b, xb, nullptr, 1, ws + P.outs[0], F, H0 * W0, 64, st));
+    } else {
+        RUN(launch_inorm_apply_bf16(xa, st_a, nullptr, nullptr, 0, xb, F, H0 * W0, 64, st));
+        RUN(res_block_h(arena, A, ci, false, xb, F, H0, W0, ws, P, xa, st));
+        RUN(res_block_h(arena, A, ci, false, xa, F, H0, W0, ws, P, ws + P.outs[0], st));
+    }
+    x = ws + P.outs[0];
+    int Hc = H0, Wc = W0;
+    for (int l = 1; l < 4; ++l) {
+        RUN(res_block_h(arena, A, ci, true, x, F, Hc, Wc, ws, P, xb, st));
+        Hc = P.Hs[l]; Wc = P.Ws[l];
+        RUN(res_block_h(arena, A, ci, false, xb, F, Hc, Wc, ws, P, ws + P.outs[l], st));
+        x = ws + P.outs[l];
+    }
+    const int ch[4] = {64, 96, 128, 128};
+    const int H8 = P.Hs[4], W8 = P.Ws[4];
+    for (int l = 0, coff = 0; l < 4; coff += ch[l], ++l)
+        RUN(launch_resize_into_bf16(ws + P.outs[l], F, P.Hs[l], P.Ws[l], ch[l], ws + P.cat, H8, W8, 416, coff, st));
+    const int i2 = ci++, i3 = ci++;
+    const ConvW& c3 = A.conv[i3];
+    RUN(conv_stats_h(arena, A, i2, ws + P.cat, nullptr, F, H8, W8, raw, ws + P.partial, st_a, st));
+    RUN(launch_inorm_apply_bf16(raw, st_a, nullptr, nullptr, 0, mid, F, H8 * W8, 256, st));
+    // conv3 writes the fp32 level-0 map of the correlation pyramid
+    RUN(conv_nhwc((const float*)mid, F, H8, W8, 256, conv_w(arena, A, i3, 1), arena + c3.b, 128, 1, 1, 0, pyramid, nullptr, nullptr,
+                  st, 1, 1, 0));
+    int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
+    pyramid_dims(H, W, stride, lh, lw);
+    for (int l = 1; l < PIPS_LEVELS; ++l)
+        RUN(launch_avgpool2(pyramid + pips_pyramid_offset(F, H, W, stride, l - 1), F, lh[l - 1], lw[l - 1], PIPS_C,
+                            pyramid + pips_pyramid_offset(F, H, W, stride, l), st));
+    return PIPS_OK;
+}
+
 }  // namespace
 
 size_t pips_encoder_workspace_bytes(int F, int H, int W, int stride) {
@@ -451,8 +545,8 @@ int pips_encoder_fwd_ex(const void* arena_v, const void* rgbs, int F, int H, int
                             ((flags & PIPS_FLAG_SPLIT_BF16) ? 4 : 0));
 }
 
-// mode bit0: bf16 MFMA operands in the 21 3x3 / 1x1 convolutions (maps stay fp32 in memory and are
-// rounded as they are staged; statistics, normalisation, resize and the 7x7 stem stay fp32);
+// mode bit0: bf16 MFMA operands in all 22 convolutions AND bf16 activation maps (the rounding points of the reference
+// under torch.autocast(bfloat16)); statistics, normalisation, adds and resizes are fp32 arithmetic, the pyramid is fp32;
 // mode bit1: rgbs is uint8 (B,S,3,H,W) instead of float;
 // mode bit2: split-bf16 (fp32-grade) convolutions where layer_mm() picks them; wins over bit0
 static int encoder_impl(const void* arena_v, const void* rgbs, int F, int H, int W, int stride, float* pyramid,
@@ -469,6 +563,8 @@ static int encoder_impl(const void* arena_v, const void* rgbs, int F, int H, int
     const ArenaLayout& A = arena_layout();
     const float* arena = (const float*)arena_v;
     float* ws = (float*)workspace;
+    if (bf16 == 1)
+        return encoder_bf16_acts(arena, A, rgbs, (mode & 2) ? 1 : 0, F, H, W, stride, pyramid, ws, P, st);
 
     // stem: conv1 + norm1 + relu (nets/pips.py:251-253)
     int tiles = 0;

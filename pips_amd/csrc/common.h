@@ -69,6 +69,38 @@ __device__ __forceinline__ f2 gelu_exact2(f2 x) {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---------------------------------------------------------------- bf16 activations (bf16 encoder mode)
+// two floats -> one dword of two bf16 (hardware round-to-nearest-even, v_cvt_pk_bf16_f32); lo in bits 0-15
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2_t_ __attribute__((ext_vector_type(2)));
+    const f2 v = {lo, hi};
+    const bf16x2_t_ b = __builtin_convertvector(v, bf16x2_t_);
+    return *reinterpret_cast<const unsigned*>(&b);
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+// the value of lane ^ 1 (DPP quad_perm [1,0,3,2]: one VALU instruction, no LDS)
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+}
+// One 32-pixel x 32-channel MFMA accumulator tile in C orientation -- lane: channel c0 + l31, register r: pixel
+// (r&3) + 8*(r>>2) + 4*half -- stored as bf16 into a channel-last map.  Neighbouring lanes (channels n, n+1) trade every
+// other pixel, so each lane writes packed channel PAIRS: one dword per store, 64-byte runs per pixel and half-wave.
+// px_ptr(px) returns the pixel's row (bf16 units, at the tile's first channel) or nullptr when the pixel is outside.
+template <typename PxPtr>
+__device__ __forceinline__ void store_c_tile_bf16(const float (&v)[16], int l31, int half, PxPtr px_ptr) {
+    const bool odd = l31 & 1;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r0 = 2 * rr, r1 = r0 + 1;                                  // consecutive pixels
+        const float recv = lane_xor1(odd ? v[r0] : v[r1]);
+        const unsigned d = odd ? pack2_bf16(recv, v[r1]) : pack2_bf16(v[r0], recv);
+        const int r = odd ? r1 : r0;
+        unsigned short* row = px_ptr((r & 3) + 8 * (r >> 2) + 4 * half);
+        if (row != nullptr) *reinterpret_cast<unsigned*>(row + (l31 & ~1)) = d;
+    }
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // InstanceNorm partials of a convolution tile, one per WAVE ROW (m tile, wm) and channel, about a PIVOT -- the value of
@@ -131,6 +163,9 @@ struct GemmArgs {
     int swz;             // XCD-aware tile order (set by the launcher)
     // implicit-GEMM geometry (conv only); M = Ho*Wo rows per frame, gridDim.z = frames
     int H, Win, Cin, Ho, Wo, KH, KW, cstride, pad;
+    // bf16-activation convolutions: {mean, rstd} [frame][Cin] of the PRODUCING layer -- relu((x - mean) * rstd) is applied
+    // to the bf16 input map while it is staged (conv_bf16_c64.hip only); null = the map is read as it is
+    const float* in_norm;
 #ifdef PIPS_GEMM_TRACE
     unsigned long long* trace;   // tools/gemm_trace.py: per-block phase timestamps
 #endif
@@ -193,9 +228,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t st);          // plain GEMM, pick
 int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
 // bf16-operand GEMM (gemm_bf16.hip): A fp32 or bf16, W bf16, C fp32 or bf16; pointers passed as float*
 int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
-int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
+// in_bf16 / out_bf16: the NHWC maps are bf16 instead of fp32 (the bf16 encoder keeps every activation in bf16)
+int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st, int in_bf16 = 0, int out_bf16 = 0);
 // 3x3 / 64 -> 64 channels with the weights of all taps and the tile's halo patch resident in LDS (conv_bf16_c64.hip); 1 = not taken
-int launch_conv3x3_c64_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
+int launch_conv3x3_c64_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st, int in_bf16 = 0, int out_bf16 = 0);
+bool conv3x3_c64_takes(int H, int W, int frames);      // whether that kernel takes a 64 -> 64 3x3 layer of this size
 // the config-3 up-projection as persistent blocks with a generated-assembly tile body (gemm_bf16_asm.hip); 1 = not taken
 int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
 int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16);   // 0 register-staged, 1 / 2 the assembly kernels
@@ -240,6 +277,14 @@ int launch_resize_into(const float* src, int F, int Hs, int Ws, int C, float* ds
                        int Cdst, int coff, hipStream_t st);
 int launch_avgpool2(const float* src, int F, int H, int W, int C, float* dst, hipStream_t st);
 int launch_resize_frames(const void* src, int src_u8, int planes, int h, int w, float* dst, int H, int W, hipStream_t st);
+// bf16-activation forms (encoder_bf16.hip): bf16 NHWC maps in and out, fp32 arithmetic
+int launch_stem_bf16(const void* rgbs, int rgb_u8, const float* w, const float* bias, void* out_bf16, float* stats,
+                     int F, int H, int W, int Ho, int Wo, int* tiles_m, hipStream_t st);
+// mode 0: y = relu(n(x));  1: relu(res + relu(n(x)));  2: relu(n2(res) + relu(n(x)));  3: relu(relu(n2(res)) + relu(n(x)))
+int launch_inorm_apply_bf16(const void* x, const float* stats, const void* res, const float* res_stats, int mode,
+                            void* y, int F, int HW, int C, hipStream_t st);
+int launch_resize_into_bf16(const void* src, int F, int Hs, int Ws, int C, void* dst, int Hd, int Wd, int Cdst, int coff,
+                            hipStream_t st);
 
 // ---------------------------------------------------------------- tracker pieces (track.hip)
 int launch_point_sample(const float* level0, int B, int S, int H8, int W8, const float* xy, int N,

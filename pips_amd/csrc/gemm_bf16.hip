@@ -35,7 +35,7 @@ template <int BM, int BN, int WGM, int WGN, int KS, bool A_BF16, bool OUT_BF16, 
 __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM * WGN * KS == 4) ? 2 : 1) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int NT = WGM * WGN * KS * 64;
     constexpr int BKB = BKE * KS;                   // K elements staged per iteration
-    static_assert(!CONV || (KS == 1 && !A_BF16 && !OUT_BF16), "conv: fp32 map in, fp32 out, no K split");
+    static_assert(!CONV || KS == 1, "conv: no K split");
     constexpr int LDB = BKB * 2 + 16;               // LDS row stride in BYTES (16-byte pad)
     constexpr int TPR = BKB / 8;                    // loader threads per row (8 elements each)
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
     const float* __restrict__ Af = p.A;                                          // A_BF16 == false
     if (CONV) Af += (size_t)frame * p.H * p.Win * p.Cin;
     const unsigned short* __restrict__ Ab = reinterpret_cast<const unsigned short*>(p.A);   // A_BF16 == true
+    if (CONV) Ab += (size_t)frame * p.H * p.Win * p.Cin;
     const unsigned short* __restrict__ Wb = reinterpret_cast<const unsigned short*>(p.W);
 
 #define PIPS_PASSES(X) X(0) X(1) X(2) X(3)
@@ -100,7 +101,13 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
 
 #define PIPS_LOAD(i)                                                                                 \
     if constexpr (i < PA) {                                                                          \
-        if constexpr (A_BF16) rq##i = *reinterpret_cast<const uint4*>(Ab + a_off##i + k0_);          \
+        if constexpr (A_BF16 && CONV) {                                                              \
+            const int hi_ = a_hi##i + kh_, wi_ = a_wi##i + kw_;                                      \
+            const bool ok_ = (unsigned)hi_ < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.Win;       \
+            const uint4 q_ = *reinterpret_cast<const uint4*>(                                        \
+                Ab + ((size_t)(ok_ ? hi_ : 0) * p.Win + (ok_ ? wi_ : 0)) * p.Cin + c0_ + cg * 8);    \
+            rq##i = ok_ ? q_ : make_uint4(0, 0, 0, 0);                                               \
+        } else if constexpr (A_BF16) rq##i = *reinterpret_cast<const uint4*>(Ab + a_off##i + k0_);   \
         else if constexpr (CONV) {                                                                   \
             const int hi_ = a_hi##i + kh_, wi_ = a_wi##i + kw_;                                      \
             const bool ok_ = (unsigned)hi_ < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.Win;       \
@@ -204,7 +211,8 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
 
     if (CONV) {
         // C orientation: col = lane&31, row = (r&3) + 8*(r>>2) + 4*half; fp32 output + column partials
-        float* __restrict__ Cc = p.C + (size_t)frame * p.M * p.ldc;
+        float* __restrict__ Cc = p.C + (size_t)frame * p.M * p.ldc;                                     // !OUT_BF16
+        unsigned short* __restrict__ Ch = reinterpret_cast<unsigned short*>(p.C) + (size_t)frame * p.M * p.ldc;
         float csum[TN], csq[TN], piv[TN];
         // bias added before the predicated stores, full tiles unpredicated (see gemm.hip)
         const bool full_tile = m0 + BM <= p.M && n0 + BN <= p.N;
@@ -222,7 +230,23 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
                 for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
                 const int rbase = m0 + wm * WTM + i * 32 + 4 * half;
                 float* cp = Cc + (size_t)rbase * p.ldc + col;
-                if (full_tile) {
+                if constexpr (OUT_BF16) {
+                    // bf16 map out: channel pairs packed across neighbouring lanes; statistics from the fp32 values
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < p.M && col_ok) {
+                            const float d = v[r] - piv[j];
+                            csum[j] += d;
+                            csq[j] += d * d;
+                        }
+                    }
+                    const int cpair = n0 + wn * WTN + j * 32 + (l31 & ~1);              // N is even: a pair is in or out together
+                    store_c_tile_bf16(v, l31, half, [&](int px) -> unsigned short* {
+                        const int row = m0 + wm * WTM + i * 32 + px;
+                        return (row < p.M && cpair < p.N) ? Ch + (size_t)row * p.ldc + (n0 + wn * WTN + j * 32) : nullptr;
+                    });
+                } else if (full_tile) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         cp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
@@ -339,36 +363,47 @@ static int pick_tile(const GemmArgs& a, hipStream_t st) {
     return launch_bf16_tile<64, 64, 2, 2, 2, A_BF16, OUT_BF16>(a, st);
 }
 
-template <int BM, int BN, int BKE>
-static int launch_conv_tile(const GemmArgs& a, int frames, hipStream_t st) {
+template <int BM, int BN, int BKE, bool A_BF16, bool OUT_BF16>
+static int launch_conv_tile_t(const GemmArgs& a, int frames, hipStream_t st) {
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), frames);
     const size_t lds = (size_t)2 * (BM + BN) * (BKE * 2 + 16);
-    auto kern = gemm_bf16_kernel<BM, BN, 2, 2, 1, false, false, BKE, true>;
+    auto kern = gemm_bf16_kernel<BM, BN, 2, 2, 1, A_BF16, OUT_BF16, BKE, true>;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     PIPS_CHECK_LAUNCH("gemm_bf16_kernel<conv>");
     return PIPS_OK;
+}
+// map types: 0 = fp32 in / fp32 out (pips_conv_nhwc_bf16), 1 = bf16 in / bf16 out, 2 = bf16 in / fp32 out (conv3 -> pyramid)
+template <int BM, int BN, int BKE>
+static int launch_conv_tile(const GemmArgs& a, int frames, hipStream_t st, int types) {
+    if (types == 1) return launch_conv_tile_t<BM, BN, BKE, true, true>(a, frames, st);
+    if (types == 2) return launch_conv_tile_t<BM, BN, BKE, true, false>(a, frames, st);
+    return launch_conv_tile_t<BM, BN, BKE, false, false>(a, frames, st);
 }
 
 // bf16-operand convolution: NHWC fp32 map, weights bf16 [Cout][kh][kw][Cin]; raw fp32 output
 // + instance-norm partials exactly like launch_conv.  Cout = 96 rides a 128-wide tile (the
 // idle quarter costs nothing at the bf16 matrix rate).
-int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) {
+int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st, int in_bf16, int out_bf16) {
     PIPS_CHECK_ARG(a.Cin % 32 == 0 && a.K == a.KH * a.KW * a.Cin, "conv_bf16: Cin %% 32, K = kh*kw*Cin");
-    {
-        const int rc = launch_conv3x3_c64_bf16(a, frames, tiles_m, st);     // 64 -> 64, 3x3: weights + halo patch in LDS
+    PIPS_CHECK_ARG(in_bf16 || !out_bf16, "conv_bf16: fp32 map in, bf16 map out is not built");
+    PIPS_CHECK_ARG(a.N % 2 == 0, "conv_bf16: Cout must be even");
+    if (in_bf16 == out_bf16) {
+        const int rc = launch_conv3x3_c64_bf16(a, frames, tiles_m, st, in_bf16, out_bf16);     // 64 -> 64, 3x3: weights + halo patch in LDS
         if (rc != 1) return rc;
     }
+    PIPS_CHECK_ARG(a.in_norm == nullptr, "conv_bf16: only the LDS-resident 64 -> 64 kernel normalises its input on load");
+    const int types = in_bf16 ? (out_bf16 ? 1 : 2) : 0;
     const bool k64 = a.Cin % 64 == 0;
     const int bn = a.N <= 64 ? 64 : 128;
     const long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.N, bn) * frames;
     const int bm = blocks128 >= 512 ? 128 : 64;
     if (tiles_m) *tiles_m = cdiv(a.M, bm) * 2;       // partials per frame: m tiles x wave rows (WGM = 2)
     if (bm == 128) {
-        if (bn == 128) return k64 ? launch_conv_tile<128, 128, 64>(a, frames, st) : launch_conv_tile<128, 128, 32>(a, frames, st);
-        return k64 ? launch_conv_tile<128, 64, 64>(a, frames, st) : launch_conv_tile<128, 64, 32>(a, frames, st);
+        if (bn == 128) return k64 ? launch_conv_tile<128, 128, 64>(a, frames, st, types) : launch_conv_tile<128, 128, 32>(a, frames, st, types);
+        return k64 ? launch_conv_tile<128, 64, 64>(a, frames, st, types) : launch_conv_tile<128, 64, 32>(a, frames, st, types);
     }
-    if (bn == 128) return k64 ? launch_conv_tile<64, 128, 64>(a, frames, st) : launch_conv_tile<64, 128, 32>(a, frames, st);
-    return k64 ? launch_conv_tile<64, 64, 64>(a, frames, st) : launch_conv_tile<64, 64, 32>(a, frames, st);
+    if (bn == 128) return k64 ? launch_conv_tile<64, 128, 64>(a, frames, st, types) : launch_conv_tile<64, 128, 32>(a, frames, st, types);
+    return k64 ? launch_conv_tile<64, 64, 64>(a, frames, st, types) : launch_conv_tile<64, 64, 32>(a, frames, st, types);
 }
 
 // A: fp32 [M][lda] (a_bf16 = 0) or bf16 [M][lda]; W: bf16 [N][K]; C: fp32 or bf16 [M][ldc]

@@ -322,6 +322,32 @@ def conv_nhwc_bf16(x, w_bf16, bias, ksize, stride, pad, want_stats=False):
     return out
 
 
+def conv_nhwc_bf16_maps(x_bf16, w_bf16, bias, ksize, stride, pad, in_norm=None, out_bf16=True, want_stats=False):
+    """The same convolution on a bf16 NHWC map (the bf16 encoder's form): ``in_norm`` (F, Cin, 2) = {mean, rstd} of the
+    producing layer applies relu((x - mean) * rstd) while the map is staged (64 -> 64 3x3 layers the LDS-resident kernel
+    takes); the output map is bf16 or fp32."""
+    lib = _lib.load()
+    assert x_bf16.dtype == torch.bfloat16 and w_bf16.dtype == torch.bfloat16 and x_bf16.is_cuda
+    x_bf16, w_bf16 = x_bf16.contiguous(), w_bf16.contiguous()
+    F, H, W, Cin = x_bf16.shape
+    Cout = w_bf16.shape[0]
+    Ho = (H + 2 * pad - ksize) // stride + 1
+    Wo = (W + 2 * pad - ksize) // stride + 1
+    out = torch.empty(F, Ho, Wo, Cout, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x_bf16.device)
+    nrm = None if in_norm is None else _f32(in_norm)
+    stats = None
+    if want_stats:
+        stats = torch.zeros(F, 2 * ((Ho * Wo + 63) // 64) + 4, Cout, 4, dtype=torch.float32, device=x_bf16.device)
+    tiles = C.c_int(0)
+    with torch.cuda.device(x_bf16.device):
+        _lib.check(lib.pips_conv_nhwc_bf16_maps(_lib.ptr(x_bf16), _lib.ptr(nrm), F, H, W, Cin, _lib.ptr(w_bf16), _lib.ptr(bias),
+                                                Cout, ksize, stride, pad, _lib.ptr(out), 1 if out_bf16 else 0, _lib.ptr(stats),
+                                                C.byref(tiles), _stream()), "pips_conv_nhwc_bf16_maps")
+    if want_stats:
+        return out, stats.view(-1)[: F * tiles.value * Cout * 4].view(F, tiles.value, Cout, 4)
+    return out
+
+
 def conv_nhwc_x3(x, w3, bias, ksize, stride, pad, want_stats=False):
     """conv_nhwc() on the split-bf16 path; w3 = split_bf16x3(w_packed)."""
     lib = _lib.load()

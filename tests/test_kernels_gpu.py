@@ -192,6 +192,48 @@ def test_conv_nhwc_bf16(F_, H, W, Cin, Cout):
     assert _rel_err(s2, (out.double() ** 2).sum(dim=(1, 2))) < 1e-5
 
 
+@pytest.mark.parametrize("F_,H,W,Cin,Cout,k,s,norm,out_bf16", [
+    (16, 92, 124, 64, 64, 3, 1, True, True),     # LDS-resident 64 -> 64 kernel, producer's InstanceNorm + ReLU applied on load
+    (4, 186, 250, 64, 64, 3, 1, True, True),     # ragged rows and columns
+    (16, 92, 124, 64, 64, 3, 1, False, True),    # the same kernel on a finished activation
+    (2, 46, 62, 64, 64, 3, 1, False, True),      # too few tiles: implicit GEMM on bf16 maps
+    (8, 92, 124, 96, 96, 3, 1, False, True),     # Cout = 96 on a 128-wide tile
+    (8, 93, 125, 64, 96, 3, 2, False, True),     # stride 2, odd size
+    (8, 92, 124, 64, 96, 1, 2, False, True),     # the 1x1 stride-2 shortcut
+    (8, 46, 62, 256, 128, 1, 1, False, False),   # conv3: bf16 map in, fp32 pyramid out
+])
+def test_conv_nhwc_bf16_maps(F_, H, W, Cin, Cout, k, s, norm, out_bf16):
+    """Convolutions of the bf16 encoder mode: bf16 map in (optionally normalised + ReLU'd while staged), bf16 or fp32 map out,
+    against conv2d in fp64 of exactly the operands the kernel is specified to form; statistics against the fp32 values."""
+    from pips_amd import ops
+    g = torch.Generator().manual_seed(F_ + H + Cin + k)
+    x = (torch.randn(F_, H, W, Cin, generator=g) * 1.5 + 0.3).bfloat16()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / math.sqrt(Cin * k * k)).bfloat16()
+    b = torch.randn(Cout, generator=g)
+    nrm = None
+    xin = x.float()
+    if norm:
+        mean = torch.randn(F_, Cin, generator=g) * 0.3
+        rstd = torch.rand(F_, Cin, generator=g) + 0.5
+        nrm = torch.stack([mean, rstd], dim=-1)
+        xin = torch.relu((xin - mean[:, None, None, :]) * rstd[:, None, None, :]).bfloat16().float()   # one rounding, on staging
+    p = k // 2
+    out, stats = ops.conv_nhwc_bf16_maps(x.to(DEV), w.to(DEV), b.to(DEV), k, s, p, in_norm=None if nrm is None else nrm.to(DEV),
+                                         out_bf16=out_bf16, want_stats=True)
+    ref = F.conv2d(xin.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), stride=s, padding=p).permute(0, 2, 3, 1)
+    out = out.cpu()
+    assert out.dtype == (torch.bfloat16 if out_bf16 else torch.float32) and tuple(out.shape) == tuple(ref.shape)
+    if out_bf16:
+        # the stored map is the RNE rounding of the fp32 result: within half a bf16 ulp (+ fp32 summation noise) of fp64
+        err = (out.double() - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-5).all()), float((err / (ref.abs() + 1e-3)).max())
+    else:
+        assert _rel_err(out.double(), ref) < 2e-6
+    s1, s2 = ops.partial_sums(stats.cpu())                     # statistics come from the fp32 accumulators
+    assert _rel_err(s1, ref.sum(dim=(1, 2))) < 1e-5
+    assert _rel_err(s2, (ref * ref).sum(dim=(1, 2))) < 1e-5
+
+
 # ----------------------------------------------------------------------------- encoder
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("H,W,stride", [(128, 160, 8), (96, 128, 4), (136, 200, 8), (368, 496, 8)])
@@ -243,20 +285,32 @@ def test_encoder_low_variance_frames(kind, weights_raw, arenas):
     assert err < 4 * floor + 1e-5
 
 
-def test_encoder_bf16_operands(weights_raw, arenas):
-    """bf16 conv operands (config 3): maps within bf16-level error of the fp32 oracle."""
+@pytest.mark.parametrize("F_,H,W", [(8, 128, 160), (16, 184, 248)])   # the second size takes the fused LDS-resident layer-1 path
+def test_encoder_bf16_operands(F_, H, W, weights_raw, arenas):
+    """bf16 encoder mode (config 3: bf16 conv operands AND bf16 activation maps, the rounding points of the reference under
+    torch.autocast(bfloat16)): maps within bf16-level error of the fp32 oracle, and no further from the oracle run under
+    autocast than that run is from fp32."""
     from pips_amd import ops
     O = _oracle()
     g = torch.Generator().manual_seed(3)
-    rgbs = torch.randint(0, 256, (8, 3, 128, 160), generator=g).float()
-    fm = O.encoder(weights_raw, 2 * (rgbs / 255.0) - 1.0, 8)
+    rgbs = torch.randint(0, 256, (F_, 3, H, W), generator=g).float()
+    x = 2 * (rgbs / 255.0) - 1.0
+    fm = O.encoder(weights_raw, x, 8)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        fm_ac = O.encoder(weights_raw, x, 8).float()
     pyr = ops.encoder_fwd(arenas["raw"], rgbs.to(DEV), 8, bf16=True)
-    got = ops.pyramid_levels(pyr, 8, 128, 160, 8)[0].cpu()
-    ref = fm.permute(0, 2, 3, 1)
+    got = ops.pyramid_levels(pyr, F_, H, W, 8)[0].cpu()
+    ref, ref_ac = fm.permute(0, 2, 3, 1), fm_ac.permute(0, 2, 3, 1)
+    rms = lambda a, b: float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
     rel = float((got - ref).abs().max() / ref.abs().max())
-    rms = float(((got - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
-    print(f"bf16-operand encoder: max rel err {rel:.2e}, rms rel err {rms:.2e}")
-    assert 1e-5 < rel < 5e-2 and rms < 3e-2           # 21 convs x 2^-9 operand rounding: ~1.5 % rms
+    print(f"bf16 encoder {F_}x{H}x{W}: vs fp32 oracle max rel {rel:.2e} rms {rms(got, ref):.2e}; vs autocast oracle rms "
+          f"{rms(got, ref_ac):.2e}; autocast oracle vs fp32 oracle rms {rms(ref_ac, ref):.2e}")
+    assert 1e-5 < rel < 8e-2 and rms(got, ref) < 4e-2          # 22 convs x 2^-9 operand + activation rounding
+    assert rms(got, ref_ac) < 1.5 * rms(ref_ac, ref) + 5e-3
+    # levels 1-3 are 2x2 means of the fp32 level-0 map
+    lv = ops.pyramid_levels(pyr, F_, H, W, 8)
+    pooled = torch.nn.functional.avg_pool2d(lv[0].permute(0, 3, 1, 2), 2, stride=2).permute(0, 2, 3, 1)
+    assert float((lv[1] - pooled).abs().max()) < 1e-5
 
 
 # ----------------------------------------------------------------------------- tracker stages
