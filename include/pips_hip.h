@@ -240,10 +240,13 @@ int    pips_conv_nhwc_bf16(const float* in, int F, int H, int W, int Cin,
  * in_norm (optional, 64 -> 64 3x3 stride-1 layers on maps the LDS-resident kernel takes: >= 512 tiles of 4x64 pixels)
  * holds {mean, rstd} per (frame, input channel) of the layer that produced the map, and relu((x - mean) * rstd) is
  * applied to it while it is staged (taps outside the image stay zero); out is bf16 (out_is_bf16) or fp32; the
- * statistics are taken from the fp32 accumulators. */
+ * statistics are taken from the fp32 accumulators.  stats_parts_cap = room in stats in partials per frame (0 = the
+ * 2*ceil(Ho*Wo/64)+4 of pips_conv_nhwc_f32); the ping-pong 64 -> 64 kernel wants ceil(W/32)*ceil(H/4)*4 and is
+ * only taken when that fits. */
 int    pips_conv_nhwc_bf16_maps(const void* in_bf16, const float* in_norm, int F, int H, int W, int Cin,
                                 const void* wgt_bf16, const float* bias, int Cout, int ksize, int cstride, int pad,
-                                void* out, int out_is_bf16, float* stats, int* tiles_m_host, void* stream);
+                                void* out, int out_is_bf16, float* stats, int stats_parts_cap, int* tiles_m_host,
+                                void* stream);
 
 /* Split-bf16 ("bf16x3") building blocks: fp32-grade results from the bf16 matrix cores.  Every
  * fp32 operand is split exactly into three bf16 terms and each product is formed from six exact

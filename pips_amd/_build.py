@@ -12,6 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpips_hip.so")
 SOURCES = ["gemm.hip", "encoder.hip", "encoder_bf16.hip", "track.hip", "gather_tiled.hip", "scoremap.hip", "gemm_bf16.hip", "gemm_bf16_asm.hip", "conv_bf16_c64.hip", "gemm_x3.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# per-file additions.  conv_bf16_c64.hip: its VALU work runs beside MFMAs of a co-resident wave, where packed fp32 ops are an
+# anti-lever -- keep hipcc's SLP vectoriser from re-packing the scalar ops (MI355X_MICROARCH.md)
+FILE_FLAGS = {"conv_bf16_c64.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -49,7 +52,7 @@ def build_library(force: bool = False, verbose: bool = True, tuning: bool = Fals
         o = os.path.join(CSRC, src.replace(".hip", ".tune.o" if tuning else ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers_):
-            cmd = [hipcc, *FLAGS, *(["-DPIPS_TUNING"] if tuning else []), "-c", s, "-o", o]
+            cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src, []), *(["-DPIPS_TUNING"] if tuning else []), "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))

@@ -66,7 +66,7 @@ SIGNATURES = {
     "pips_conv_nhwc_bf16": (c_int, [fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp,
                                     C.POINTER(c_int), c_void_p]),
     "pips_conv_nhwc_bf16_maps": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int,
-                                         c_void_p, c_int, fp, C.POINTER(c_int), c_void_p]),
+                                         c_void_p, c_int, fp, c_int, C.POINTER(c_int), c_void_p]),
     "pips_split_bf16x3": (c_int, [fp, c_size_t, c_void_p, c_void_p]),
     "pips_gemm_f32x3": (c_int, [fp, c_int, c_void_p, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, c_int, c_void_p]),
     "pips_conv_nhwc_f32x3": (c_int, [fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp,

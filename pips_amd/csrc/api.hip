@@ -263,10 +263,10 @@ int pips_gemm_f32x3(const float* A, int lda, const void* W3, const float* bias, 
 // in_bf16 / out_bf16 (mm == 1 only): the NHWC maps themselves are bf16; in_norm: see GemmArgs
 static int conv_nhwc(const float* in, int F, int H, int W, int Cin, const float* wgt, const float* bias, int Cout,
                      int k, int s, int p, float* out, float* stats, int* tiles, hipStream_t st, int bf16 = 0,
-                     int in_bf16 = 0, int out_bf16 = 0, const float* in_norm = nullptr) {
+                     int in_bf16 = 0, int out_bf16 = 0, const float* in_norm = nullptr, int parts_cap = 0) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.A = in; g.W = wgt; g.bias = bias; g.C = out; g.stats = stats; g.in_norm = in_norm;
+    g.A = in; g.W = wgt; g.bias = bias; g.C = out; g.stats = stats; g.in_norm = in_norm; g.stats_parts_cap = parts_cap;
     g.H = H; g.Win = W; g.Cin = Cin; g.KH = g.KW = k; g.cstride = s; g.pad = p;
     g.Ho = conv_out(H, k, s, p); g.Wo = conv_out(W, k, s, p);
     g.M = g.Ho * g.Wo; g.N = Cout; g.K = k * k * Cin; g.ldc = Cout; g.epi = EPI_BIAS;
@@ -278,10 +278,10 @@ static int conv_nhwc(const float* in, int F, int H, int W, int Cin, const float*
 
 int pips_conv_nhwc_bf16_maps(const void* in_bf16, const float* in_norm, int F, int H, int W, int Cin, const void* wgt_bf16,
                              const float* bias, int Cout, int ksize, int cstride, int pad, void* out, int out_is_bf16,
-                             float* stats, int* tiles_m_host, void* stream) {
+                             float* stats, int stats_parts_cap, int* tiles_m_host, void* stream) {
     PIPS_CHECK_ARG(in_bf16 && wgt_bf16 && out, "conv_bf16_maps: null pointer");
     return conv_nhwc((const float*)in_bf16, F, H, W, Cin, (const float*)wgt_bf16, bias, Cout, ksize, cstride, pad, (float*)out,
-                     stats, tiles_m_host, (hipStream_t)stream, 1, 1, out_is_bf16 ? 1 : 0, in_norm);
+                     stats, tiles_m_host, (hipStream_t)stream, 1, 1, out_is_bf16 ? 1 : 0, in_norm, stats_parts_cap);
 }
 
 int pips_conv_nhwc_f32x3(const float* in, int F, int H, int W, int Cin, const void* wgt3, const float* bias,
@@ -323,6 +323,13 @@ struct EncPlan {
     size_t total;             // floats
 };
 
+// room for InstanceNorm partials per frame of a layer with H x W output pixels: the documented bound of the conv entry
+// points, or one partial per wave of the 4 x 32-pixel tiles of the ping-pong 64 -> 64 kernel (conv_bf16_c64.hip)
+int enc_parts_cap(int H, int W) {
+    const int a = 2 * cdiv(H * W, 64) + 4, b = cdiv(W, 32) * cdiv(H, 4) * 4;
+    return a > b ? a : b;
+}
+
 EncPlan plan_encoder(int F, int H, int W, int stride) {
     EncPlan P;
     P.F = F; P.H = H; P.W = W; P.stride = stride;
@@ -341,7 +348,7 @@ EncPlan plan_encoder(int F, int H, int W, int stride) {
     // partial statistics: float4 [F][parts][C]; parts <= 2 wave rows x (rows/64 + 1) m tiles
     size_t pmax = 0;
     for (int l = 0; l < 4; ++l) {
-        size_t t = (size_t)F * (2 * cdiv(P.Hs[l] * P.Ws[l], 64) + 4) * ch[l] * 4;
+        size_t t = (size_t)F * enc_parts_cap(P.Hs[l], P.Ws[l]) * ch[l] * 4;
         pmax = pmax > t ? pmax : t;
     }
     {
@@ -427,7 +434,8 @@ int conv_stats_h(const float* arena, const ArenaLayout& A, int ci, const void* i
     const ConvW& c = A.conv[ci];
     int tiles = 0;
     RUN(conv_nhwc((const float*)in, F, H, W, c.cin, conv_w(arena, A, ci, 1), arena + c.b, c.cout, c.k, c.stride, c.pad,
-                  (float*)out, partial, &tiles, st, 1, 1, 1, in_norm));
+                  (float*)out, partial, &tiles, st, 1, 1, 1, in_norm,
+                  enc_parts_cap(conv_out(H, c.k, c.stride, c.pad), conv_out(W, c.k, c.stride, c.pad))));
     return launch_inorm_finalize_pivot(partial, F, tiles, c.cout, mean_rstd, st);
 }
 

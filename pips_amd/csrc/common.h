@@ -69,6 +69,12 @@ __device__ __forceinline__ f2 gelu_exact2(f2 x) {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup barrier that orders LDS traffic ONLY.  hipcc's __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: it
+// also drains the wave's global loads and stores, so a prefetch issued before a barrier is waited for AT the barrier and the
+// full memory latency is exposed once per barrier (measured in conv3x3_c64_pp_kernel: 8k clocks per half step whatever the
+// half step did).  Register dependences on outstanding loads are still tracked by the compiler's own s_waitcnt insertion.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------- bf16 activations (bf16 encoder mode)
 // two floats -> one dword of two bf16 (hardware round-to-nearest-even, v_cvt_pk_bf16_f32); lo in bits 0-15
 __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
@@ -93,10 +99,13 @@ __device__ __forceinline__ void store_c_tile_bf16(const float (&v)[16], int l31,
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
         const int r0 = 2 * rr, r1 = r0 + 1;                                  // consecutive pixels
-        const float recv = lane_xor1(odd ? v[r0] : v[r1]);
-        const unsigned d = odd ? pack2_bf16(recv, v[r1]) : pack2_bf16(v[r0], recv);
-        const int r = odd ? r1 : r0;
-        unsigned short* row = px_ptr((r & 3) + 8 * (r >> 2) + 4 * half);
+        float a = v[r0], b = v[r1];
+        // opaque copies: hipcc otherwise reads "odd ? v[r0] : v[r1]" as a dynamically indexed element of the accumulator
+        // vector and lowers it to a 16-step compare/select chain per value (measured: +1100 VALU instructions per tile)
+        asm("" : "+v"(a), "+v"(b));
+        const float recv = lane_xor1(odd ? a : b);
+        const unsigned d = pack2_bf16(odd ? recv : a, odd ? b : recv);
+        unsigned short* row = px_ptr((r0 & 3) + 8 * (r0 >> 2) + 4 * half + (odd ? 1 : 0));
         if (row != nullptr) *reinterpret_cast<unsigned*>(row + (l31 & ~1)) = d;
     }
 }
@@ -166,6 +175,7 @@ struct GemmArgs {
     // bf16-activation convolutions: {mean, rstd} [frame][Cin] of the PRODUCING layer -- relu((x - mean) * rstd) is applied
     // to the bf16 input map while it is staged (conv_bf16_c64.hip only); null = the map is read as it is
     const float* in_norm;
+    int stats_parts_cap;     // room in stats in partials per frame; 0 = the documented 2*ceil(Ho*Wo/64)+4
 #ifdef PIPS_GEMM_TRACE
     unsigned long long* trace;   // tools/gemm_trace.py: per-block phase timestamps
 #endif

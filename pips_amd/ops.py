@@ -336,13 +336,14 @@ def conv_nhwc_bf16_maps(x_bf16, w_bf16, bias, ksize, stride, pad, in_norm=None, 
     out = torch.empty(F, Ho, Wo, Cout, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x_bf16.device)
     nrm = None if in_norm is None else _f32(in_norm)
     stats = None
+    cap = max(2 * ((Ho * Wo + 63) // 64) + 4, ((Wo + 31) // 32) * ((Ho + 3) // 4) * 4)
     if want_stats:
-        stats = torch.zeros(F, 2 * ((Ho * Wo + 63) // 64) + 4, Cout, 4, dtype=torch.float32, device=x_bf16.device)
+        stats = torch.zeros(F, cap, Cout, 4, dtype=torch.float32, device=x_bf16.device)
     tiles = C.c_int(0)
     with torch.cuda.device(x_bf16.device):
         _lib.check(lib.pips_conv_nhwc_bf16_maps(_lib.ptr(x_bf16), _lib.ptr(nrm), F, H, W, Cin, _lib.ptr(w_bf16), _lib.ptr(bias),
                                                 Cout, ksize, stride, pad, _lib.ptr(out), 1 if out_bf16 else 0, _lib.ptr(stats),
-                                                C.byref(tiles), _stream()), "pips_conv_nhwc_bf16_maps")
+                                                cap, C.byref(tiles), _stream()), "pips_conv_nhwc_bf16_maps")
     if want_stats:
         return out, stats.view(-1)[: F * tiles.value * Cout * 4].view(F, tiles.value, Cout, 4)
     return out

@@ -225,8 +225,9 @@ def test_conv_nhwc_bf16_maps(F_, H, W, Cin, Cout, k, s, norm, out_bf16):
     assert out.dtype == (torch.bfloat16 if out_bf16 else torch.float32) and tuple(out.shape) == tuple(ref.shape)
     if out_bf16:
         # the stored map is the RNE rounding of the fp32 result: within half a bf16 ulp (+ fp32 summation noise) of fp64
+        # (normalise-on-load: the kernel forms x * rstd - mean * rstd, a staged value may round to the neighbouring bf16)
         err = (out.double() - ref).abs()
-        assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-5).all()), float((err / (ref.abs() + 1e-3)).max())
+        assert bool((err <= ref.abs() * 2.0 ** -8 + (3e-3 if norm else 1e-5)).all()), float((err / (ref.abs() + 1e-3)).max())
     else:
         assert _rel_err(out.double(), ref) < 2e-6
     s1, s2 = ops.partial_sums(stats.cpu())                     # statistics come from the fp32 accumulators
