@@ -14,8 +14,13 @@ the script reads RANK/LOCAL_RANK/WORLD_SIZE; launched bare (WORLD_SIZE unset) it
 itself under torch.distributed.run with N ranks.  WORLD_SIZE != N is an error.
 
 Prints ONE JSON line (rank 0): the driver contract plus
+  "ms_per_step_median"  -- median of the per-step durations between HIP events recorded around every timed step (the
+                           contract's ms_per_step / value stay the wall-clock bracket over all K steps);
   "roofline"            -- dominant kernel (fp32-MFMA GEMM of the mixer) vs the 157.3 TF fp32 peak,
-                           timed live with HIP events on the launch stream;
+                           timed live with HIP events on the launch stream (any number of ranks: measured on rank 0);
+  "config3"             -- BASELINE configs[2] (bf16 operands): "weak" = B=8 clips per GPU, "strong" = B=64 clips in total
+                           split over the ranks, both barrier-bracketed, max over ranks, all-gather included;
+  "collective_ms"       -- the final all-gather of [x,y,vis] alone (N > 1), HIP-event timed;
   "gather"              -- the correlation-gather kernel at config 2 (L2-resident; informational);
   "stages_ms"           -- where one forward's time goes;
   "config3"/"config4"/"config5" -- the other BASELINE configs, each with its own numbers; config4
@@ -77,11 +82,47 @@ def ev_time_ms(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def gemm_roofline(model, device, b, flags=0):
+    """The dominant kernel -- the mixer's channel-mix GEMMs -- timed IN SITU: a real mixer pass on the real weights with a
+    HIP event pair around every GEMM launch on the launch stream (pips_mixer_fwd_timed); mean over the 12 layers and 5
+    passes, empty-pair overhead subtracted.  Returns {name: {ms, tflops}}."""
+    import torch
+    from pips_amd import ops
+    arena = model._packed(device, need=7)
+    M = b * NPTS * S
+    X = torch.randn(M, 544, generator=torch.Generator().manual_seed(0)).to(device)
+    ups, downs, ovh = [], [], []
+    for _ in range(6):
+        _, t = ops.mixer_fwd_timed(arena, X, flags=flags)
+        ups.append(t["up_proj"]); downs.append(t["down_proj"]); ovh.append(t["event_overhead"])
+    ups, downs, ovh = ups[1:], downs[1:], ovh[1:]
+    o = sum(ovh) / len(ovh)
+    t_up, t_down = sum(ups) / len(ups) - o, sum(downs) / len(downs) - o
+    flops = 2.0 * M * 2048 * 512
+    return {"up_proj(M=%d,N=2048,K=512)" % M: {"ms": t_up, "tflops": flops / t_up / 1e9},
+            "down_proj(M=%d,N=512,K=2048)" % M: {"ms": t_down, "tflops": flops / t_down / 1e9}}
+
+
+def roofline_object(kern, fake=False):
+    dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
+    # HBM-side bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+    # command, committed per round under profiles/ (a live bench run cannot collect PMC counters itself)
+    traffic, traffic_src = pmc_traffic("igemm_f32_kernel<64, 64, 2, 2, 1, false>" if dom[0].startswith("up") else
+                                       "igemm_f32_kernel<64, 64, 2, 2, 2, false>")
+    # both GEMM shapes run the same kernel template; report the slower (dominant) launch
+    return {"bound": "mfma", "achieved": dom[1]["tflops"], "peak": PEAK_F32_MFMA_TF,
+            "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_F32_MFMA_TF, "traffic": traffic,
+            "traffic_source": traffic_src,
+            "kernel": "igemm_f32_kernel " + dom[0], "launch_ms": dom[1]["ms"],
+            "timing": "HIP event pair around each in-situ launch, empty-pair overhead subtracted",
+            "all": kern}
+
+
 def stage_profile(model, xys, rgbs, device, b):
     """Per-stage and per-kernel timings with the staged C-ABI entry points (same kernels)."""
     import torch
     from pips_amd import ops
-    arena = model._packed(device)
+    arena = model._packed(device, need=7)          # this leg also times the bf16 / split kernels on the same arena
     F = b * S
     H8, W8 = H // STRIDE, W // STRIDE
     M = b * NPTS * S
@@ -152,26 +193,109 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
-def config3_leg(device):
-    """BASELINE configs[2] per-GPU share: B=8 clips, bf16 MFMA operands."""
+def _max_over_ranks(dt, world, device, on_device):
+    if world == 1:
+        return dt
     import torch
-    from pips_amd import Pips
+    import torch.distributed as dist
+    t = torch.tensor([dt], device=device if on_device else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def config3_leg(device, world=1, rank=0, fake=False, on_device_collectives=True):
+    """BASELINE configs[2]: bf16 MFMA operands, clips sharded over the ranks + one all-gather of [x,y,vis] per step.
+    weak = 8 clips per GPU (the config's per-GPU share at 8 GPUs); strong = 64 clips in total, 64 / world per GPU, run as
+    forwards of <= 8 clips.  Every figure: barrier + synchronize on both sides, max over ranks, >= 10 timed steps."""
+    import torch
+    import torch.distributed as dist
+    from pips_amd import dist as pdist
     b = 8
-    model = Pips(S=S, stride=STRIDE).to(device).eval()
-    model.mixer_dtype = model.encoder_dtype = torch.bfloat16
-    xys, rgbs = make_inputs(0, device, b)
-    fn = lambda: model(xys, rgbs, iters=ITERS)
-    for _ in range(2):
-        fn()
-    t = ev_time_ms(fn, 5)
+    if fake:
+        model = _CpuStandIn()
+        xys, rgbs = make_inputs(rank, device, b, 32, 32, 16)
+        npts = 16
+    else:
+        from pips_amd import Pips
+        model = Pips(S=S, stride=STRIDE).to(device).eval()
+        model.mixer_dtype = model.encoder_dtype = torch.bfloat16
+        xys, rgbs = make_inputs(rank, device, b)
+        npts = NPTS
+    sync = (lambda: None) if fake else torch.cuda.synchronize
+
+    def step(nclips):
+        preds = vis = None
+        done = 0
+        while done < nclips:                                    # forwards of <= 8 clips (one GPU's share of the weak case)
+            n = min(b, nclips - done)
+            preds, _, vis, _ = model(xys[:n], rgbs[:n], iters=ITERS)
+            done += n
+        if world > 1:
+            pdist.all_gather_result(preds[-1], vis)
+
+    def timed(nclips, reps):
+        for _ in range(2):
+            step(nclips)
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step(nclips)
+        sync()
+        if world > 1:
+            dist.barrier()
+        dt = _max_over_ranks(time.perf_counter() - t0, world, device, on_device_collectives and not fake)
+        return dt / reps * 1e3
+
     flop_per_update = 72.2e6
-    ups = b * S * NPTS * ITERS / t * 1e3
-    return {"workload": "BASELINE configs[2], one GPU's share: B=8 S=8 368x496 N=256 I=6, bf16 MFMA operands "
-                        "(fp32 accumulate/state), encoder included",
-            "value": ups, "unit": "particle-updates/s", "ms_per_step": t, "dtype": "bf16 MFMA operands",
-            "roofline": {"bound": "mfma", "achieved": ups * flop_per_update / 1e12, "peak": PEAK_BF16_MFMA_TF,
-                         "unit": "TFLOP/s", "frac": ups * flop_per_update / 1e12 / PEAK_BF16_MFMA_TF,
-                         "note": "whole forward: 72.2 MFLOP per particle-update (SURVEY 8d) against the dense bf16 MFMA peak"}}
+    t_weak = timed(b, 10)
+    ups_weak = world * b * S * npts * ITERS / t_weak * 1e3
+    total_strong = 64
+    out = {"workload": "BASELINE configs[2]: S=8 368x496 N=256 I=6, bf16 MFMA operands and bf16 encoder activations (fp32 "
+                       "accumulate / residual stream / state), encoder included, clips sharded over the ranks",
+           "n_gpus": world, "unit": "particle-updates/s", "dtype": "bf16 MFMA operands",
+           "weak": {"clips_per_gpu": b, "clips_total": b * world, "ms_per_step": t_weak, "value": ups_weak, "steps": 10},
+           # back-compatible top-level fields = the weak case (one GPU's share B=8)
+           "value": ups_weak, "ms_per_step": t_weak}
+    if total_strong % world == 0:
+        per = total_strong // world
+        reps = 10 if per <= b else 3
+        t_strong = timed(per, reps)
+        out["strong"] = {"clips_total": total_strong, "clips_per_gpu": per, "ms_per_step": t_strong,
+                         "value": total_strong * S * npts * ITERS / t_strong * 1e3, "steps": reps,
+                         "note": "64 clips per step in forwards of <= 8 clips per GPU"}
+    per_gpu = ups_weak / world
+    out["roofline"] = {"bound": "mfma", "achieved": per_gpu * flop_per_update / 1e12, "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s",
+                       "frac": per_gpu * flop_per_update / 1e12 / PEAK_BF16_MFMA_TF,
+                       "note": "whole forward per GPU: 72.2 MFLOP per particle-update (SURVEY 8d) against the dense bf16 MFMA peak"}
+    return out
+
+
+def collective_leg(device, world, fake, npts):
+    """The data path's only exchange, alone: all_gather_into_tensor of the packed [x,y,vis] of 8 clips per rank
+    (196 KB per rank at N=256), event-timed (wall-clock under the CPU stand-in), median of 20."""
+    import torch
+    from pips_amd import dist as pdist
+    tr = torch.zeros(8, S, npts, 2, device=device)
+    vi = torch.zeros(8, S, npts, device=device)
+    ts = []
+    for i in range(25):
+        if fake:
+            t0 = time.perf_counter()
+            pdist.all_gather_result(tr, vi)
+            dt = (time.perf_counter() - t0) * 1e3
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            pdist.all_gather_result(tr, vi)
+            e1.record()
+            e1.synchronize()
+            dt = e0.elapsed_time(e1)
+        if i >= 5:
+            ts.append(dt)
+    return {"median_ms": statistics.median(ts), "bytes_per_rank": int(tr.numel() * 4 + vi.numel() * 4), "reps": len(ts),
+            "what": "pack [x,y,vis] + all_gather_into_tensor + unpack (pips_amd.dist.all_gather_result)"}
 
 
 def config4_leg(device):
@@ -378,24 +502,41 @@ def main(argv=None):
             pdist.all_gather_result(preds[-1], vis)
         return preds
 
+    on_dev = backend == "nccl" and not fake
+
+    def timed_steps(nsteps):
+        """The contract's bracket (barrier + synchronize, wall clock over exactly nsteps steps, max over ranks) and, beside
+        it, one HIP event per step boundary on the launch stream -> per-step durations (median reported)."""
+        if world > 1:
+            dist.barrier()
+        sync()
+        evs = [] if fake else [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]
+        marks = []
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            if fake:
+                marks.append(time.perf_counter())
+            else:
+                evs[i].record()
+            step()
+        if fake:
+            marks.append(time.perf_counter())
+        else:
+            evs[nsteps].record()
+        sync()
+        if world > 1:
+            dist.barrier()
+        dt = _max_over_ranks(time.perf_counter() - t0, world, device, on_dev)
+        per = ([(b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:])] if fake else
+               [evs[i].elapsed_time(evs[i + 1]) for i in range(nsteps)])
+        return dt, per
+
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device if (backend == "nccl" and not fake) else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, per_step = timed_steps(args.steps)
 
-    updates = world * b_per_gpu * S * (16 if fake else NPTS) * ITERS * args.steps
+    npts = 16 if fake else NPTS
+    updates = world * b_per_gpu * S * npts * ITERS * args.steps
     res = {
         "metric": "particle-updates/sec (B*S*N*iters/s) at S=8 N=256 368x496",
         "value": updates / dt,
@@ -404,6 +545,10 @@ def main(argv=None):
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step_median": statistics.median(per_step),
+        "ms_per_step_timing": "ms_per_step: wall clock over all timed steps (barrier + synchronize on both sides, max over ranks); "
+                              "ms_per_step_median: median of the per-step gaps between HIP events recorded on the launch stream "
+                              "(rank 0)",
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -421,41 +566,38 @@ def main(argv=None):
     }
     if fake:
         res["data"] = "PIPS_BENCH_FAKE=1: CPU stand-in model, launcher/collective self-test only -- not a measurement"
-    headline = rank == 0 and world == 1 and args.config == 2 and args.matmul == "exact" and not fake
+    main_cfg = args.config == 2 and args.matmul == "exact"
+    headline = rank == 0 and world == 1 and main_cfg and not fake
     if headline and not args.no_stage_profile:
         # the same workload on the fp32-grade split-bf16 matrix path (Pips.matmul = "split"; passes the
         # same fp32 parity gates, tests/test_forward_gpu.py) -- reported beside the exact-fp32 headline
         model.matmul = "split"
         for _ in range(args.warmup):
             step()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        dts = time.perf_counter() - t1
+        dts, per_s = timed_steps(args.steps)
         model.matmul = "exact"
         res["split_bf16"] = {"value": updates / dts, "unit": "particle-updates/s", "ms_per_step": dts / args.steps * 1e3,
+                             "ms_per_step_median": statistics.median(per_s),
                              "note": "Pips.matmul='split' (PIPS_FLAG_SPLIT_BF16): mixer GEMMs + the larger convs as "
                                      "6 exact bf16 MFMA products per fp32 product; same parity gates as fp32"}
         stages, kern, gather, split = stage_profile(model, xys, rgbs, device, b_per_gpu)
         res["split_bf16"].update(split)
-        dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
-        # HBM-side bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
-        # command, committed per round under profiles/ (a live bench run cannot collect PMC counters itself)
-        traffic, traffic_src = pmc_traffic("igemm_f32_kernel<64, 64, 2, 2, 1, false>" if dom[0].startswith("up") else
-                                           "igemm_f32_kernel<64, 64, 2, 2, 2, false>")
-        # both GEMM shapes run the same kernel template; report the slower (dominant) launch
-        res["roofline"] = {"bound": "mfma", "achieved": dom[1]["tflops"], "peak": PEAK_F32_MFMA_TF,
-                           "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_F32_MFMA_TF, "traffic": traffic,
-                           "traffic_source": traffic_src,
-                           "kernel": "igemm_f32_kernel " + dom[0], "launch_ms": dom[1]["ms"],
-                           "timing": "HIP event pair around each in-situ launch, empty-pair overhead subtracted",
-                           "all": kern}
+        res["roofline"] = roofline_object(kern)
         res["gather"] = gather
         res["stages_ms"] = stages
         flop_per_update = 72.2e6
         res["forward_mfma_frac"] = res["value"] / world * flop_per_update / (PEAK_F32_MFMA_TF * 1e12)
+    if world > 1 and main_cfg and not args.no_extras:
+        # A multi-rank line still describes the workload it scales: the dominant kernel's roofline (rank 0, in situ), the
+        # exchange alone, and BASELINE configs[2] -- the multi-GPU config -- weak (8 clips per GPU) and strong (64 clips).
+        if not fake and rank == 0:
+            res["roofline"] = roofline_object(gemm_roofline(model, device, b_per_gpu))
+        dist.barrier()
+        res["collective_ms"] = collective_leg(device, world, fake, npts)
+        try:
+            res["config3"] = config3_leg(device, world, rank, fake, on_dev)
+        except Exception as e:                                       # (every rank raises alike: shapes and code are identical)
+            res["config3"] = {"error": f"{type(e).__name__}: {e}"}
     if headline and not args.no_extras:
         for name, leg in (("config3", config3_leg), ("config4", config4_leg), ("config5", config5_leg),
                           ("torch_rocm_baseline", torch_rocm_baseline)):

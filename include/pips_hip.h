@@ -80,6 +80,14 @@ int         pips_abi_version(void);
  * columns, updater Linear transposed, the rest verbatim). */
 size_t pips_weight_arena_bytes(void);
 int    pips_repack_weights(const void* const* params_host, int nparams, void* arena, void* stream);
+/* The arena's three sections can be (re)built separately: PIPS_PACK_FP32 (the fp32 layouts, from params), PIPS_PACK_BF16
+ * (bf16 copies of every matrix-core weight: the bf16-operand modes) and PIPS_PACK_SPLIT (three bf16 planes per weight: the
+ * split-bf16 mode) -- the last two are derived from the arena's fp32 section (params may be null without PIPS_PACK_FP32),
+ * so a process packs only what its matrix mode reads.  pips_repack_weights = all three. */
+#define PIPS_PACK_FP32  1
+#define PIPS_PACK_BF16  2
+#define PIPS_PACK_SPLIT 4
+int    pips_repack_weights_ex(const void* const* params_host, int nparams, void* arena, int sections, void* stream);
 
 /* ---- whole forward -------------------------------------------------------------------
  * Replaces: Pips.forward, inference branch (nets/pips.py:428-611 minus the dead fcp

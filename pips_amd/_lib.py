@@ -21,6 +21,7 @@ SIGNATURES = {
     "pips_abi_version": (c_int, []),
     "pips_weight_arena_bytes": (c_size_t, []),
     "pips_repack_weights": (c_int, [C.POINTER(c_void_p), c_int, c_void_p, c_void_p]),
+    "pips_repack_weights_ex": (c_int, [C.POINTER(c_void_p), c_int, c_void_p, c_int, c_void_p]),
     "pips_workspace_bytes": (c_size_t, [c_int] * 6),
     "pips_forward": (c_int, [c_void_p, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_void_p, c_size_t, fp, fp, fp, c_void_p]),

@@ -159,13 +159,20 @@ size_t pips_weight_arena_bytes(void) {
 }
 
 int pips_repack_weights(const void* const* params, int nparams, void* arena_v, void* stream) {
-    PIPS_CHECK_ARG(params != nullptr && arena_v != nullptr, "repack: null pointer");
-    PIPS_CHECK_ARG(nparams == PIPS_NPARAMS, "repack: expected %d tensors, got %d", PIPS_NPARAMS, nparams);
-    for (int i = 0; i < nparams; ++i) PIPS_CHECK_ARG(params[i] != nullptr, "repack: tensor %d is null", i);
+    return pips_repack_weights_ex(params, nparams, arena_v, PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT, stream);
+}
+
+int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v, int sections, void* stream) {
+    PIPS_CHECK_ARG(arena_v != nullptr, "repack: null pointer");
+    PIPS_CHECK_ARG(sections != 0 && (sections & ~(PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT)) == 0, "repack: bad section mask %d", sections);
     hipStream_t st = (hipStream_t)stream;
     const ArenaLayout& A = arena_layout();
     float* arena = (float*)arena_v;
     int pi = 0;
+  if (sections & PIPS_PACK_FP32) {
+    PIPS_CHECK_ARG(params != nullptr, "repack: null pointer");
+    PIPS_CHECK_ARG(nparams == PIPS_NPARAMS, "repack: expected %d tensors, got %d", PIPS_NPARAMS, nparams);
+    for (int i = 0; i < nparams; ++i) PIPS_CHECK_ARG(params[i] != nullptr, "repack: tensor %d is null", i);
     auto src = [&]() { return (const float*)params[pi++]; };
     auto copy = [&](size_t dst_off, size_t n) {
         (void)hipMemcpyAsync(arena + dst_off, src(), n * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -201,7 +208,10 @@ int pips_repack_weights(const void* const* params, int nparams, void* arena_v, v
                        PIPS_C, PIPS_C);
     copy(A.b_upd, PIPS_C);
     copy(A.w_vis, PIPS_C); copy(A.b_vis, 1);
-    // bf16 copies of the channel-mix / head weights (bf16-operand mixer)
+    if (pi != PIPS_NPARAMS) return PIPS_E_ARG;
+  }
+  if (sections & PIPS_PACK_BF16) {
+    // bf16 copies of the channel-mix / head / conv weights (bf16-operand modes), from the fp32 section
     __bf16* hb = reinterpret_cast<__bf16*>(arena + A.total);
     auto to_h = [&](size_t src_off, size_t dst_off, size_t n) {
         hipLaunchKernelGGL(cvt_bf16_kernel, dim3(nblk(n)), dim3(256), 0, st, arena + src_off, hb + dst_off, n);
@@ -214,7 +224,9 @@ int pips_repack_weights(const void* const* params, int nparams, void* arena_v, v
     to_h(A.w_in, A.h_in, (size_t)PIPS_DMIX * PIPS_KIN_PAD);
     for (int i = 1; i < 22; ++i)
         to_h(A.conv[i].w, A.h_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
-    // split-bf16 planes of the same weights (fp32-grade matrix path on the bf16 cores)
+  }
+  if (sections & PIPS_PACK_SPLIT) {
+    // split-bf16 planes of the same weights (fp32-grade matrix path on the bf16 cores), from the fp32 section
     unsigned short* tb = reinterpret_cast<unsigned short*>(arena + A.total) + A.total_h;
     auto to_t = [&](size_t src_off, size_t dst_off, size_t n) {
         (void)launch_split_bf16x3(arena + src_off, n, tb + dst_off, st);
@@ -227,8 +239,9 @@ int pips_repack_weights(const void* const* params, int nparams, void* arena_v, v
     to_t(A.w_head, A.t_head, (size_t)PIPS_NOUT * PIPS_DMIX);
     for (int i = 1; i < 22; ++i)
         to_t(A.conv[i].w, A.t_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
+  }
     PIPS_CHECK_LAUNCH("pips_repack_weights");
-    return pi == PIPS_NPARAMS ? PIPS_OK : PIPS_E_ARG;
+    return PIPS_OK;
 }
 
 // ------------------------------------------------------------------ building blocks

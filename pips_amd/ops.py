@@ -28,8 +28,21 @@ def _f32(t):
     return t.contiguous().to(torch.float32)
 
 
-def pack_weights(state_dict, device) -> torch.Tensor:
-    """state dict (reference key names/layouts) -> packed device arena (pips_repack_weights)."""
+PACK_FP32, PACK_BF16, PACK_SPLIT = 1, 2, 4
+
+
+def pack_more(arena, sections):
+    """Build further sections (PACK_BF16 / PACK_SPLIT) of an arena whose fp32 section is already packed."""
+    lib = _lib.load()
+    with torch.cuda.device(arena.device):
+        _lib.check(lib.pips_repack_weights_ex(None, 0, _lib.ptr(arena), int(sections) & ~PACK_FP32, _stream()),
+                   "pips_repack_weights_ex")
+    return arena
+
+
+def pack_weights(state_dict, device, sections=PACK_FP32 | PACK_BF16 | PACK_SPLIT) -> torch.Tensor:
+    """state dict (reference key names/layouts) -> packed device arena (pips_repack_weights_ex); ``sections``: which of the
+    fp32 / bf16-copy / split-plane sections to build now (pack_more adds the others later)."""
     lib = _lib.load()
     names = list(param_table().keys())
     missing = [k for k in names if k not in state_dict]
@@ -39,7 +52,8 @@ def pack_weights(state_dict, device) -> torch.Tensor:
         srcs = [_f32(state_dict[k].detach().to(device)) for k in names]
         arena = torch.empty(lib.pips_weight_arena_bytes() // 4, dtype=torch.float32, device=device)
         arr = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
-        _lib.check(lib.pips_repack_weights(arr, len(srcs), _lib.ptr(arena), _stream()), "pips_repack_weights")
+        _lib.check(lib.pips_repack_weights_ex(arr, len(srcs), _lib.ptr(arena), int(sections) | PACK_FP32, _stream()),
+                   "pips_repack_weights_ex")
         torch.cuda.current_stream().synchronize()      # srcs may be temporaries
     return arena
 

@@ -87,6 +87,7 @@ class Pips(nn.Module):
         self._arena = None
         self._arena_key = None
         self._arena_params = None
+        self._arena_sections = 0
         self._ws = {}
         self._times = None
 
@@ -101,7 +102,13 @@ class Pips(nn.Module):
         self.invalidate_weights()
         return out
 
-    def _packed(self, device):
+    def _packed(self, device, need=None):
+        """The packed weight arena for ``device``.  Only the sections the current matrix mode reads are built (fp32 always;
+        bf16 copies for the bf16-operand modes; split planes for matmul='split'): a rank of a bf16 job never packs the 171 MB
+        of split planes.  ``need`` = ops.PACK_* mask (default: what self._flags() implies)."""
+        if need is None:
+            fl = self._flags()
+            need = ops.PACK_FP32 | (ops.PACK_BF16 if fl & 6 else 0) | (ops.PACK_SPLIT if fl & 16 else 0)
         if self._plist is None:
             # (owning module, leaf name) of every parameter: the LIVE object is looked up on every forward, so a
             # parameter that was replaced (load_state_dict(assign=True), ``node.weight = nn.Parameter(...)``) is seen
@@ -116,9 +123,13 @@ class Pips(nn.Module):
         live = [d[leaf] for d, leaf in self._plist]
         key = (str(device),) + tuple((id(p), p.data_ptr(), p._version) for p in live)
         if self._arena is None or key != self._arena_key:
-            self._arena = ops.pack_weights(dict(zip(self._names, live)), device)
+            self._arena = ops.pack_weights(dict(zip(self._names, live)), device, sections=need)
             self._arena_key = key
+            self._arena_sections = need | ops.PACK_FP32
             self._arena_params = live          # keeps the ids in the key from being recycled
+        elif need & ~self._arena_sections:
+            ops.pack_more(self._arena, need & ~self._arena_sections)
+            self._arena_sections |= need
         return self._arena
 
     def _flags(self):

@@ -133,7 +133,7 @@ def test_packed_weights_follow_parameter_changes():
     import pips_amd.ops as ops
     packed = []
     orig = ops.pack_weights
-    ops.pack_weights = lambda sd, dev: packed.append({k: v for k, v in sd.items()}) or object()
+    ops.pack_weights = lambda sd, dev, sections=7: packed.append({k: v for k, v in sd.items()}) or object()
     try:
         m._packed("cpu")
         m._packed("cpu")

@@ -76,6 +76,13 @@ def test_bench_spawns_its_own_ranks():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["ms_per_step_median"] > 0
+    # a multi-rank line carries the config it is about: the exchange alone, and BASELINE
+    # configs[2] weak (8 clips per GPU) and strong (64 clips in total) -- here through the CPU stand-in
+    assert res["collective_ms"]["median_ms"] > 0 and res["collective_ms"]["reps"] == 20
+    c3 = res["config3"]
+    assert c3["n_gpus"] == 2 and c3["weak"]["clips_per_gpu"] == 8 and c3["weak"]["clips_total"] == 16 and c3["weak"]["value"] > 0
+    assert c3["strong"]["clips_total"] == 64 and c3["strong"]["clips_per_gpu"] == 32 and c3["strong"]["value"] > 0
 
 
 def test_bench_rejects_world_size_mismatch():
