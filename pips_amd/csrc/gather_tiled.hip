@@ -24,9 +24,10 @@
 //                          particle-level); the particle's feature chunk comes through the scalar cache into SGPRs
 //                          (wave-uniform), so a chunk costs a lane 4 `ds_read_b128` + 8 `v_pk_fma_f32` per
 //                          particle-level and no cross-lane reduction; the 48 accumulators of a wave (4 levels x
-//                          6 particles x even/odd chain) stay in registers across the phases.  The LDS image is dense
-//                          (DMA writes 1 KiB linear pieces) and XOR-swizzled on the GLOBAL side -- the lane that fetches
-//                          LDS quad position j of pixel (rx,ry) reads channel quad j ^ (ry & 3).  Particles arrive
+//                          6 particles x even/odd chain) stay in registers across the phases.  The LDS image is a
+//                          sequence of 1 KiB linear DMA pieces; staged rows are PADDED by one 16-byte slot (filled by a
+//                          duplicate fetch): a pixel's four quads sit at consecutive addresses and the b128 reads of a
+//                          service group are conflict-free without a swizzle.  Particles arrive
 //                          sorted by 4x4-pixel cell, so the two slots of a pair often share the window anchor at the
 //                          coarse levels and one fragment serves both.  The 2x2 blend of the 8x8 correlations to the
 //                          49 taps uses ds_bpermute.  The whole item body is generated assembly (gather_item_asm.inc,
@@ -55,7 +56,7 @@ constexpr int NW = 16;                    // waves per block
 constexpr int SLOTS = 6;                  // particle slots per wave
 constexpr int GMAX = NW * SLOTS;          // particles per work item
 constexpr int Q = 4;                      // 16-byte channel quads per pixel per chunk (16 channels)
-constexpr int LDS_MISC = 8192;            // scratch behind the stages (item entries, record prefetch, landing zone of the L2 touches)
+constexpr int LDS_MISC = 15360;           // scratch behind the stages (item entries, record prefetch, landing zone of the L2 touches)
 
 #ifndef PIPS_TRACE_WAVE
 #define PIPS_TRACE_WAVE 0
@@ -89,16 +90,19 @@ __device__ __forceinline__ void corr_window(float cxm, float cym, int lvl, int H
 }
 
 // ---------------------------------------------------------------------------- binning
-// order  [F][N]        int4 {mixer row m, bits of cx, bits of cy, 0} of frame f's particles sorted by (tile, 4x4-pixel cell
-//                      inside the tile in Morton order): neighbours in the list mostly share their window anchor at the
-//                      coarse levels; a record saves the gather a dependent load (index -> coordinates)
+// order  [F][N][4]     one int4 PER LEVEL {bx | by << 16, bits of wx, bits of wy, mixer row m} of frame f's particles sorted by
+//                      (tile, 4x4-pixel cell inside the tile in Morton order): neighbours in the list mostly share their
+//                      window anchor at the coarse levels.  The window geometry of nets/pips.py:318-319 + grid_sample (two
+//                      fp32 divisions per level) is computed HERE, once per particle-level, not per lane of the gather
+//                      (anchors far outside the map are clamped to +-20000: their windows are empty either way)
 // items  [F][max_items] int4 {tile, first, count, 0}; a tile with more than GMAX particles is split evenly
 // nitems [F]
 // LDS: hist[nbins] | cursor[nbins] | tile_off[ntiles + 1],  nbins = 16 * ntiles
-__global__ __launch_bounds__(1024) void bin_particles_kernel(const float* __restrict__ coords, int N, int H0, int W0,
+__global__ __launch_bounds__(1024) void bin_particles_kernel(const float* __restrict__ coords, int N, TiledLevels lv,
                                                              int tiles_x, int tiles_y, int max_items,
                                                              int4* __restrict__ order, int4* __restrict__ items,
                                                              int* __restrict__ nitems) {
+    const int H0 = lv.H[0], W0 = lv.W[0];
     extern __shared__ int sm[];
     const int ntiles = tiles_x * tiles_y, nbins = ntiles * 16;
     int* hist = sm;
@@ -151,7 +155,15 @@ __global__ __launch_bounds__(1024) void bin_particles_kernel(const float* __rest
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const int pos = atomicAdd(&cursor[key_of(n)], 1);
         const size_t m = ((size_t)b * N + n) * S + s;
-        order[(size_t)f * N + pos] = make_int4((int)m, __float_as_int(coords[m * 2 + 0]), __float_as_int(coords[m * 2 + 1]), 0);
+        const float cx = coords[m * 2 + 0], cy = coords[m * 2 + 1];
+#pragma unroll
+        for (int l = 0; l < PIPS_LEVELS; ++l) {
+            int bx, by; float wx, wy;
+            corr_window(cx, cy, l, lv.H[l], lv.W[l], bx, by, wx, wy);
+            bx = min(max(bx, -20000), 20000); by = min(max(by, -20000), 20000);
+            order[((size_t)f * N + pos) * PIPS_LEVELS + l] =
+                make_int4((int)(((unsigned)bx & 0xffffu) | ((unsigned)by << 16)), __float_as_int(wx), __float_as_int(wy), (int)m);
+        }
     }
 }
 
@@ -190,22 +202,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // the phase body fills with feature chunks, and keeps the set-up free of scalar branches)
 struct LaneGeom {
     int x0, y0, RW, RH, W, H;
-    int nquads;             // RW*RH*Q 16-byte LDS positions
+    int nquads;             // RH * (RW*Q + 1) 16-byte LDS positions: a staged row = RW pixels of Q quads + one pad slot
     unsigned base;          // byte offset of the (frame, level) map in the pyramid buffer
     int lbase, lsize;       // LDS byte offset of the level's stage pair, size of one stage
 };
 #define PIPS_RL(v, i) __builtin_amdgcn_readlane((int)(v), (i))
-
-// XOR key of region pixel (rx, ry): LDS 16-byte slot = 4 * (pixel index & 3) + (quad ^ key) is a bijection of
-// (rx & 3, ry & 3) -> the 16 lanes of a ds_read_b128 service group (4 consecutive x in each of 4 consecutive
-// rows) hit 16 different 16-byte bank groups
-__device__ __forceinline__ int swz_key(int rx, int ry) {
-#ifdef PIPS_TILED_DBG_NOSWZ
-    return 0;
-#endif
-    (void)rx;
-    return ry & 3;
-}
 
 // buffer resource over the pyramid: raw (stride 0) addressing, byte offset = soffset (SGPR) + voffset (VGPR) < 4 GiB;
 // keeps every address of the hot loop out of the vector registers
@@ -278,7 +279,7 @@ __device__ __forceinline__ LaneGeom lane_geom(const TiledLevels& lv, int lane, i
     const int x1 = min(Tx + w + h, g.W - 1), y1 = min(Ty + w + h, g.H - 1);
     g.RW = max(x1 - g.x0 + 1, 1); g.RH = max(y1 - g.y0 + 1, 1);
     if (x1 < g.x0 || y1 < g.y0) { g.x0 = g.y0 = 0; g.RW = g.RH = 1; }            // (tile beyond this level's map)
-    g.nquads = g.RW * g.RH * Q;
+    g.nquads = g.RH * (g.RW * Q + 1);
     g.base = (unsigned)((off + frame_base * g.H * g.W * C) * sizeof(float));
     g.lbase = l == 0 ? LB0 : (l == 1 ? LB1 : (l == 2 ? LB2 : LB3));
     g.lsize = l == 0 ? SZ0 : (l == 1 ? SZ1 : (l == 2 ? SZ2 : SZ3));
@@ -294,14 +295,47 @@ __device__ __forceinline__ void dma_setup(const LaneGeom& g, int wave, int lane,
         const int l = (gp >= c1) + (gp >= c2) + (gp >= c3);                      // wave-uniform
         const int piece = gp - (l > 0 ? c1 : 0) - (l > 1 ? c2 - c1 : 0) - (l > 2 ? c3 - c2 : 0);
         const int RW = PIPS_RL(g.RW, l), W = PIPS_RL(g.W, l), x0 = PIPS_RL(g.x0, l), y0 = PIPS_RL(g.y0, l);
+        // LDS slot L of the level's stage = (row ry, position e in the row); rows are PADDED by one 16-byte slot (a pixel's
+        // four quads sit at consecutive addresses and the 16 lanes of a ds_read_b128 service group -- 4 consecutive x in
+        // each of 4 consecutive window rows -- hit 16 different bank groups: no swizzle, no address arithmetic per quad);
+        // the lane that fills a pad slot fetches the row's last quad again
         const int L = min(piece * 64 + lane, PIPS_RL(g.nquads, l) - 1);
-        const int p = L / Q, j = L - p * Q;
-        const int ry = (int)(((float)p + 0.5f) * (1.0f / (float)RW));         // p < 1024: exact
-        const int rx = p - ry * RW;
-        const int q = j ^ swz_key(rx, ry);
+        const int pitch = RW * Q + 1;
+        const int ry = L / pitch;
+        const int e = min(L - ry * pitch, RW * Q - 1);
+        const int rx = e >> 2, q = e & 3;
         wp.doff[r] = (unsigned)PIPS_RL(g.base, l) + (unsigned)(((y0 + ry) * W + (x0 + rx)) * (C * 4) + q * 16);
         wp.lds[r] = gp < c4 ? PIPS_RL(g.lbase, l) + piece * 1024 : -1;
         wp.par[r] = PIPS_RL(g.lsize, l);
+    }
+}
+
+// ---- per-tile tables (tile_table_kernel, once per launch): what a wave needs for a work item beyond its particles depends
+// on the tile and the map sizes only -- staged regions, the wave's DMA pieces and every lane's source offset in them.  The
+// first cut recomputed it per item and wave (~700 VALU instructions, 12k of the 70k clocks of an item).
+//   gpk_tab  [tile][wave][32]        the asm's lane-parallel input: lanes l / 4+l / 8+l = x0|y0<<16, RW|RH<<16, W|H<<16 of
+//                                    level l; lane 16+r = LDS offset of the wave's DMA piece r (-1: none), lane 24+r = its
+//                                    stage size (= which level it belongs to)
+//   doff_tab [tile][wave][MAXP][64]  byte offset (from the pyramid start, frame 0) of the 16 bytes lane fetches in piece r
+__global__ __launch_bounds__(NW * 64) void tile_table_kernel(TiledLevels lv, int tiles_x, int* __restrict__ gpk_tab,
+                                                             unsigned* __restrict__ doff_tab) {
+    const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const LaneGeom g = lane_geom(lv, lane, tx, ty, 0);
+    WavePieces wp;
+    dma_setup(g, wave, lane, wp);
+#pragma unroll
+    for (int r = 0; r < MAXP; ++r) doff_tab[(((size_t)tile * NW + wave) * MAXP + r) * 64 + lane] = wp.doff[r];
+    if (lane < 32) {
+        const unsigned v0 = (unsigned)g.x0 | ((unsigned)g.y0 << 16), v1 = (unsigned)g.RW | ((unsigned)g.RH << 16),
+                       v2 = (unsigned)g.W | ((unsigned)g.H << 16);                // (g is lane-parallel by lane & 3)
+        int v = (int)(lane < 4 ? v0 : (lane < 8 ? v1 : (lane < 12 ? v2 : 0u)));
+#pragma unroll
+        for (int r = 0; r < MAXP; ++r) {
+            if (lane == 16 + r) v = wp.lds[r];
+            if (lane == 24 + r) v = wp.par[r];
+        }
+        gpk_tab[((size_t)tile * NW + wave) * 32 + lane] = v;
     }
 }
 
@@ -311,12 +345,16 @@ __device__ __forceinline__ void dma_setup(const LaneGeom& g, int wave, int lane,
 // global -> LDS by the waves' own LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR staging, no ds_write), double
 // buffered: chunk c+1 lands while chunk c is consumed, one barrier per chunk.  C++ does the item's index arithmetic
 // (lane-parallel) and starts the first stage; gather_item_asm.inc does the rest.
-__global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* __restrict__ pyramid, TiledLevels lv,
+struct FrameStrides { unsigned b[PIPS_LEVELS]; };          // bytes of one frame's map per level
+
+__global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* __restrict__ pyramid, FrameStrides fs,
                                                                   int S_, const float* __restrict__ ffeats, int N,
-                                                                  int tiles_x, int max_items, int F,
+                                                                  int max_items, int F,
                                                                   const int4* __restrict__ order,
                                                                   const int4* __restrict__ items,
                                                                   const int* __restrict__ nitems,
+                                                                  const int* __restrict__ gpk_tab,
+                                                                  const unsigned* __restrict__ doff_tab,
                                                                   float* __restrict__ X) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid0 = threadIdx.x, lane0 = tid0 & 63;
@@ -329,23 +367,23 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
         rs = (u4v){(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
     }
     const __amdgpu_buffer_rsrc_t recs = make_rsrc(order), frs = make_rsrc(ffeats);
-    // scratch behind the stages:  [junk 256 B | entries 64 x 16 B | per wave: records 2 x 8 x 16 B | waves 0-1: rows 2 x 64 x 4 B]
+    // scratch behind the stages:  [junk 256 B | entries 64 x 16 B | per wave: records 2 x 24 x 16 B | waves 0-1: rows 2 x 64 x 4 B]
     char* misc = smem + LDS_MISC_OFF;
     int4* ent = reinterpret_cast<int4*>(misc + 256);
-    int4* recbuf = reinterpret_cast<int4*>(misc + 256 + 1024) + wave * 16;
-    unsigned* rowbuf = reinterpret_cast<unsigned*>(misc + 256 + 1024 + 4096) + min(wave, 1) * 128;
+    int4* recbuf = reinterpret_cast<int4*>(misc + 256 + 1024) + wave * (2 * 4 * SLOTS);
+    unsigned* rowbuf = reinterpret_cast<unsigned*>(misc + 256 + 1024 + NW * 2 * 4 * SLOTS * 16) + min(wave, 1) * 128;
     // Records of item (first, count) this wave needs, by LDS-DMA into buffer p (no VGPRs: the copy is in flight across
-    // the asm statement of the item before): the wave's six slots (16 B each, lanes 0-5) and, in waves 0-1, the mixer
-    // row of particle tid (4 B) for the L2 touches of the features
+    // the asm statement of the item before): the (slot, level) records of the wave's six slots (16 B each, lanes 0-23:
+    // lane 4k+l = slot k, level l) and, in waves 0-1, the mixer row of particle tid (4 B) for the L2 touches of the features
     auto prefetch_records = [&](int f_, int first, int count, int p, int lane, int tid) {
         const int base_n = count / NW, rem = count - base_n * NW;
         const int nslot = base_n + (wave < rem ? 1 : 0), start = wave * base_n + min(wave, rem);
-        const unsigned o0 = (unsigned)(((size_t)f_ * N + first) * sizeof(int4));
-        if (lane < SLOTS)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(recs, (lptr_t)(recbuf + p * 8), 16,
-                                                     (int)(o0 + (unsigned)(nslot > 0 ? start + min(lane, nslot - 1) : 0) * 16u), 0, 0, 0);
+        const unsigned o0 = (unsigned)(((size_t)f_ * N + first) * (PIPS_LEVELS * sizeof(int4)));
+        if (lane < 4 * SLOTS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(recs, (lptr_t)(recbuf + p * (4 * SLOTS)), 16,
+                                                     (int)(o0 + (unsigned)((nslot > 0 ? start + min(lane >> 2, nslot - 1) : 0) * 4 + (lane & 3)) * 16u), 0, 0, 0);
         if (tid < count)                                                         // (count <= 96: waves 0 and 1)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(recs, (lptr_t)(rowbuf + p * 64), 4, (int)(o0 + (unsigned)tid * 16u), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(recs, (lptr_t)(rowbuf + p * 64), 4, (int)(o0 + (unsigned)tid * 64u + 12u), 0, 0, 0);
     };
     for (int base = 0;; base += 64) {
         // ---- this block's next (up to) 64 work items: item i of the block is entry j + i J of the XCD's list (frames
@@ -385,8 +423,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
 #endif
             PIPS_TR(0);
             const int b = f / S, s = f - b * S;
-            const size_t frame_base = (size_t)(b * S_ + s);
-            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            const unsigned fi = (unsigned)(b * S_ + s);                                  // frame index in the map buffer
             const int p = i & 1;
             // ---- the next item's records on their way while this one is worked on (first in the DMA queue: the
             //      stage pieces, issued from the asm, are 72 KiB)
@@ -394,12 +431,21 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
             const int nf = i + 1 < 64 ? nx_f : -1;
             if (nf >= 0) prefetch_records(nf, nx_first, nx_count, p ^ 1, lane, tid);
             PIPS_TR(13);
-            // ---- staged regions and the wave's DMA pieces (the asm issues them, the first stage between its address
-            //      set-up: no barrier needed -- a wave gets here only after the barrier of the previous item's last
-            //      phase, behind which nobody reads parity 0)
-            const LaneGeom g = lane_geom(lv, lane, tx, ty, frame_base);
+            // ---- staged regions and the wave's DMA pieces from the tile tables (the asm issues the pieces, the first stage
+            //      between its address set-up: no barrier needed -- a wave gets here only after the barrier of the previous
+            //      item's last phase, behind which nobody reads parity 0)
+            int gpk = gpk_tab[((size_t)tile * NW + wave) * 32 + (lane & 31)];
             WavePieces wp;
-            dma_setup(g, wave, lane, wp);
+            {
+                const unsigned* dt = doff_tab + (((size_t)tile * NW + wave) * MAXP) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < MAXP; ++r) {
+                    const int par = PIPS_RL(gpk, 24 + r);                                   // the piece's level, by its stage size
+                    const unsigned fb = fi * (par == SZ0 ? fs.b[0] : (par == SZ1 ? fs.b[1] : (par == SZ2 ? fs.b[2] : fs.b[3])));
+                    wp.doff[r] = dt[r * 64] + fb;
+                }
+            }
+            if (PIPS_TILED_ABLATE & 4) gpk = (lane & 31) >= 16 && (lane & 31) < 16 + MAXP ? -1 : gpk;
             PIPS_TR(14);
 
             // ---- the list is already ordered (bin_particles_kernel); spread it over the waves
@@ -411,14 +457,17 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
                 warm_off = rowbuf[p * 64 + lane] * (unsigned)(C * 4);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lptr_t)misc, 4, (int)warm_off, 0, 0, 0);
             }
-            // ---- lane-parallel window geometry: lane k*4+l <-> (slot k, level l); slots past the wave's own
-            //      particles repeat its last one (or the item's first, for an empty wave)
+            // ---- lane-parallel window geometry: lane k*4+l <-> (slot k, level l), straight out of the records (computed by
+            //      bin_particles_kernel); slots past the wave's own particles repeat its last one (or the item's first)
             float geo_wx, geo_wy;
             int geo_bx, geo_by, geo_row;
             {
-                const int4 r = recbuf[p * 8 + min(lane >> 2, SLOTS - 1)];
-                geo_row = r.x;                                                        // mixer row m
-                corr_window(__int_as_float(r.y), __int_as_float(r.z), lane & 3, g.H, g.W, geo_bx, geo_by, geo_wx, geo_wy);
+                const int4 r = recbuf[p * (4 * SLOTS) + min(lane, 4 * SLOTS - 1)];
+                geo_bx = (int)(short)(r.x & 0xffff);
+                geo_by = r.x >> 16;
+                geo_wx = __int_as_float(r.y);
+                geo_wy = __int_as_float(r.z);
+                geo_row = r.w;                                                        // mixer row m
             }
             PIPS_TR(15);
             // slot k re-uses slot k-1's fragment at level l when both windows have the same anchor: bit 4k+l
@@ -427,22 +476,6 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
                 const int pbx = __shfl_up(geo_bx, 4), pby = __shfl_up(geo_by, 4);
                 same = (unsigned)__ballot(lane >= 4 && lane < 4 * SLOTS && pbx == geo_bx && pby == geo_by);
                 same = PIPS_TILED_REUSE ? __builtin_amdgcn_readfirstlane(same) : 0u;
-            }
-            // wave-uniform inputs of the asm as ONE lane-parallel register: lanes l / 4+l / 8+l = x0|y0<<16, RW|RH<<16,
-            // W|H<<16 of level l; lane 16+r = LDS offset of the wave's DMA piece r (-1: none), lane 24+r = its stage size
-            int gpk;
-            {
-                const unsigned v0 = (unsigned)g.x0 | ((unsigned)g.y0 << 16), v1 = (unsigned)g.RW | ((unsigned)g.RH << 16),
-                               v2 = (unsigned)g.W | ((unsigned)g.H << 16);                // (g is lane-parallel by lane & 3)
-                gpk = (int)(lane < 4 ? v0 : (lane < 8 ? v1 : v2));
-                // (v_writelane: the per-lane selects of wave-uniform values compile to one exec-masked branch each)
-#pragma unroll
-                for (int r = 0; r < MAXP; ++r) {
-                    const int pl = __builtin_amdgcn_readfirstlane((PIPS_TILED_ABLATE & 4) ? -1 : wp.lds[r]);
-                    const int pp = __builtin_amdgcn_readfirstlane(wp.par[r]);
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(gpk) : "s"(pl), "n"(16 + r));
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(gpk) : "s"(pp), "n"(24 + r));
-                }
             }
             PIPS_TR(1);
 #ifdef PIPS_TILED_TRACE
@@ -476,8 +509,10 @@ static int tiled_max_items(int N, int H8, int W8) { return cdiv(W8, TS) * cdiv(H
 size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8) {
     const int F = B * S;
     const int max_items = tiled_max_items(N, H8, W8);
-    return align_up((size_t)F * N * sizeof(int4), 256) + align_up((size_t)F * max_items * sizeof(int4), 256) +
-           align_up((size_t)F * sizeof(int), 256);
+    const size_t ntiles = (size_t)cdiv(W8, TS) * cdiv(H8, TS);
+    return align_up((size_t)F * N * PIPS_LEVELS * sizeof(int4), 256) + align_up((size_t)F * max_items * sizeof(int4), 256) +
+           align_up((size_t)F * sizeof(int), 256) + align_up(ntiles * NW * 32 * sizeof(int), 256) +
+           align_up(ntiles * NW * MAXP * 64 * sizeof(unsigned), 256);
 }
 
 // Selection: dense query sets (on average >= 16 particles per 16x16 level-0 tile) take the tiled kernel;
@@ -488,6 +523,7 @@ bool tiled_gather_fits(int B, int N, int H8, int W8) {
     size_t px = 0;
     for (int l = 0, h = H8, w = W8; l < PIPS_LEVELS; ++l, h /= 2, w /= 2) px += ((size_t)B * S * h * w * C + 63) / 64 * 64;
     return px * 4 < (1ull << 32) && (size_t)B * N * S * PIPS_KIN_PAD * 4 < (1ull << 32) &&
+           (size_t)B * S * N * PIPS_LEVELS * sizeof(int4) < (1ull << 32) && H8 < 16384 && W8 < 16384 &&
            ((size_t)33 * cdiv(W8, TS) * cdiv(H8, TS) + 1) * sizeof(int) <= 64 * 1024;
 }
 bool tiled_gather_wanted(int B, int N, int H8, int W8) {
@@ -509,23 +545,33 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     const int tiles_x = cdiv(W8, TS), tiles_y = cdiv(H8, TS), ntiles = tiles_x * tiles_y;
     const int max_items = tiled_max_items(N, H8, W8);
     char* p = (char*)scratch;
-    int4* order = (int4*)p; p += align_up((size_t)F * N * sizeof(int4), 256);
+    int4* order = (int4*)p; p += align_up((size_t)F * N * PIPS_LEVELS * sizeof(int4), 256);
     int4* items = (int4*)p; p += align_up((size_t)F * max_items * sizeof(int4), 256);
-    int* nitems = (int*)p;
+    int* nitems = (int*)p; p += align_up((size_t)F * sizeof(int), 256);
+    int* gpk_tab = (int*)p; p += align_up((size_t)ntiles * NW * 32 * sizeof(int), 256);
+    unsigned* doff_tab = (unsigned*)p;
     const size_t bin_lds = ((size_t)2 * 16 * ntiles + ntiles + 1) * sizeof(int);
     PIPS_CHECK_ARG(bin_lds <= 64 * 1024, "tiled gather: map too large for the tile histogram");
-    PIPS_CHECK_ARG((lvl_off[PIPS_LEVELS - 1] + (size_t)F * lvlH[PIPS_LEVELS - 1] * lvlW[PIPS_LEVELS - 1] * C) * 4 < (1ull << 32) && (size_t)B * N * S * PIPS_KIN_PAD * 4 < (1ull << 32),
-                   "tiled gather: maps / features beyond 32-bit byte offsets");
+    PIPS_CHECK_ARG((lvl_off[PIPS_LEVELS - 1] + (size_t)F * lvlH[PIPS_LEVELS - 1] * lvlW[PIPS_LEVELS - 1] * C) * 4 < (1ull << 32) && (size_t)B * N * S * PIPS_KIN_PAD * 4 < (1ull << 32) &&
+                       (size_t)F * N * PIPS_LEVELS * sizeof(int4) < (1ull << 32),
+                   "tiled gather: maps / features / records beyond 32-bit byte offsets");
+    PIPS_CHECK_ARG(H8 < 16384 && W8 < 16384, "tiled gather: map too large for 16-bit window anchors");
+    TiledLevels lv;
+    FrameStrides fs;
+    for (int l = 0; l < PIPS_LEVELS; ++l) {
+        lv.off[l] = lvl_off[l]; lv.H[l] = lvlH[l]; lv.W[l] = lvlW[l];
+        fs.b[l] = (unsigned)((size_t)lvlH[l] * lvlW[l] * C * sizeof(float));
+    }
     if (ev) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL(bin_particles_kernel, dim3(F), dim3(1024), bin_lds, st, coords, N, H8, W8, tiles_x, tiles_y, max_items,
+    hipLaunchKernelGGL(bin_particles_kernel, dim3(F), dim3(1024), bin_lds, st, coords, N, lv, tiles_x, tiles_y, max_items,
                        order, items, nitems);
     PIPS_CHECK_LAUNCH("bin_particles_kernel");
+    hipLaunchKernelGGL(tile_table_kernel, dim3(ntiles), dim3(NW * 64), 0, st, lv, tiles_x, gpk_tab, doff_tab);
+    PIPS_CHECK_LAUNCH("tile_table_kernel");
     const int M = B * N * S;
     if (ev) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(embed_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ffeats, coords, times, M, X);
     PIPS_CHECK_LAUNCH("embed_rows_kernel");
-    TiledLevels lv;
-    for (int l = 0; l < PIPS_LEVELS; ++l) { lv.off[l] = lvl_off[l]; lv.H[l] = lvlH[l]; lv.W[l] = lvlW[l]; }
     {
         static std::atomic<unsigned long long> raised{0};
         const int rc = ensure_dynamic_lds(raised, (const void*)gather_tiled_kernel, LDS_BYTES_V3);
@@ -539,8 +585,8 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     }
     const int grid = max(cus / 8, 1) * 8;
     if (ev) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(gather_tiled_kernel, dim3(grid), dim3(NW * 64), LDS_BYTES_V3, st, pyramid, lv, S_, ffeats,
-                       N, tiles_x, max_items, F, order, items, nitems, X);
+    hipLaunchKernelGGL(gather_tiled_kernel, dim3(grid), dim3(NW * 64), LDS_BYTES_V3, st, pyramid, fs, S_, ffeats,
+                       N, max_items, F, order, items, nitems, gpk_tab, doff_tab, X);
     if (ev) (void)hipEventRecord(ev[3], st);
     PIPS_CHECK_LAUNCH("gather_tiled_kernel");
     return PIPS_OK;

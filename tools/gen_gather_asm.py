@@ -14,7 +14,7 @@ Registers (everything from v23 / s16 up is private to the statement):
     v23          in-map bits of this lane's window pixel, bit 4*slot + level
     v[24:39]     fragment B (16 channels of this lane's pixel, odd slot of a pair) / temporaries
     v[40:87]     accumulators, unit u = level*6 + slot -> v[40+2u : 41+2u] (even / odd channel partial sums)
-    v[88:111]    LDS byte address of this lane's window pixel of unit u (stage parity 0, swizzle key folded in)
+    v[88:111]    LDS byte address of this lane's window pixel of unit u (stage parity 0); staged rows are padded by 16 B
     v[112:127]   fragment A (even slot of a pair) / temporaries
     s[16:21]     byte offsets of the six slots' feature rows
     s[22:35]     counters, temporaries (not s32)
@@ -92,6 +92,7 @@ def setup(a):
     a("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (t, t))                 # lane id
     a("v_and_b32 v%d, 7, v%d" % (wi, t))
     a("v_lshrrev_b32 v%d, 3, v%d" % (wj, t))
+    a("v_lshlrev_b32 v%d, 6, v%d" % (p, wi))                       # wi * 64: the lane's column offset inside a window row
     a("v_mov_b32 v%d, 0" % INM)
     a("s_mov_b32 s%d, 0" % S_ALLIN)                                # bit 4k+l: the unit's window lies wholly inside the map
     dma_piece(a, 0, first=True)
@@ -108,6 +109,8 @@ def setup(a):
         a("s_and_b32 s%d, s%d, 0xffff" % (W, H))
         a("s_lshr_b32 s%d, s%d, 16" % (H, H))
         a("s_sub_u32 s%d, s%d, 1" % (RWm, RW))
+        a("s_lshl_b32 s%d, s%d, 6" % (RW, RW))
+        a("s_add_u32 s%d, s%d, 16" % (RW, RW))                     # row pitch of the staged region: RW pixels of 64 B + 16 B pad
         a("s_add_u32 s%d, %%[ldsb], %d" % (lb, LB[l]))             # LDS address of the level's stage pair
         nextl = a.label()
         for k in range(SLOTS):
@@ -135,10 +138,8 @@ def setup(a):
             a("s_lshl_b32 s%d, s%d, 6" % (S_T, S_T))
             a("s_add_u32 s%d, s%d, s%d" % (S_T, S_T, lb))          # lb + 64 dx
             a("v_add_u32 v%d, s%d, v%d" % (ry, S_T + 1, wj))
-            a("v_mad_u32_u24 v%d, v%d, s%d, v%d" % (p, ry, RW, wi))
-            a("v_and_b32 v%d, 3, v%d" % (t, ry))                    # swizzle key
-            a("v_lshl_add_u32 v%d, v%d, 6, s%d" % (adr(l, k), p, S_T))
-            a("v_lshl_or_b32 v%d, v%d, 4, v%d" % (adr(l, k), t, adr(l, k)))
+            a("v_mad_u32_u24 v%d, v%d, s%d, v%d" % (adr(l, k), ry, RW, p))     # ry * pitch + wi * 64
+            a("v_add_u32 v%d, s%d, v%d" % (adr(l, k), S_T, adr(l, k)))
             a("s_branch %df" % done)
             a("%d:" % slow)
             a("v_add_u32 v%d, s%d, v%d" % (px, S_U, wi))
@@ -153,10 +154,9 @@ def setup(a):
             a("v_subrev_u32 v%d, s%d, v%d" % (ry, y0, py))
             a("s_sub_u32 s%d, s%d, 1" % (S_T, RH))
             a("v_med3_i32 v%d, v%d, 0, s%d" % (ry, ry, S_T))
-            a("v_mad_u32_u24 v%d, v%d, s%d, v%d" % (p, ry, RW, rx))
-            a("v_and_b32 v%d, 3, v%d" % (t, ry))                    # swizzle key
-            a("v_lshl_add_u32 v%d, v%d, 6, s%d" % (adr(l, k), p, lb))
-            a("v_lshl_or_b32 v%d, v%d, 4, v%d" % (adr(l, k), t, adr(l, k)))
+            a("v_lshlrev_b32 v%d, 6, v%d" % (rx, rx))
+            a("v_mad_u32_u24 v%d, v%d, s%d, v%d" % (adr(l, k), ry, RW, rx))     # ry * pitch + rx * 64
+            a("v_add_u32 v%d, s%d, v%d" % (adr(l, k), lb, adr(l, k)))
             a("%d:" % done)
             if k == 0:                                             # (units every wave runs, whatever its particle count)
                 dma_piece(a, pieces, first=True)                   # the first stage (chunk 0 -> parity 0) goes out between the units
@@ -217,10 +217,8 @@ def reads(a, l, k, frag, par):
     if "reads" in ABL:
         return
     ad = adr(l, k)
-    for i in range(1, Q):                            # the destination registers double as address temporaries
-        a("v_xor_b32 v%d, %s, v%d" % (frag + 4 * i, hex(16 * i), ad))
-    for i in range(Q):
-        a("ds_read_b128 v[%d:%d], v%d offset:%d" % (frag + 4 * i, frag + 4 * i + 3, ad if i == 0 else frag + 4 * i, par * SZ[l]))
+    for i in range(Q):                               # the four channel quads of the pixel: consecutive 16 B (rows are padded, not swizzled)
+        a("ds_read_b128 v[%d:%d], v%d offset:%d" % (frag + 4 * i, frag + 4 * i + 3, ad, par * SZ[l] + 16 * i))
 
 
 def fmas(a, l, k, s, frag):
