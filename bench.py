@@ -182,7 +182,9 @@ def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of a kernel from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE in separate runs of the same commands, tools/profile_round.sh; a live bench run cannot collect PMC
     counters itself).  Returns (bytes or None, source)."""
-    name = "r2_pmc_traffic.json"
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))      # the latest round's passes
+    name = os.path.basename(files[-1]) if files else "r2_pmc_traffic.json"
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
         for k, v in pmc.items():

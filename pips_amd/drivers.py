@@ -60,8 +60,11 @@ def track_chained(model, rgbs, xy0, iters=6):
     dev = rgbs.device
     T, N, S = rgbs.shape[1], xy0.shape[1], 8
     cache = model.encode(rgbs)
-    trajs = torch.zeros(1, T, N, 2, dtype=torch.float32, device=dev)
+    # S - 1 frames of padding behind the video: a window that runs past the end is written whole and cut off on return
+    # (no per-row masks, no host round trips inside a hop)
+    trajs = torch.zeros(1, T + S - 1, N, 2, dtype=torch.float32, device=dev)
     trajs[0, 0] = xy0[0].to(dev)
+    offs = torch.arange(S, device=dev).unsqueeze(1)                                # (S,1)
     cur = torch.zeros(N, dtype=torch.int64, device=dev)
     active = torch.arange(N, device=dev)
     feat = None
@@ -74,11 +77,8 @@ def track_chained(model, rgbs, xy0, iters=6):
         if feat is None:
             feat = ffeat[0].clone()                                              # carried forever (:57)
         xys = preds[-1][0]                                                        # (8,n,2)
-        for s in range(S):                                                        # traj_e[cur:cur+8] = xys[:S_local]
-            fr = c + s
-            ok = fr < T
-            trajs[0, fr[ok], active[ok]] = xys[s, ok]
+        trajs[0, c.unsqueeze(0) + offs, active.unsqueeze(0).expand(S, -1)] = xys   # traj_e[cur:cur+8] = xys[:S_local]
         si = skip_scan(torch.sigmoid(vis[0]))
         cur[active] = c + si
-        active = active[cur[active] < T]
-    return trajs
+        active = active[cur[active] < T]                                          # (one host sync per hop: the live count)
+    return trajs[:, :T].contiguous()
