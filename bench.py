@@ -345,6 +345,12 @@ def config4_leg(device):
                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": traffic,
                                 "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": comp,
+                                # the kernel's own on-chip floors (exact fp32 on the vector ALUs): the 0.80 HBM target
+                                # (76 us) lies below both
+                                "valu_floor_ms": b * S * n * 4 * 64 * 128 / (105.0 * 256 * 2.4e9) * 1e3,
+                                "lds_floor_ms": 0.78 * b * S * n * 4 * 64 * 128 * 4 / (256.0 * 256 * 2.4e9) * 1e3,
+                                "floors_note": "valu: 4.29 G lane-FMAs at the measured 105 lane-FMA/clk/CU (tools/valu_peak.hip) x 256 CUs x "
+                                               "2.4 GHz; lds: 17.2 GB of window fragments x 0.78 (anchor sharing) at 256 B/clk/CU",
                                 "timing": "HIP event pair around the kernel launch (pips_mixer_input_build_tiled_timed), "
                                           "mean of 10 launches on the real maps"},
             "gather": out}

@@ -16,7 +16,10 @@
  *     library never allocates, frees or synchronises (the *_timed entry points excepted).  The
  *     only state kept between calls is idempotent: the dynamic-LDS attribute of each kernel
  *     instantiation (raised on its first launch on a device, tracked per device with atomics)
- *     and PIPS_* tuning environment variables read once.  Calls are re-entrant and stream-ordered
+ *     and the device's compute-unit count (one atomic slot per device).  The library reads no
+ *     environment variables (the PIPS_* tuning hooks exist only in a -DPIPS_TUNING build,
+ *     pips_amd/_build.py --tuning, where each is read once in a thread-safe static initialiser).
+ *     Calls are re-entrant and stream-ordered
  *     on `stream` (a hipStream_t passed as void*).  hipGraph capture: run the same call once
  *     eagerly first (so no attribute is set while capturing), then capture and replay -- replays
  *     are bit-identical to the eager call (tests/test_forward_gpu.py::test_forward_in_hip_graph);
@@ -169,7 +172,8 @@ int    pips_mixer_input_build(const float* pyramid, int B, int S, int H8, int W8
  * (BASELINE configs[3], test_on_davis.py:103-130): particles binned by 16x16 map tile, the tile's
  * halo region at each level staged in LDS once per tile (csrc/gather_tiled.hip).  pips_track /
  * pips_forward pick it by themselves when the query set is dense (>= 1024 particles and >= 16 per
- * tile on average; PIPS_GATHER_TILED=0/1 overrides).  scratch holds the per-frame sort; values agree
+ * tile on average, within the kernel's 32-bit offset limits -- otherwise the direct kernel).  scratch holds the per-frame sort
+ * and the per-tile tables; values agree
  * with the direct kernel to fp32 summation order.  The _timed form also returns the HIP-event
  * durations (ms) of its three launches {bin_particles, embed_rows, gather_tiled} in ms3_host and
  * synchronises the stream (measurement only). */

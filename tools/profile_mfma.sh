@@ -11,7 +11,7 @@ HEAD="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-stage-profi
 rm -rf /tmp/pm_*
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/pm_head -o p -- $HEAD > /dev/null 2>&1
 python $R/tools/mfma_util.py /tmp/pm_head > $R/gpurun_out/${TAG}_pmc_mfma_util_exact.txt 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/pm_c3 -o p -- python $R/bench.py --leg config3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/pm_c3 -o p -- python $R/bench.py --config 3 --steps 5 --warmup 2 --no-cpu-baseline --no-stage-profile --no-extras > /dev/null 2>&1
 python $R/tools/mfma_util.py /tmp/pm_c3 > $R/gpurun_out/${TAG}_pmc_mfma_util_config3.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/pm_split -o p -- $HEAD --matmul split > /dev/null 2>&1
 python $R/tools/mfma_util.py /tmp/pm_split > $R/gpurun_out/${TAG}_pmc_mfma_util_split.txt 2>&1
