@@ -91,6 +91,10 @@ static ArenaLayout build_layout() {
     A.h_conv[0] = 0;                                   // the 7x7 stem stays fp32 (VALU kernel)
     for (int i = 1; i < 22; ++i) A.h_conv[i] = take_h((size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
     A.h_in = take_h((size_t)PIPS_DMIX * PIPS_KIN_PAD);
+    for (int d = 0; d < PIPS_DEPTH; ++d) {
+        A.f_w1[d] = take_h((size_t)4 * PIPS_DMIX * PIPS_DMIX);
+        A.f_w2[d] = take_h((size_t)4 * PIPS_DMIX * PIPS_DMIX);
+    }
     A.total_h = hoff;
     size_t toff = 0;
     auto take_t = [&](size_t n) { size_t o = toff; toff += (3 * n + 127) / 128 * 128; return o; };
@@ -222,6 +226,10 @@ int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v
     }
     to_h(A.w_head, A.h_head, (size_t)PIPS_NOUT * PIPS_DMIX);
     to_h(A.w_in, A.h_in, (size_t)PIPS_DMIX * PIPS_KIN_PAD);
+    for (int d = 0; d < PIPS_DEPTH; ++d) {                 // fragment-major copies for the fused FeedForward (ffn_fused.hip)
+        (void)launch_pack_frag(hb + A.h_w1[d], hb + A.f_w1[d], 4 * PIPS_DMIX, PIPS_DMIX, st);
+        (void)launch_pack_frag(hb + A.h_w2[d], hb + A.f_w2[d], PIPS_DMIX, 4 * PIPS_DMIX, st);
+    }
     for (int i = 1; i < 22; ++i)
         to_h(A.conv[i].w, A.h_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
   }
@@ -795,6 +803,12 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
         RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1));
+        if (bf16 && ev == nullptr && ffn_fused_takes(M)) {
+            // large M: up-projection, GELU and down-projection in one launch, the hidden activation stays on the CU
+            const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
+            RUN(launch_ffn_fused(xn, x, hw + A.f_w1[d], arena + L.b1, hw + A.f_w2[d], arena + L.b2, M, st));
+            continue;
+        }
         if (bf16) {
             const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
             TIMED(gemm_h(xn, 1, PIPS_DMIX, hw + A.h_w1[d], arena + L.b1, h, 1, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX,

@@ -9,6 +9,6 @@ mkdir -p "$ROOT/build"
 cd "$ROOT/pips_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc "$@" -c $UNIT.hip -o "$ROOT/build/${UNIT}_$NAME.o"
 OBJS=""
-for f in gemm encoder encoder_bf16 track gather_tiled scoremap gemm_bf16 gemm_bf16_asm conv_bf16_c64 gemm_x3 api; do [ $f = $UNIT ] || OBJS="$OBJS $f.o"; done
+for f in gemm encoder encoder_bf16 track gather_tiled scoremap gemm_bf16 gemm_bf16_asm conv_bf16_c64 gemm_x3 ffn_fused api; do [ $f = $UNIT ] || OBJS="$OBJS $f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build/libpips_$NAME.so" $OBJS "$ROOT/build/${UNIT}_$NAME.o"
 echo "$ROOT/build/libpips_$NAME.so"
