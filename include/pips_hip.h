@@ -86,10 +86,11 @@ int    pips_repack_weights(const void* const* params_host, int nparams, void* ar
 /* The arena's three sections can be (re)built separately: PIPS_PACK_FP32 (the fp32 layouts, from params), PIPS_PACK_BF16
  * (bf16 copies of every matrix-core weight: the bf16-operand modes) and PIPS_PACK_SPLIT (three bf16 planes per weight: the
  * split-bf16 mode) -- the last two are derived from the arena's fp32 section (params may be null without PIPS_PACK_FP32),
- * so a process packs only what its matrix mode reads.  pips_repack_weights = all three. */
+ * so a process packs only what its matrix mode reads.  pips_repack_weights = all sections. */
 #define PIPS_PACK_FP32  1
 #define PIPS_PACK_BF16  2
 #define PIPS_PACK_SPLIT 4
+#define PIPS_PACK_FFN   8   /* the channel-mix weights in the fragment-stream order of pips_mixer_fwd_bf16_fused (implies PIPS_PACK_BF16) */
 int    pips_repack_weights_ex(const void* const* params_host, int nparams, void* arena, int sections, void* stream);
 
 /* ---- whole forward -------------------------------------------------------------------
@@ -195,6 +196,11 @@ int    pips_mixer_fwd(const void* arena, const float* X, int M, float* delta,
  * activations rounded to bf16 (RNE) as they are staged, fp32 accumulation and epilogues. */
 int    pips_mixer_fwd_bf16(const void* arena, const float* X, int M, float* delta,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* The same with every channel-mix FeedForward as ONE launch (csrc/ffn_fused.hip: a block owns 64 rows, the 2048-wide hidden
+ * activation never leaves the CU, weights streamed from L2 in fragment order; arena section PIPS_PACK_FFN; M % 64 == 0).  An
+ * alternative route, measured within 2 % of the two-GEMM route at BASELINE configs[2] and not taken by default. */
+int    pips_mixer_fwd_bf16_fused(const void* arena, const float* X, int M, float* delta,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 /* Same with every GEMM on the split-bf16 (bf16x3) path: fp32-grade results, see pips_gemm_f32x3. */
 int    pips_mixer_fwd_x3(const void* arena, const float* X, int M, float* delta,
                          void* workspace, size_t workspace_bytes, void* stream);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "pips_mixer_workspace_bytes": (c_size_t, [c_int]),
     "pips_mixer_fwd": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_bf16": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
+    "pips_mixer_fwd_bf16_fused": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_x3": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_timed": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p, C.POINTER(c_float)]),
     "pips_mixer_fwd_timed_ex": (c_int, [c_void_p, fp, c_int, c_int, fp, c_void_p, c_size_t, c_void_p,

@@ -163,12 +163,13 @@ size_t pips_weight_arena_bytes(void) {
 }
 
 int pips_repack_weights(const void* const* params, int nparams, void* arena_v, void* stream) {
-    return pips_repack_weights_ex(params, nparams, arena_v, PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT, stream);
+    return pips_repack_weights_ex(params, nparams, arena_v, PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT | PIPS_PACK_FFN, stream);
 }
 
 int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v, int sections, void* stream) {
     PIPS_CHECK_ARG(arena_v != nullptr, "repack: null pointer");
-    PIPS_CHECK_ARG(sections != 0 && (sections & ~(PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT)) == 0, "repack: bad section mask %d", sections);
+    PIPS_CHECK_ARG(sections != 0 && (sections & ~(PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT | PIPS_PACK_FFN)) == 0, "repack: bad section mask %d", sections);
+    if (sections & PIPS_PACK_FFN) sections |= PIPS_PACK_BF16;        // re-ordered from the bf16 copies
     hipStream_t st = (hipStream_t)stream;
     const ArenaLayout& A = arena_layout();
     float* arena = (float*)arena_v;
@@ -226,12 +227,17 @@ int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v
     }
     to_h(A.w_head, A.h_head, (size_t)PIPS_NOUT * PIPS_DMIX);
     to_h(A.w_in, A.h_in, (size_t)PIPS_DMIX * PIPS_KIN_PAD);
-    for (int d = 0; d < PIPS_DEPTH; ++d) {                 // fragment-major copies for the fused FeedForward (ffn_fused.hip)
+
+    for (int i = 1; i < 22; ++i)
+        to_h(A.conv[i].w, A.h_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
+  }
+  if (sections & PIPS_PACK_FFN) {
+    // the channel-mix weights once more, in the fragment-stream order of ffn_fused.hip (from the bf16 copies)
+    __bf16* hb = reinterpret_cast<__bf16*>(arena + A.total);
+    for (int d = 0; d < PIPS_DEPTH; ++d) {
         (void)launch_pack_frag(hb + A.h_w1[d], hb + A.f_w1[d], 4 * PIPS_DMIX, PIPS_DMIX, st);
         (void)launch_pack_frag(hb + A.h_w2[d], hb + A.f_w2[d], PIPS_DMIX, 4 * PIPS_DMIX, st);
     }
-    for (int i = 1; i < 22; ++i)
-        to_h(A.conv[i].w, A.h_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
   }
   if (sections & PIPS_PACK_SPLIT) {
     // split-bf16 planes of the same weights (fp32-grade matrix path on the bf16 cores), from the fp32 section
@@ -750,6 +756,11 @@ int pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16)
 // 32-element K blocks (544 = 17 x 32).
 static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                       size_t workspace_bytes, void* stream, hipEvent_t* ev, int bf16 = 0) {
+    const bool force_fused = bf16 == 3;            // pips_mixer_fwd_bf16_fused: the fused FeedForward whatever the size
+    if (force_fused) {
+        PIPS_CHECK_ARG(M % 64 == 0, "mixer (fused FeedForward): M=%d must be a multiple of 64", M);
+        bf16 = 1;
+    }
     PIPS_CHECK_ARG(arena_v && X && delta && workspace, "mixer: null pointer");
     PIPS_CHECK_ARG(M > 0 && M % PIPS_S == 0, "mixer: M=%d must be a positive multiple of %d", M, PIPS_S);
     if (workspace_bytes < pips_mixer_workspace_bytes(M)) {
@@ -803,7 +814,7 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
         RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1));
-        if (bf16 && ev == nullptr && ffn_fused_takes(M)) {
+        if (bf16 && ev == nullptr && (force_fused || ffn_fused_takes(M))) {
             // large M: up-projection, GELU and down-projection in one launch, the hidden activation stays on the CU
             const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
             RUN(launch_ffn_fused(xn, x, hw + A.f_w1[d], arena + L.b1, hw + A.f_w2[d], arena + L.b2, M, st));
@@ -843,6 +854,11 @@ int pips_mixer_fwd(const void* arena_v, const float* X, int M, float* delta, voi
 int pips_mixer_fwd_bf16(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                         size_t workspace_bytes, void* stream) {
     return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 1);
+}
+
+int pips_mixer_fwd_bf16_fused(const void* arena_v, const float* X, int M, float* delta, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 3);
 }
 
 int pips_mixer_fwd_x3(const void* arena_v, const float* X, int M, float* delta, void* workspace,

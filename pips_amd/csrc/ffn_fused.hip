@@ -129,21 +129,8 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const unsigned short* __
         const int i = tid + it * 256, r = i >> 6, cc = i & 63;
         *reinterpret_cast<uint4*>(XN + r * FF_XN_PITCH + cc * 16) = *reinterpret_cast<const uint4*>(xn + (row0 + r) * FF_D + cc * 8);
     }
-    // ---- residual tile + b2 into the down-projection's accumulators: ax[i][j][4g+e] = x[32i + l31][128 wave + 32j + 8g + 4 half + e]
     f32x16 ax[2][4];
     float* xrow = x + (row0 + l31) * FF_D + 128 * wave + 4 * half;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 bb = *reinterpret_cast<const float4*>(b2 + 128 * wave + 32 * j + 8 * g + 4 * half);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float4 v = *reinterpret_cast<const float4*>(xrow + (size_t)i * 32 * FF_D + 32 * j + 8 * g);
-                ax[i][j][4 * g] = v.x + bb.x; ax[i][j][4 * g + 1] = v.y + bb.y;
-                ax[i][j][4 * g + 2] = v.z + bb.z; ax[i][j][4 * g + 3] = v.w + bb.w;
-            }
-        }
     __syncthreads();
 
     f32x16 au[2][2];
@@ -218,6 +205,20 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const unsigned short* __
 
     // chunk 0: U alone, its GELU alone; chunks 1..7: U(c), then D(c-1) with GELU(c) in between; then D(7)
     phase_u(0, base_u(0), base_u(1), true);
+    // ---- residual tile + b2 into the down-projection's accumulators: ax[i][j][4g+e] = x[32i + l31][128 wave + 32j + 8g + 4 half + e]
+    // (requested behind U(0): first needed by D(0), a whole U phase later)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bb = *reinterpret_cast<const float4*>(b2 + 128 * wave + 32 * j + 8 * g + 4 * half);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(xrow + (size_t)i * 32 * FF_D + 32 * j + 8 * g);
+                ax[i][j][4 * g] = v.x + bb.x; ax[i][j][4 * g + 1] = v.y + bb.y;
+                ax[i][j][4 * g + 2] = v.z + bb.z; ax[i][j][4 * g + 3] = v.w + bb.w;
+            }
+        }
 #pragma unroll
     for (int p = 0; p < 16; ++p) gelu_piece(p, HB);
     lds_barrier();
@@ -242,9 +243,12 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const unsigned short* __
                     make_float4(ax[i][j][4 * g], ax[i][j][4 * g + 1], ax[i][j][4 * g + 2], ax[i][j][4 * g + 3]);
 }
 
-// whether launch_ffn_fused takes a FeedForward of M rows: whole 64-row blocks, and enough of them to fill the GPU
+// Whether the bf16 mixer takes the fused FeedForward by itself for M rows.  NOT by default: end to end (same box, same call,
+// BASELINE configs[2]) the two assembly GEMMs are 1-2 % ahead -- 14.52 / 14.57 ms against 14.71 / 14.72 ms per forward -- although
+// rocprofv3 reads 90.7 us for this kernel against 49.9 + 47.5 us for the pair.  pips_mixer_fwd_bf16_fused
+// forces it (parity test, tools/ffn_probe.py).
 bool ffn_fused_takes(int M) {
-    if (!PIPS_TUNE("PIPS_FFN_FUSED", 1) || M % FF_ROWS != 0) return false;
+    if (!PIPS_TUNE("PIPS_FFN_FUSED", 0) || M % FF_ROWS != 0) return false;
     const int cus = device_cus(), min_blocks = PIPS_TUNE("PIPS_FFN_MIN_BLOCKS", 0);        // tuning hook: take smaller problems too
     return cus > 0 && M / FF_ROWS >= (min_blocks > 0 ? min_blocks : cus);
 }

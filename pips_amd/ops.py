@@ -28,7 +28,7 @@ def _f32(t):
     return t.contiguous().to(torch.float32)
 
 
-PACK_FP32, PACK_BF16, PACK_SPLIT = 1, 2, 4
+PACK_FP32, PACK_BF16, PACK_SPLIT, PACK_FFN = 1, 2, 4, 8
 
 
 def pack_more(arena, sections):
@@ -40,7 +40,7 @@ def pack_more(arena, sections):
     return arena
 
 
-def pack_weights(state_dict, device, sections=PACK_FP32 | PACK_BF16 | PACK_SPLIT) -> torch.Tensor:
+def pack_weights(state_dict, device, sections=PACK_FP32 | PACK_BF16 | PACK_SPLIT | PACK_FFN) -> torch.Tensor:
     """state dict (reference key names/layouts) -> packed device arena (pips_repack_weights_ex); ``sections``: which of the
     fp32 / bf16-copy / split-plane sections to build now (pack_more adds the others later)."""
     lib = _lib.load()
@@ -185,9 +185,10 @@ def score_map_terms(pyr, B, H8, W8, ffeats, tgt):
     return out
 
 
-def mixer_fwd(arena, X, bf16=False, split=False):
+def mixer_fwd(arena, X, bf16=False, split=False, fused=False):
     """X (M,544) -> delta (M/8, 1040).  bf16: bf16 MFMA operands in the channel-mix/head GEMMs;
-    split: every GEMM on the fp32-grade split-bf16 path."""
+    split: every GEMM on the fp32-grade split-bf16 path; fused (with bf16, M % 64 == 0): each channel-mix FeedForward as
+    one launch (pips_mixer_fwd_bf16_fused; the arena needs its PACK_FFN section)."""
     lib = _lib.load()
     X = _f32(X)
     M = X.shape[0]
@@ -195,7 +196,7 @@ def mixer_fwd(arena, X, bf16=False, split=False):
     nb = lib.pips_mixer_workspace_bytes(M)
     ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
-        fn = lib.pips_mixer_fwd_x3 if split else (lib.pips_mixer_fwd_bf16 if bf16 else lib.pips_mixer_fwd)
+        fn = lib.pips_mixer_fwd_x3 if split else ((lib.pips_mixer_fwd_bf16_fused if fused else lib.pips_mixer_fwd_bf16) if bf16 else lib.pips_mixer_fwd)
         _lib.check(fn(_lib.ptr(arena), _lib.ptr(X), M, _lib.ptr(delta), _lib.ptr(ws), nb, _stream()), "pips_mixer_fwd")
     return delta
 

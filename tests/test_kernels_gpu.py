@@ -515,6 +515,33 @@ def test_mixer_bf16_operands(P, weights_raw, arenas):
     assert 1e-5 < e_bf16 < 3e-2          # bf16 operand rounding (2^-9 per product) through 25 GEMMs
 
 
+@pytest.mark.parametrize("P", [8, 256, 2048])
+def test_mixer_bf16_fused_feedforward_route(P, weights_raw, arenas):
+    """pips_mixer_fwd_bf16_fused (one launch per channel-mix FeedForward, ffn_fused.hip) against the two-GEMM bf16 route: the
+    same operand roundings (bf16 weights, bf16 LayerNorm output, bf16 hidden activation), a different summation order."""
+    from pips_amd import ops
+    O = _oracle()
+    g = torch.Generator().manual_seed(P + 7)
+    x = torch.randn(min(P, 256), 8, 519, generator=g)
+    if P > 256:
+        x = x.repeat(P // 256, 1, 1) + 0.01 * torch.randn(P, 8, 519, generator=g)
+    X = torch.zeros(P * 8, 544)
+    X[:, :519] = x.reshape(P * 8, 519)
+    two = ops.mixer_fwd(arenas["raw"], X.to(DEV), bf16=True).cpu()
+    one = ops.mixer_fwd(arenas["raw"], X.to(DEV), bf16=True, fused=True).cpu()
+    ref = O.mixer(weights_raw, x)
+    scale = max(1.0, float(ref.abs().max()))
+    d = float((one - two).abs().max()) / scale
+    e = float((one - ref).abs().max()) / scale
+    print(f"P={P}: fused vs two-GEMM {d:.2e}, fused vs fp32 oracle {e:.2e}")
+    assert torch.isfinite(one).all()
+    assert d < 1e-2 and e < 3e-2
+    from pips_amd._lib import PipsHipError
+    with pytest.raises(PipsHipError):                       # M must be whole 64-row blocks
+        ops.mixer_fwd(arenas["raw"], X[:40].to(DEV), bf16=True, fused=True)
+
+
+
 def test_state_update(weights_raw, arenas):
     from pips_amd import ops
     O = _oracle()

@@ -1,5 +1,5 @@
 """The bf16 mixer pass (12 layers) at M rows, per layer: how the fused FeedForward scales with the number of 64-row blocks.
-   PIPS_LIB_PATH=pips_amd/libpips_hip_tune.so PIPS_FFN_MIN_BLOCKS=1 python tools/ffn_probe.py"""
+   python tools/ffn_probe.py (the fused route, forced);  PIPS_FFN_FUSED=0 python tools/ffn_probe.py (the two-GEMM route)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,5 +17,5 @@ def t(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 for M in [int(m) for m in os.environ.get("FFN_MS", "4096,8192,16384,32768,65536").split(",")]:
     X = torch.randn(M, 544, generator=torch.Generator().manual_seed(0)).to(dev)
-    us = t(lambda: ops.mixer_fwd(arena, X, bf16=True))
+    us = t(lambda: ops.mixer_fwd(arena, X, bf16=True, fused=os.environ.get('PIPS_FFN_FUSED', '1') == '1'))
     print(f"M={M:6d} ({M//64:4d} blocks): mixer pass {us:8.1f} us = {us/12:6.1f} us per layer (token-mix + FeedForward)   FFN_FUSED={os.environ.get('PIPS_FFN_FUSED','1')}")
