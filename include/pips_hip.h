@@ -42,7 +42,7 @@ extern "C" {
 #define PIPS_E_WORKSPACE  -2   /* workspace too small                                */
 #define PIPS_E_LAUNCH     -3   /* hipLaunch error (see pips_last_error)              */
 
-#define PIPS_S        8        /* frames per window, fixed by the mixer weights      */
+#define PIPS_S        8        /* frames per window of the shipped checkpoints; other S: the _s entry points */
 #define PIPS_C        128      /* latent channels            nets/pips.py:408        */
 #define PIPS_LEVELS   4        /* correlation pyramid levels nets/pips.py:409        */
 #define PIPS_RADIUS   3        /* correlation radius         nets/pips.py:410        */
@@ -92,6 +92,29 @@ int    pips_repack_weights(const void* const* params_host, int nparams, void* ar
 #define PIPS_PACK_SPLIT 4
 #define PIPS_PACK_FFN   8   /* the channel-mix weights in the fragment-stream order of pips_mixer_fwd_bf16_fused (implies PIPS_PACK_BF16) */
 int    pips_repack_weights_ex(const void* const* params_host, int nparams, void* arena, int sections, void* stream);
+
+/* ---- any window length: Pips(S != 8) ----------------------------------------------------
+ * Replaces: the S argument of nets.pips.Pips.__init__ (nets/pips.py:401-402), which sizes the token-mixing weights
+ * (4S x S, S x 4S: :102-109,117) and the head (S*(C+2) x 512: :295-301).  Every entry point above and below without an S
+ * argument means S = PIPS_S = 8, the window of every shipped checkpoint, and runs kernels specialised for it; the _s
+ * variants take 1 <= S <= PIPS_S_MAX (the arena must have been packed for the same S) and run the token mixing, the final
+ * LayerNorm + mean and the state update on generic kernels (same arithmetic, not tuned), the GEMMs and the gather on
+ * the same kernels as S = 8.  pips_forward / pips_workspace_bytes take S from their own argument.  Rows of the mixer output
+ * (delta) are pips_delta_stride(S) = S*(C+2) rounded up to a multiple of 4 floats apart. */
+#define PIPS_S_MAX 16
+size_t pips_weight_arena_bytes_s(int S);
+int    pips_repack_weights_s(const void* const* params_host, int nparams, void* arena, int S, int sections, void* stream);
+int    pips_delta_stride(int S);
+size_t pips_mixer_workspace_bytes_s(int M, int S);
+int    pips_mixer_fwd_s(const void* arena, const float* X, int M, int S, int flags, float* delta,
+                        void* workspace, size_t workspace_bytes, void* stream);     /* flags: BF16_MIXER / SPLIT_BF16 */
+size_t pips_track_workspace_bytes_s(int B, int N, int S);
+/* pips_track / pips_track_ce (below) with the window length as an argument; ce_* may be NULL */
+int    pips_track_s(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
+                    const float* coords_init, const float* feat_init, const int* win_start, const float* times, int N,
+                    int stride, int iters, int flags, int S, void* workspace, size_t workspace_bytes, float* out_trajs,
+                    float* out_vis, float* out_ffeat0, const float* ce_tgt, float* ce_terms, void* ce_ws,
+                    size_t ce_ws_bytes, void* stream);
 
 /* ---- whole forward -------------------------------------------------------------------
  * Replaces: Pips.forward, inference branch (nets/pips.py:428-611 minus the dead fcp

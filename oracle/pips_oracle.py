@@ -216,7 +216,7 @@ def iteration(sd, pyramid, ffeats, coords, coords0, taps=None):
     if taps is not None:
         taps["fcorrs"] = fcorrs
         taps["mix_in"] = x
-    delta = mixer(sd, x, taps).reshape(-1, S_FRAMES, LATENT + 2)
+    delta = mixer(sd, x, taps).reshape(-1, ffeats.shape[1], LATENT + 2)          # DeltaBlock.forward: (B*N, self.S, C+2)
     if taps is not None:
         taps["delta"] = delta
     return update_step(sd, ffeats, coords, coords0, delta)

@@ -33,6 +33,14 @@ SIGNATURES = {
     "pips_score_map_prepare": (c_int, [fp, c_int, c_int, c_int, c_int, fp, c_void_p]),
     "pips_score_map_terms": (c_int, [fp, c_int, c_int, c_int, c_int, fp, c_int, fp, fp, c_void_p]),
     "pips_track_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pips_weight_arena_bytes_s": (c_size_t, [c_int]),
+    "pips_repack_weights_s": (c_int, [C.POINTER(c_void_p), c_int, c_void_p, c_int, c_int, c_void_p]),
+    "pips_delta_stride": (c_int, [c_int]),
+    "pips_mixer_workspace_bytes_s": (c_size_t, [c_int, c_int]),
+    "pips_mixer_fwd_s": (c_int, [c_void_p, fp, c_int, c_int, c_int, fp, c_void_p, c_size_t, c_void_p]),
+    "pips_track_workspace_bytes_s": (c_size_t, [c_int, c_int, c_int]),
+    "pips_track_s": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p, fp, c_int, c_int, c_int,
+                             c_int, c_int, c_void_p, c_size_t, fp, fp, fp, fp, fp, c_void_p, c_size_t, c_void_p]),
     "pips_track": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_void_p, fp, c_int, c_int, c_int,
                            c_int, c_void_p, c_size_t, fp, fp, fp, c_void_p]),
     "pips_encoder_workspace_bytes": (c_size_t, [c_int] * 4),

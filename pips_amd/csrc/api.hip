@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace pips {
 
@@ -40,9 +41,10 @@ int device_cus() {
 
 // ------------------------------------------------------------------ arena layout
 // conv geometry in execution (= state-dict) order: nets/pips.py:206-223, 135-136, 169-170
-static ArenaLayout build_layout() {
+static ArenaLayout build_layout(int S) {
     ArenaLayout A;
     memset(&A, 0, sizeof(A));
+    A.S = S; A.nout = S * (PIPS_C + 2); A.nout_pad = (A.nout + 3) & ~3;
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };   // 256-B aligned
     int ci = 0, idx = 0;
@@ -69,14 +71,12 @@ static ArenaLayout build_layout() {
     A.b_in = take(PIPS_DMIX);
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         MixLayerW& L = A.mix[d];
-        L.tw0 = take(32 * 8); L.tb0 = take(32); L.tw3 = take(8 * 32); L.tb3 = take(8);
         L.ln1g = take(PIPS_DMIX); L.ln1b = take(PIPS_DMIX);
         L.w1 = take((size_t)4 * PIPS_DMIX * PIPS_DMIX); L.b1 = take(4 * PIPS_DMIX);
         L.w2 = take((size_t)4 * PIPS_DMIX * PIPS_DMIX); L.b2 = take(PIPS_DMIX);
         L.ln2g = take(PIPS_DMIX); L.ln2b = take(PIPS_DMIX);
     }
     A.lnf_g = take(PIPS_DMIX); A.lnf_b = take(PIPS_DMIX);
-    A.w_head = take((size_t)PIPS_NOUT * PIPS_DMIX); A.b_head = take(PIPS_NOUT);
     A.norm_g = take(PIPS_C); A.norm_b = take(PIPS_C);
     A.w_upd_t = take(PIPS_C * PIPS_C); A.b_upd = take(PIPS_C);
     A.w_vis = take(PIPS_C); A.b_vis = take(1);
@@ -87,7 +87,6 @@ static ArenaLayout build_layout() {
         A.h_w1[d] = take_h((size_t)4 * PIPS_DMIX * PIPS_DMIX);
         A.h_w2[d] = take_h((size_t)4 * PIPS_DMIX * PIPS_DMIX);
     }
-    A.h_head = take_h((size_t)PIPS_NOUT * PIPS_DMIX);
     A.h_conv[0] = 0;                                   // the 7x7 stem stays fp32 (VALU kernel)
     for (int i = 1; i < 22; ++i) A.h_conv[i] = take_h((size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
     A.h_in = take_h((size_t)PIPS_DMIX * PIPS_KIN_PAD);
@@ -103,16 +102,33 @@ static ArenaLayout build_layout() {
         A.t_w1[d] = take_t((size_t)4 * PIPS_DMIX * PIPS_DMIX);
         A.t_w2[d] = take_t((size_t)4 * PIPS_DMIX * PIPS_DMIX);
     }
-    A.t_head = take_t((size_t)PIPS_NOUT * PIPS_DMIX);
     A.t_conv[0] = 0;
     for (int i = 1; i < 22; ++i) A.t_conv[i] = take_t((size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
     A.total_t = toff;
+    // ---- the S-dependent block, behind the three sections (offsets in floats from the arena base)
+    off = A.total + (A.total_h + A.total_t + 1) / 2;
+    off = (off + 63) / 64 * 64;
+    for (int d = 0; d < PIPS_DEPTH; ++d) {
+        MixLayerW& L = A.mix[d];
+        L.tw0 = take((size_t)4 * S * S); L.tb0 = take(4 * S); L.tw3 = take((size_t)S * 4 * S); L.tb3 = take(S);
+    }
+    A.w_head = take((size_t)A.nout_pad * PIPS_DMIX); A.b_head = take(A.nout_pad);
+    // bf16 copy / split planes of the head: addressed like the members of their sections, i.e. in ushorts from
+    // (arena + total) and from (arena + total) + total_h
+    const size_t hh = take(((size_t)A.nout_pad * PIPS_DMIX + 1) / 2);
+    const size_t th = take((3 * (size_t)A.nout_pad * PIPS_DMIX + 1) / 2);
+    A.h_head = 2 * (hh - A.total);
+    A.t_head = 2 * (th - A.total) - A.total_h;
+    A.total_all = off;
     return A;
 }
 
-const ArenaLayout& arena_layout() {
-    static const ArenaLayout A = build_layout();
-    return A;
+const ArenaLayout& arena_layout(int S) {
+    static ArenaLayout table[PIPS_S_MAX + 1];
+    static std::once_flag once[PIPS_S_MAX + 1];
+    if (S < 1 || S > PIPS_S_MAX) S = PIPS_S;          // (callers validate S; the S-independent members are the same anyway)
+    std::call_once(once[S], [S]() { table[S] = build_layout(S); });
+    return table[S];
 }
 
 // ------------------------------------------------------------------ repack kernels
@@ -157,21 +173,27 @@ extern "C" {
 const char* pips_last_error(void) { return g_err; }
 int pips_abi_version(void) { return 1; }
 
-size_t pips_weight_arena_bytes(void) {
-    return arena_layout().total * sizeof(float) +
-           (arena_layout().total_h + arena_layout().total_t) * sizeof(unsigned short);
+size_t pips_weight_arena_bytes(void) { return pips_weight_arena_bytes_s(PIPS_S); }
+int pips_delta_stride(int S) { return (S < 1 || S > PIPS_S_MAX) ? 0 : arena_layout(S).nout_pad; }
+size_t pips_weight_arena_bytes_s(int S) {
+    if (S < 1 || S > PIPS_S_MAX) return 0;
+    return arena_layout(S).total_all * sizeof(float);
 }
 
 int pips_repack_weights(const void* const* params, int nparams, void* arena_v, void* stream) {
-    return pips_repack_weights_ex(params, nparams, arena_v, PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT | PIPS_PACK_FFN, stream);
+    return pips_repack_weights_s(params, nparams, arena_v, PIPS_S, PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT | PIPS_PACK_FFN, stream);
+}
+int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v, int sections, void* stream) {
+    return pips_repack_weights_s(params, nparams, arena_v, PIPS_S, sections, stream);
 }
 
-int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v, int sections, void* stream) {
+int pips_repack_weights_s(const void* const* params, int nparams, void* arena_v, int S, int sections, void* stream) {
     PIPS_CHECK_ARG(arena_v != nullptr, "repack: null pointer");
+    PIPS_CHECK_ARG(S >= 1 && S <= PIPS_S_MAX, "repack: S=%d outside 1..%d", S, PIPS_S_MAX);
     PIPS_CHECK_ARG(sections != 0 && (sections & ~(PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT | PIPS_PACK_FFN)) == 0, "repack: bad section mask %d", sections);
     if (sections & PIPS_PACK_FFN) sections |= PIPS_PACK_BF16;        // re-ordered from the bf16 copies
     hipStream_t st = (hipStream_t)stream;
-    const ArenaLayout& A = arena_layout();
+    const ArenaLayout& A = arena_layout(S);
     float* arena = (float*)arena_v;
     int pi = 0;
   if (sections & PIPS_PACK_FP32) {
@@ -200,14 +222,18 @@ int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v
     copy(A.b_in, PIPS_DMIX);
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
-        copy(L.tw0, 32 * 8); copy(L.tb0, 32); copy(L.tw3, 8 * 32); copy(L.tb3, 8);
+        copy(L.tw0, (size_t)4 * S * S); copy(L.tb0, 4 * S); copy(L.tw3, (size_t)S * 4 * S); copy(L.tb3, S);     // nets/pips.py:102-109 over S tokens
         copy(L.ln1g, PIPS_DMIX); copy(L.ln1b, PIPS_DMIX);
         copy(L.w1, (size_t)4 * PIPS_DMIX * PIPS_DMIX); copy(L.b1, 4 * PIPS_DMIX);
         copy(L.w2, (size_t)4 * PIPS_DMIX * PIPS_DMIX); copy(L.b2, PIPS_DMIX);
         copy(L.ln2g, PIPS_DMIX); copy(L.ln2b, PIPS_DMIX);
     }
     copy(A.lnf_g, PIPS_DMIX); copy(A.lnf_b, PIPS_DMIX);
-    copy(A.w_head, (size_t)PIPS_NOUT * PIPS_DMIX); copy(A.b_head, PIPS_NOUT);
+    if (A.nout_pad != A.nout) {                          // odd S: zero rows up to a multiple of 4
+        (void)hipMemsetAsync(arena + A.w_head, 0, (size_t)A.nout_pad * PIPS_DMIX * sizeof(float), st);
+        (void)hipMemsetAsync(arena + A.b_head, 0, (size_t)A.nout_pad * sizeof(float), st);
+    }
+    copy(A.w_head, (size_t)A.nout * PIPS_DMIX); copy(A.b_head, A.nout);
     copy(A.norm_g, PIPS_C); copy(A.norm_b, PIPS_C);
     hipLaunchKernelGGL(transpose_kernel, dim3(nblk(PIPS_C * PIPS_C)), dim3(256), 0, st, src(), arena + A.w_upd_t,
                        PIPS_C, PIPS_C);
@@ -225,7 +251,7 @@ int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v
         to_h(A.mix[d].w1, A.h_w1[d], (size_t)4 * PIPS_DMIX * PIPS_DMIX);
         to_h(A.mix[d].w2, A.h_w2[d], (size_t)4 * PIPS_DMIX * PIPS_DMIX);
     }
-    to_h(A.w_head, A.h_head, (size_t)PIPS_NOUT * PIPS_DMIX);
+    to_h(A.w_head, A.h_head, (size_t)A.nout_pad * PIPS_DMIX);
     to_h(A.w_in, A.h_in, (size_t)PIPS_DMIX * PIPS_KIN_PAD);
 
     for (int i = 1; i < 22; ++i)
@@ -250,7 +276,7 @@ int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v
         to_t(A.mix[d].w1, A.t_w1[d], (size_t)4 * PIPS_DMIX * PIPS_DMIX);
         to_t(A.mix[d].w2, A.t_w2[d], (size_t)4 * PIPS_DMIX * PIPS_DMIX);
     }
-    to_t(A.w_head, A.t_head, (size_t)PIPS_NOUT * PIPS_DMIX);
+    to_t(A.w_head, A.t_head, (size_t)A.nout_pad * PIPS_DMIX);
     for (int i = 1; i < 22; ++i)
         to_t(A.conv[i].w, A.t_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
   }
@@ -657,7 +683,8 @@ int pips_point_sample(const float* level0, int B, int S, int H8, int W8, const f
 // scratch != null and a dense, un-windowed query set: LDS-tiled kernel; otherwise the direct one
 static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats, const float* coords,
                        const float* times, int N, const int* win_start, float* X, hipStream_t st,
-                       void* scratch = nullptr, size_t scratch_bytes = 0, int force_tiled = -1, hipEvent_t* ev = nullptr) {
+                       void* scratch = nullptr, size_t scratch_bytes = 0, int force_tiled = -1, hipEvent_t* ev = nullptr,
+                       int Sw = PIPS_S) {       // S: frames per clip in the pyramid; Sw: window length = mixer rows per particle
     size_t off[PIPS_LEVELS];
     int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
     lh[0] = H8; lw[0] = W8;
@@ -668,14 +695,14 @@ static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const
         o += ((size_t)B * S * lh[l] * lw[l] * PIPS_C + 63) / 64 * 64;
     }
     PIPS_CHECK_ARG(lh[PIPS_LEVELS - 1] >= 1 && lw[PIPS_LEVELS - 1] >= 1, "mixer_input: map too small");
-    const bool can_tile = scratch != nullptr && win_start == nullptr && S == PIPS_S &&
+    const bool can_tile = scratch != nullptr && win_start == nullptr && S == PIPS_S && Sw == PIPS_S &&
                           scratch_bytes >= tiled_gather_scratch_bytes(B, N, H8, W8);
     const bool tiled = force_tiled >= 0 ? (force_tiled != 0) : tiled_gather_wanted(B, N, H8, W8);
     if (tiled && can_tile)
         return launch_mixer_input_tiled(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, scratch, scratch_bytes, st, ev);
     PIPS_CHECK_ARG(force_tiled != 1, "tiled gather needs scratch of %zu bytes, no win_start and 8 frames per clip",
                    tiled_gather_scratch_bytes(B, N, H8, W8));
-    return launch_mixer_input(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, win_start, X, st);
+    return launch_mixer_input(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, win_start, X, st, Sw);
 }
 
 int pips_mixer_input_build(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats,
@@ -716,11 +743,12 @@ int pips_mixer_input_build_tiled_timed(const float* pyramid, int B, int S, int H
     return rc;
 }
 
-size_t pips_mixer_workspace_bytes(int M) {
-    if (M <= 0) return 0;
+size_t pips_mixer_workspace_bytes(int M) { return pips_mixer_workspace_bytes_s(M, PIPS_S); }
+size_t pips_mixer_workspace_bytes_s(int M, int S) {
+    if (M <= 0 || S < 1 || S > PIPS_S_MAX) return 0;
     Bump b;
     b.take((size_t)M * PIPS_DMIX); b.take((size_t)M * PIPS_DMIX); b.take((size_t)M * 4 * PIPS_DMIX);
-    b.take((size_t)(M / PIPS_S) * PIPS_DMIX);
+    b.take((size_t)(M / S) * PIPS_DMIX);
     return b.off * sizeof(float);
 }
 
@@ -754,29 +782,32 @@ int pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16)
 // bf16 == 1: bf16 MFMA operands for every Linear of the mixer (weights pre-converted; the LayerNorm-2 output and the
 // 2048-wide hidden activation stored as bf16, everything else fp32); the 544-wide input projection rides
 // 32-element K blocks (544 = 17 x 32).
+// S: the window length the arena was packed for (tokens per particle); delta rows are nout_pad(S) wide.
 static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, void* workspace,
-                      size_t workspace_bytes, void* stream, hipEvent_t* ev, int bf16 = 0) {
+                      size_t workspace_bytes, void* stream, hipEvent_t* ev, int bf16 = 0, int S = PIPS_S) {
     const bool force_fused = bf16 == 3;            // pips_mixer_fwd_bf16_fused: the fused FeedForward whatever the size
     if (force_fused) {
         PIPS_CHECK_ARG(M % 64 == 0, "mixer (fused FeedForward): M=%d must be a multiple of 64", M);
         bf16 = 1;
     }
     PIPS_CHECK_ARG(arena_v && X && delta && workspace, "mixer: null pointer");
-    PIPS_CHECK_ARG(M > 0 && M % PIPS_S == 0, "mixer: M=%d must be a positive multiple of %d", M, PIPS_S);
-    if (workspace_bytes < pips_mixer_workspace_bytes(M)) {
-        set_error("mixer: workspace %zu < %zu bytes", workspace_bytes, pips_mixer_workspace_bytes(M));
+    PIPS_CHECK_ARG(S >= 1 && S <= PIPS_S_MAX, "mixer: S=%d outside 1..%d", S, PIPS_S_MAX);
+    PIPS_CHECK_ARG(M > 0 && M % S == 0, "mixer: M=%d must be a positive multiple of S=%d", M, S);
+    if (workspace_bytes < pips_mixer_workspace_bytes_s(M, S)) {
+        set_error("mixer: workspace %zu < %zu bytes", workspace_bytes, pips_mixer_workspace_bytes_s(M, S));
         return PIPS_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const ArenaLayout& A = arena_layout();
+    const ArenaLayout& A = arena_layout(S);
+    const int NOUT = A.nout_pad;
     const float* arena = (const float*)arena_v;
     Bump b;
     float* ws = (float*)workspace;
     float* x = ws + b.take((size_t)M * PIPS_DMIX);
     float* xn = ws + b.take((size_t)M * PIPS_DMIX);
     float* h = ws + b.take((size_t)M * 4 * PIPS_DMIX);
-    float* pooled = ws + b.take((size_t)(M / PIPS_S) * PIPS_DMIX);
-    const int P = M / PIPS_S;
+    float* pooled = ws + b.take((size_t)(M / S) * PIPS_DMIX);
+    const int P = M / S;
     int g = 0;
 #define TIMED(call)                                                        \
     do {                                                                   \
@@ -792,14 +823,14 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
                               EPI_BIAS, nullptr, 0, stream));
         for (int d = 0; d < PIPS_DEPTH; ++d) {
             const MixLayerW& L = A.mix[d];
-            RUN(launch_token_mix(arena, L, x, xn, P, st));
+            RUN(launch_token_mix(arena, L, x, xn, P, st, 0, S));
             TIMED(pips_gemm_f32x3(xn, PIPS_DMIX, tw + A.t_w1[d], arena + L.b1, h, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX,
                                   PIPS_DMIX, EPI_GELU, nullptr, 0, stream));
             TIMED(pips_gemm_f32x3(h, 4 * PIPS_DMIX, tw + A.t_w2[d], arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX,
                                   4 * PIPS_DMIX, EPI_RESIDUAL, x, PIPS_DMIX, stream));
         }
-        RUN(launch_ln_mean(x, arena + A.lnf_g, arena + A.lnf_b, pooled, P, st));
-        TIMED(pips_gemm_f32x3(pooled, PIPS_DMIX, tw + A.t_head, arena + A.b_head, delta, PIPS_NOUT, P, PIPS_NOUT,
+        RUN(launch_ln_mean(x, arena + A.lnf_g, arena + A.lnf_b, pooled, P, st, S));
+        TIMED(pips_gemm_f32x3(pooled, PIPS_DMIX, tw + A.t_head, arena + A.b_head, delta, NOUT, P, NOUT,
                               PIPS_DMIX, EPI_BIAS, nullptr, 0, stream));
         return PIPS_OK;
     }
@@ -813,7 +844,7 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
     }
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
-        RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1));
+        RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1, S));
         if (bf16 && ev == nullptr && (force_fused || ffn_fused_takes(M))) {
             // large M: up-projection, GELU and down-projection in one launch, the hidden activation stays on the CU
             const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
@@ -833,13 +864,13 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
         TIMED(pips_gemm_f32(h, 4 * PIPS_DMIX, arena + L.w2, arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
                             EPI_RESIDUAL, x, PIPS_DMIX, stream));
     }
-    RUN(launch_ln_mean(x, arena + A.lnf_g, arena + A.lnf_b, pooled, P, st));
+    RUN(launch_ln_mean(x, arena + A.lnf_g, arena + A.lnf_b, pooled, P, st, S));
     if (bf16) {
         const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
-        TIMED(gemm_h(pooled, 0, PIPS_DMIX, hw + A.h_head, arena + A.b_head, delta, 0, PIPS_NOUT, P, PIPS_NOUT,
+        TIMED(gemm_h(pooled, 0, PIPS_DMIX, hw + A.h_head, arena + A.b_head, delta, 0, NOUT, P, NOUT,
                      PIPS_DMIX, EPI_BIAS, nullptr, 0, st));
     } else {
-        TIMED(pips_gemm_f32(pooled, PIPS_DMIX, arena + A.w_head, arena + A.b_head, delta, PIPS_NOUT, P, PIPS_NOUT,
+        TIMED(pips_gemm_f32(pooled, PIPS_DMIX, arena + A.w_head, arena + A.b_head, delta, NOUT, P, NOUT,
                             PIPS_DMIX, EPI_BIAS, nullptr, 0, stream));
     }
 #undef TIMED
@@ -864,6 +895,12 @@ int pips_mixer_fwd_bf16_fused(const void* arena_v, const float* X, int M, float*
 int pips_mixer_fwd_x3(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                       size_t workspace_bytes, void* stream) {
     return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 2);
+}
+
+int pips_mixer_fwd_s(const void* arena_v, const float* X, int M, int S, int flags, float* delta, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr,
+                      (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0), S);
 }
 
 int pips_mixer_fwd_timed(const void* arena_v, const float* X, int M, float* delta, void* workspace,
@@ -916,17 +953,17 @@ int pips_state_update(const void* arena, const float* delta, float* ffeats, floa
 // ------------------------------------------------------------------ tracker driver / whole forward
 namespace {
 struct TrackPlan { size_t coords, coords0, ffeats, ffeat0, X, delta, mixer, total; };   // floats
-TrackPlan plan_track(int B, int N) {
+TrackPlan plan_track(int B, int N, int S = PIPS_S) {
     TrackPlan P;
     Bump b;
-    const int M = B * N * PIPS_S;
+    const int M = B * N * S;
     P.coords = b.take((size_t)M * 2);
     P.coords0 = b.take((size_t)M * 2);
     P.ffeats = b.take((size_t)M * PIPS_C);
     P.ffeat0 = b.take((size_t)B * N * PIPS_C);
     P.X = b.take((size_t)M * PIPS_KIN_PAD);
-    P.delta = b.take((size_t)B * N * PIPS_NOUT);
-    P.mixer = b.take(pips_mixer_workspace_bytes(M) / sizeof(float));
+    P.delta = b.take((size_t)B * N * arena_layout(S).nout_pad);
+    P.mixer = b.take(pips_mixer_workspace_bytes_s(M, S) / sizeof(float));
     P.total = b.off;
     return P;
 }
@@ -937,15 +974,16 @@ FwdPlan plan_forward(int B, int S, int H, int W, int N, int stride) {
     const int F = B * S;
     P.pyramid = b.take(pips_pyramid_floats(F, H, W, stride));
     P.enc = b.take(pips_encoder_workspace_bytes(F, H, W, stride) / sizeof(float));
-    P.track = b.take(plan_track(B, N).total);
+    P.track = b.take(plan_track(B, N, S).total);
     P.total = b.off;
     return P;
 }
 }  // namespace
 
-size_t pips_track_workspace_bytes(int B, int N) {
-    if (B <= 0 || N <= 0) return 0;
-    return plan_track(B, N).total * sizeof(float);
+size_t pips_track_workspace_bytes(int B, int N) { return pips_track_workspace_bytes_s(B, N, PIPS_S); }
+size_t pips_track_workspace_bytes_s(int B, int N, int S) {
+    if (B <= 0 || N <= 0 || S < 1 || S > PIPS_S_MAX) return 0;
+    return plan_track(B, N, S).total * sizeof(float);
 }
 
 // level table of a pyramid with frames*H8*W8 level-0 pixels (pips_pyramid_offset's packing)
@@ -977,13 +1015,34 @@ int pips_score_map_terms(const float* U, int B, int S, int H8, int W8, const flo
     return launch_score_terms(U, B, S, H8, W8, ffeats, N, tgt, out, (hipStream_t)stream);
 }
 
+}  // extern "C"
+
+// S = window length (tokens per particle) the arena was packed for; S == PIPS_S runs the specialised kernels
+static int track_impl(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
+                      const float* coords_init, const float* feat_init, const int* win_start, const float* times, int N,
+                      int stride, int iters, int flags, int S, void* workspace, size_t workspace_bytes, float* out_trajs,
+                      float* out_vis, float* out_ffeat0, const float* ce_tgt, float* ce_terms, void* ce_ws,
+                      size_t ce_ws_bytes, void* stream);
+
+extern "C" {
+
 int pips_track(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
                const float* coords_init, const float* feat_init, const int* win_start, const float* times, int N,
                int stride, int iters, int flags, void* workspace, size_t workspace_bytes, float* out_trajs,
                float* out_vis, float* out_ffeat0, void* stream) {
-    return pips_track_ce(arena, pyramid, B, T, H8, W8, xys, coords_init, feat_init, win_start, times, N, stride, iters,
-                         flags, workspace, workspace_bytes, out_trajs, out_vis, out_ffeat0, nullptr, nullptr, nullptr, 0,
-                         stream);
+    return track_impl(arena, pyramid, B, T, H8, W8, xys, coords_init, feat_init, win_start, times, N, stride, iters,
+                      flags, PIPS_S, workspace, workspace_bytes, out_trajs, out_vis, out_ffeat0, nullptr, nullptr, nullptr, 0,
+                      stream);
+}
+
+int pips_track_s(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
+                 const float* coords_init, const float* feat_init, const int* win_start, const float* times, int N,
+                 int stride, int iters, int flags, int S, void* workspace, size_t workspace_bytes, float* out_trajs,
+                 float* out_vis, float* out_ffeat0, const float* ce_tgt, float* ce_terms, void* ce_ws,
+                 size_t ce_ws_bytes, void* stream) {
+    return track_impl(arena, pyramid, B, T, H8, W8, xys, coords_init, feat_init, win_start, times, N, stride, iters,
+                      flags, S, workspace, workspace_bytes, out_trajs, out_vis, out_ffeat0, ce_tgt, ce_terms, ce_ws, ce_ws_bytes,
+                      stream);
 }
 
 int pips_track_ce(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
@@ -991,31 +1050,44 @@ int pips_track_ce(const void* arena, const float* pyramid, int B, int T, int H8,
                   int stride, int iters, int flags, void* workspace, size_t workspace_bytes, float* out_trajs,
                   float* out_vis, float* out_ffeat0, const float* ce_tgt, float* ce_terms, void* ce_ws,
                   size_t ce_ws_bytes, void* stream) {
+    return track_impl(arena, pyramid, B, T, H8, W8, xys, coords_init, feat_init, win_start, times, N, stride, iters,
+                      flags, PIPS_S, workspace, workspace_bytes, out_trajs, out_vis, out_ffeat0, ce_tgt, ce_terms, ce_ws,
+                      ce_ws_bytes, stream);
+}
+
+}  // extern "C"
+
+static int track_impl(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
+                      const float* coords_init, const float* feat_init, const int* win_start, const float* times, int N,
+                      int stride, int iters, int flags, int S, void* workspace, size_t workspace_bytes, float* out_trajs,
+                      float* out_vis, float* out_ffeat0, const float* ce_tgt, float* ce_terms, void* ce_ws,
+                      size_t ce_ws_bytes, void* stream) {
     PIPS_CHECK_ARG(arena && pyramid && xys && times && workspace && out_trajs && out_vis, "track: null pointer");
     PIPS_CHECK_ARG(B > 0 && N > 0 && T >= 1 && iters >= 0 && stride >= 1, "track: need B,N,T,stride >= 1 and iters >= 0");
+    PIPS_CHECK_ARG(S >= 1 && S <= PIPS_S_MAX, "track: window length S=%d outside 1..%d", S, PIPS_S_MAX);
     PIPS_CHECK_ARG(H8 >= 8 && W8 >= 8, "track: map %dx%d too small for a 4-level pyramid", H8, W8);
-    const TrackPlan P = plan_track(B, N);
+    const TrackPlan P = plan_track(B, N, S);
     if (workspace_bytes < P.total * sizeof(float)) {
         set_error("track: workspace %zu < %zu bytes", workspace_bytes, P.total * sizeof(float));
         return PIPS_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
-    const int S = PIPS_S, M = B * N * S;
+    const int M = B * N * S;
     float* coords = ws + P.coords; float* coords0 = ws + P.coords0; float* ffeats = ws + P.ffeats;
     float* ffeat0 = out_ffeat0 != nullptr ? out_ffeat0 : ws + P.ffeat0;
     const size_t traj_sz = (size_t)B * S * N * 2;
-    RUN(launch_init_coords(xys, coords_init, B, N, (float)stride, coords, coords0, out_trajs, st));
+    RUN(launch_init_coords(xys, coords_init, B, N, (float)stride, coords, coords0, out_trajs, st, S));
     if (feat_init != nullptr) {
         if (feat_init != ffeat0)
             (void)hipMemcpyAsync(ffeat0, feat_init, (size_t)B * N * PIPS_C * sizeof(float), hipMemcpyDeviceToDevice, st);
     } else {
         RUN(launch_point_sample_strided(pyramid, B, T, H8, W8, coords, S * 2, N, win_start, ffeat0, st));   // :463
     }
-    RUN(launch_init_ffeats(ffeat0, B * N, ffeats, st));                                                      // :466
+    RUN(launch_init_ffeats(ffeat0, B * N, ffeats, st, S));                                                    // :466
     if (ce_tgt != nullptr) {            // score-map loss terms of every iteration (:501-511, 58-92): evaluation only
-        PIPS_CHECK_ARG(ce_terms && ce_ws && win_start == nullptr && T == PIPS_S,
-                       "track: score-map terms need their output and workspace, 8 frames per clip and no windows");
+        PIPS_CHECK_ARG(ce_terms && ce_ws && win_start == nullptr && T == S,
+                       "track: score-map terms need their output and workspace, S frames per clip and no windows");
         if (ce_ws_bytes < pips_score_map_workspace_bytes(B, T, H8, W8)) {
             set_error("track: score-map workspace %zu < %zu bytes", ce_ws_bytes, pips_score_map_workspace_bytes(B, T, H8, W8));
             return PIPS_E_WORKSPACE;
@@ -1023,24 +1095,26 @@ int pips_track_ce(const void* arena, const float* pyramid, int B, int T, int H8,
         RUN(pips_score_map_prepare(pyramid, B, T, H8, W8, (float*)ce_ws, stream));
     }
     if (iters == 0)       // the loop body never runs: vis_e comes from the initial features (:559)
-        RUN(launch_vis_head((const float*)arena, ffeats, B, N, out_vis, st));
+        RUN(launch_vis_head((const float*)arena, ffeats, B, N, out_vis, st, S));
     for (int it = 0; it < iters; ++it) {                                                                     // :499
         if (ce_tgt != nullptr)           // fcorr_fn.corr(ffeats) of this iteration (:501), before the update
             RUN(launch_score_terms((const float*)ce_ws, B, S, H8, W8, ffeats, N, ce_tgt, ce_terms + (size_t)it * M * 2, st));
         // the mixer workspace is idle while the gather runs: it doubles as the binning scratch
         RUN(mixer_input(pyramid, B, T, H8, W8, ffeats, coords, times, N, win_start, ws + P.X, st, ws + P.mixer,
-                        pips_mixer_workspace_bytes(M)));
-        RUN(mixer_impl(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes(M), stream, nullptr,
-                       (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0)));
+                        pips_mixer_workspace_bytes_s(M, S), -1, nullptr, S));
+        RUN(mixer_impl(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes_s(M, S), stream, nullptr,
+                       (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0), S));
         RUN(launch_state_update((const float*)arena, ws + P.delta, ffeats, coords, coords0, B, N, (float)stride,
-                                out_trajs + (size_t)(it + 1) * traj_sz, it + 1 == iters ? out_vis : nullptr, st));
+                                out_trajs + (size_t)(it + 1) * traj_sz, it + 1 == iters ? out_vis : nullptr, st, S));
     }
     PIPS_CHECK_LAUNCH("pips_track");
     return PIPS_OK;
 }
 
+extern "C" {
+
 size_t pips_workspace_bytes(int B, int S, int H, int W, int N, int stride) {
-    if (B <= 0 || S != PIPS_S || H <= 0 || W <= 0 || N <= 0 || stride < 1) return 0;
+    if (B <= 0 || S < 1 || S > PIPS_S_MAX || H <= 0 || W <= 0 || N <= 0 || stride < 1) return 0;
     return plan_forward(B, S, H, W, N, stride).total * sizeof(float);
 }
 
@@ -1059,7 +1133,7 @@ int pips_forward_ce(const void* arena, const float* rgbs, const float* xys, cons
                     void* stream) {
     PIPS_CHECK_ARG(arena && xys && times && workspace && out_trajs && out_vis, "forward: null pointer");
     PIPS_CHECK_ARG((flags & PIPS_FLAG_REUSE_MAPS) || rgbs != nullptr, "forward: rgbs is null");
-    PIPS_CHECK_ARG(S == PIPS_S, "forward: S=%d, the mixer weights fix S=%d (nets/pips.py:295-301)", S, PIPS_S);
+    PIPS_CHECK_ARG(S >= 1 && S <= PIPS_S_MAX, "forward: S=%d outside 1..%d (the arena must be packed for the same S, nets/pips.py:295-301)", S, PIPS_S_MAX);
     PIPS_CHECK_ARG(B > 0 && N > 0 && iters >= 0, "forward: need B,N >= 1 and iters >= 0");
     RUN(check_geometry(B * S, H, W, stride));
     const FwdPlan P = plan_forward(B, S, H, W, N, stride);
@@ -1074,9 +1148,9 @@ int pips_forward_ce(const void* arena, const float* rgbs, const float* xys, cons
                          pips_encoder_workspace_bytes(B * S, H, W, stride), stream,
                          ((flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0) | ((flags & PIPS_FLAG_RGB_U8) ? 2 : 0) |
                              ((flags & PIPS_FLAG_SPLIT_BF16) ? 4 : 0)));
-    return pips_track_ce(arena, pyramid, B, S, H / stride, W / stride, xys, coords_init, feat_init, nullptr, times, N,
-                         stride, iters, flags, ws + P.track, plan_track(B, N).total * sizeof(float), out_trajs, out_vis,
-                         out_ffeat0, ce_tgt, ce_terms, ce_ws, ce_ws_bytes, stream);
+    return track_impl(arena, pyramid, B, S, H / stride, W / stride, xys, coords_init, feat_init, nullptr, times, N,
+                      stride, iters, flags, S, ws + P.track, plan_track(B, N, S).total * sizeof(float), out_trajs, out_vis,
+                      out_ffeat0, ce_tgt, ce_terms, ce_ws, ce_ws_bytes, stream);
 }
 
 }  // extern "C"

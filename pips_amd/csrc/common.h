@@ -274,8 +274,14 @@ struct ArenaLayout {
     // split-bf16 planes [3][N][K] of every matrix-core weight (gemm_x3.hip), in ushort units from
     // the end of the bf16 section
     size_t t_in, t_w1[PIPS_DEPTH], t_w2[PIPS_DEPTH], t_head, t_conv[22], total_t;
+    // Everything whose SHAPE depends on the window length S (nets/pips.py:295-301: the token-mixing weights 4S x S / S x 4S
+    // and the head S*(C+2) x 512, with its bf16 copy and split planes) sits in a fourth block behind the three sections, so that
+    // every other offset is the same for every S.  S-dependent members: mix[].tw0/tb0/tw3/tb3, w_head, b_head, h_head, t_head.
+    int S, nout, nout_pad;   // nout = S*(C+2); rows nout .. nout_pad-1 of the head are zero (N % 4 == 0 for the bf16 GEMM)
+    size_t total_all;        // floats, the whole arena
 };
-const ArenaLayout& arena_layout();
+// window lengths 1 .. PIPS_S_MAX (pips_hip.h): the generic kernels keep the S tokens of two channels in registers
+const ArenaLayout& arena_layout(int S = PIPS_S);    // S-independent members are valid whatever S was asked for
 
 // ---------------------------------------------------------------- encoder pieces (encoder.hip)
 inline int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
@@ -307,12 +313,13 @@ int launch_point_sample(const float* level0, int B, int S, int H8, int W8, const
                         float* out, hipStream_t st);
 int launch_point_sample_strided(const float* level0, int B, int S, int H8, int W8, const float* xy,
                                 int xy_stride, int N, const int* win_start, float* out, hipStream_t st);
+// Sw (last argument of the tracker launchers): the window length = mixer rows per particle; PIPS_S runs the specialised kernels
 int launch_init_coords(const float* xys, const float* coords_init, int B, int N, float stride,
-                       float* coords, float* coords0, float* out_traj0, hipStream_t st);
-int launch_init_ffeats(const float* ffeat0, int BN, float* ffeats, hipStream_t st);
+                       float* coords, float* coords0, float* out_traj0, hipStream_t st, int Sw = PIPS_S);
+int launch_init_ffeats(const float* ffeat0, int BN, float* ffeats, hipStream_t st, int Sw = PIPS_S);
 int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW,
                        int B, int S, const float* ffeats, const float* coords, const float* times,
-                       int N, const int* win_start, float* X, hipStream_t st);
+                       int N, const int* win_start, float* X, hipStream_t st, int Sw = PIPS_S);
 // LDS-tiled gather for dense query sets (gather_tiled.hip)
 size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8);
 bool tiled_gather_wanted(int B, int N, int H8, int W8);
@@ -321,16 +328,16 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
                              int S, const float* ffeats, const float* coords, const float* times, int N,
                              float* X, void* scratch, size_t scratch_bytes, hipStream_t st, hipEvent_t* ev = nullptr);
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
-                     hipStream_t st, int xn_bf16 = 0);
+                     hipStream_t st, int xn_bf16 = 0, int Sw = PIPS_S);
 int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,
-                   hipStream_t st);
+                   hipStream_t st, int Sw = PIPS_S);
 int launch_score_upsum(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int F, float* U,
                        hipStream_t st);
 int launch_score_terms(const float* U, int B, int S, int H8, int W8, const float* ffeats, int N, const float* tgt,
                        float* out, hipStream_t st);
-int launch_vis_head(const float* arena, const float* ffeats, int B, int N, float* out_vis, hipStream_t st);
+int launch_vis_head(const float* arena, const float* ffeats, int B, int N, float* out_vis, hipStream_t st, int Sw = PIPS_S);
 int launch_state_update(const float* arena, const float* delta, float* ffeats, float* coords,
                         const float* coords0, int B, int N, float stride, float* out_traj,
-                        float* out_vis, hipStream_t st);
+                        float* out_vis, hipStream_t st, int Sw = PIPS_S);
 
 }  // namespace pips

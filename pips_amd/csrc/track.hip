@@ -57,44 +57,44 @@ int launch_point_sample(const float* level0, int B, int S_, int H8, int W8, cons
 // nets/pips.py:450-455 (coords), :466 (ffeats repeat), :468 (coords_bak), :474 (first entry
 // of coord_predictions2).  Phase 0 writes coords; phase 1 (after the point sample) ffeats.
 __global__ void init_coords_kernel(const float* __restrict__ xys, const float* __restrict__ coords_init,
-                                   int B, int N, float stride, float* __restrict__ coords,
+                                   int B, int N, int Sw, float stride, float* __restrict__ coords,
                                    float* __restrict__ coords0, float* __restrict__ out_traj0) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // (b*N + n)*S + s
-    if (i >= B * N * S) return;
-    const int s = i % S, pn = i / S, n = pn % N, b = pn / N;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // (b*N + n)*Sw + s
+    if (i >= B * N * Sw) return;
+    const int s = i % Sw, pn = i / Sw, n = pn % N, b = pn / N;
     float x, y;
     if (coords_init != nullptr) {
-        const float* p = coords_init + (((size_t)b * S + s) * N + n) * 2;
+        const float* p = coords_init + (((size_t)b * Sw + s) * N + n) * 2;
         x = p[0] / stride; y = p[1] / stride;
     } else {
         x = xys[(size_t)pn * 2 + 0] / stride; y = xys[(size_t)pn * 2 + 1] / stride;
     }
     coords[(size_t)i * 2 + 0] = x; coords[(size_t)i * 2 + 1] = y;
     coords0[(size_t)i * 2 + 0] = x; coords0[(size_t)i * 2 + 1] = y;
-    float* o = out_traj0 + (((size_t)b * S + s) * N + n) * 2;
+    float* o = out_traj0 + (((size_t)b * Sw + s) * N + n) * 2;
     o[0] = x * stride; o[1] = y * stride;
 }
 
-__global__ void init_ffeats_kernel(const float4* __restrict__ ffeat0, int BN, float4* __restrict__ ffeats) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over BN*S*32 float4
-    if (i >= (size_t)BN * S * (C / 4)) return;
-    const size_t pn = i / (S * (C / 4));
+__global__ void init_ffeats_kernel(const float4* __restrict__ ffeat0, int BN, int Sw, float4* __restrict__ ffeats) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over BN*Sw*32 float4
+    if (i >= (size_t)BN * Sw * (C / 4)) return;
+    const size_t pn = i / ((size_t)Sw * (C / 4));
     ffeats[i] = ffeat0[pn * (C / 4) + (i % (C / 4))];
 }
 
 int launch_init_coords(const float* xys, const float* coords_init, int B, int N, float stride,
-                       float* coords, float* coords0, float* out_traj0, hipStream_t st) {
-    const int total = B * N * S;
+                       float* coords, float* coords0, float* out_traj0, hipStream_t st, int Sw) {
+    const int total = B * N * Sw;
     hipLaunchKernelGGL(init_coords_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, xys, coords_init, B,
-                       N, stride, coords, coords0, out_traj0);
+                       N, Sw, stride, coords, coords0, out_traj0);
     PIPS_CHECK_LAUNCH("init_coords_kernel");
     return PIPS_OK;
 }
 
-int launch_init_ffeats(const float* ffeat0, int BN, float* ffeats, hipStream_t st) {
-    const size_t total = (size_t)BN * S * (C / 4);
+int launch_init_ffeats(const float* ffeat0, int BN, float* ffeats, hipStream_t st, int Sw) {
+    const size_t total = (size_t)BN * Sw * (C / 4);
     hipLaunchKernelGGL(init_ffeats_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const float4*>(ffeat0), BN, reinterpret_cast<float4*>(ffeats));
+                       reinterpret_cast<const float4*>(ffeat0), BN, Sw, reinterpret_cast<float4*>(ffeats));
     PIPS_CHECK_LAUNCH("init_ffeats_kernel");
     return PIPS_OK;
 }
@@ -118,14 +118,17 @@ struct LevelTable {
 
 // waves_per_eu(2,4): let the compiler spend up to 128 VGPRs so 16 x 1 KiB loads stay in flight per
 // wave (left alone it squeezes into 64 VGPRs for 8 waves/SIMD and issues the loads two at a time)
+// SCT: window length (mixer rows per particle) as a compile-time constant, 0 = the run-time argument Srt (Pips(S != 8))
+template <int SCT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void mixer_input_kernel(const float* __restrict__ pyramid,
-                                                          LevelTable lv, int S_,
+                                                          LevelTable lv, int S_, int Srt,
                                                           const float* __restrict__ ffeats,
                                                           const float* __restrict__ coords,
                                                           const float* __restrict__ times, int N,
                                                           const int* __restrict__ win_start,
                                                           float* __restrict__ X) {
     __shared__ float Dw[PIPS_LEVELS][64];
+    const int S = SCT ? SCT : Srt;                       // (shadows the file-scope constant)
     const int m = blockIdx.x;
     const int s = m % S, pn = m / S;
     const int b = pn / N;
@@ -238,11 +241,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 
 int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW,
                        int B, int S_, const float* ffeats, const float* coords, const float* times,
-                       int N, const int* win_start, float* X, hipStream_t st) {
+                       int N, const int* win_start, float* X, hipStream_t st, int Sw) {
     LevelTable lv;
     for (int l = 0; l < PIPS_LEVELS; ++l) { lv.off[l] = lvl_off[l]; lv.H[l] = lvlH[l]; lv.W[l] = lvlW[l]; }
-    hipLaunchKernelGGL(mixer_input_kernel, dim3(B * N * S), dim3(256), 0, st, pyramid, lv, S_, ffeats,
-                       coords, times, N, win_start, X);
+    if (Sw == PIPS_S)
+        hipLaunchKernelGGL(mixer_input_kernel<PIPS_S>, dim3(B * N * S), dim3(256), 0, st, pyramid, lv, S_, Sw, ffeats,
+                           coords, times, N, win_start, X);
+    else
+        hipLaunchKernelGGL(mixer_input_kernel<0>, dim3(B * N * Sw), dim3(256), 0, st, pyramid, lv, S_, Sw, ffeats,
+                           coords, times, N, win_start, X);
     PIPS_CHECK_LAUNCH("mixer_input_kernel");
     return PIPS_OK;
 }
@@ -573,8 +580,122 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Any window length (Pips(S != 8), nets/pips.py:295-301: token MLP S -> 4S -> S).  The same arithmetic as token_mix_kernel with
+// the token axis as guarded compile-time-unrolled loops over SMAX >= Sw registers (the guards are wave-uniform), weights of
+// run-time size in dynamic LDS, plain shuffle reductions.  Not tuned: no shipped checkpoint has S != 8.
+template <int SMAX>
+__device__ __forceinline__ void block_sum_any(float (&v)[SMAX], int Sw, float* red /* [4][SMAX] */) {
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t)
+        if (t < Sw) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v[t] += __shfl_xor(v[t], o);
+        }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                       // previous use of red finished
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int t = 0; t < SMAX; ++t)
+            if (t < Sw) red[wave * SMAX + t] = v[t];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t)
+        if (t < Sw) v[t] = (red[t] + red[SMAX + t]) + (red[2 * SMAX + t] + red[3 * SMAX + t]);
+}
+
+// two-pass LayerNorm statistics of Sw tokens x 512 channels, 2 channels per thread
+template <int SMAX>
+__device__ __forceinline__ void ln_stats_any(const f2 (&x)[SMAX], int Sw, float (&mean)[SMAX], float (&rstd)[SMAX], float* red) {
+    float a[SMAX];
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t) a[t] = x[t].x + x[t].y;
+    block_sum_any<SMAX>(a, Sw, red);
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t) mean[t] = a[t] * (1.0f / PIPS_DMIX);
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t) {
+        const f2 d = x[t] - (f2){mean[t], mean[t]};
+        a[t] = d.x * d.x + d.y * d.y;
+    }
+    block_sum_any<SMAX>(a, Sw, red);
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t) rstd[t] = rsqrt_nr(a[t] * (1.0f / PIPS_DMIX) + 1e-5f);
+}
+
+template <int SMAX, bool XN_BF16>
+__global__ __launch_bounds__(256) void token_mix_any_kernel(const float* __restrict__ arena, MixLayerW L, float* __restrict__ x,
+                                                            float* __restrict__ xn, int Sw) {
+    extern __shared__ float dyn[];
+    const int H4 = 4 * Sw, tid = threadIdx.x;
+    float* w0 = dyn;                  // [4S][S]
+    float* b0 = w0 + H4 * Sw;         // [4S]
+    float* w3 = b0 + H4;              // [S][4S]
+    float* b3 = w3 + Sw * H4;         // [S]
+    float* red = b3 + Sw;             // [4][SMAX]
+    for (int i = tid; i < H4 * Sw; i += 256) { w0[i] = arena[L.tw0 + i]; w3[i] = arena[L.tw3 + i]; }
+    for (int i = tid; i < H4; i += 256) b0[i] = arena[L.tb0 + i];
+    if (tid < Sw) b3[tid] = arena[L.tb3 + tid];
+
+    float* xp = x + (size_t)blockIdx.x * Sw * PIPS_DMIX + 2 * tid;
+    f2 xv[SMAX];
+    float mean[SMAX], rstd[SMAX];
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t) xv[t] = t < Sw ? *reinterpret_cast<const f2*>(xp + t * PIPS_DMIX) : (f2){0.f, 0.f};
+    const f2 g1 = *reinterpret_cast<const f2*>(arena + L.ln1g + 2 * tid), be1 = *reinterpret_cast<const f2*>(arena + L.ln1b + 2 * tid);
+    const f2 g2 = *reinterpret_cast<const f2*>(arena + L.ln2g + 2 * tid), be2 = *reinterpret_cast<const f2*>(arena + L.ln2b + 2 * tid);
+    ln_stats_any<SMAX>(xv, Sw, mean, rstd, red);          // (its barriers also publish the weights)
+
+    f2 h[SMAX], y[SMAX];
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t) {
+        h[t] = (xv[t] - (f2){mean[t], mean[t]}) * (g1 * (f2){rstd[t], rstd[t]}) + be1;
+        const float bt = t < Sw ? b3[t] : 0.f;
+        y[t] = (f2){bt, bt};
+    }
+    for (int j = 0; j < H4; ++j) {
+        f2 u = (f2){b0[j], b0[j]};
+#pragma unroll
+        for (int t = 0; t < SMAX; ++t)
+            if (t < Sw) u = h[t] * w0[j * Sw + t] + u;
+        u = gelu_exact2(u);
+#pragma unroll
+        for (int t = 0; t < SMAX; ++t)
+            if (t < Sw) y[t] = u * w3[t * H4 + j] + y[t];
+    }
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t) y[t] += xv[t];
+
+    ln_stats_any<SMAX>(y, Sw, mean, rstd, red);
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t)
+        if (t < Sw) {
+            *reinterpret_cast<f2*>(xp + t * PIPS_DMIX) = y[t];
+            const f2 o = (y[t] - (f2){mean[t], mean[t]}) * (g2 * (f2){rstd[t], rstd[t]}) + be2;
+            if (XN_BF16) {
+                reinterpret_cast<unsigned*>(xn)[((size_t)blockIdx.x * Sw + t) * (PIPS_DMIX / 2) + tid] = pack2_bf16(o.x, o.y);
+            } else {
+                *reinterpret_cast<f2*>(xn + ((size_t)blockIdx.x * Sw + t) * PIPS_DMIX + 2 * tid) = o;
+            }
+        }
+}
+
+template <int SMAX>
+static int launch_token_mix_any(const float* arena, const MixLayerW& L, float* x, float* xn, int particles, hipStream_t st,
+                                int xn_bf16, int Sw) {
+    const size_t lds = (size_t)(8 * Sw * Sw + 5 * Sw + 4 * SMAX) * sizeof(float);
+    if (xn_bf16)
+        hipLaunchKernelGGL((token_mix_any_kernel<SMAX, true>), dim3(particles), dim3(256), lds, st, arena, L, x, xn, Sw);
+    else
+        hipLaunchKernelGGL((token_mix_any_kernel<SMAX, false>), dim3(particles), dim3(256), lds, st, arena, L, x, xn, Sw);
+    PIPS_CHECK_LAUNCH("token_mix_any_kernel");
+    return PIPS_OK;
+}
+
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
-                     hipStream_t st, int xn_bf16) {
+                     hipStream_t st, int xn_bf16, int Sw) {
+    if (Sw != PIPS_S)
+        return launch_token_mix_any<PIPS_S_MAX>(arena, L, x, xn, particles, st, xn_bf16, Sw);
     if (xn_bf16 && PIPS_TUNE("PIPS_TOKEN_MFMA", 1)) {
         // bf16-operand mixer: token MLP on the matrix cores, one wave per particle
         hipLaunchKernelGGL(token_mix_mfma_kernel, dim3(cdiv(particles, 4)), dim3(256), 0, st, arena, L, x, reinterpret_cast<unsigned*>(xn), particles);
@@ -611,8 +732,32 @@ __global__ __launch_bounds__(256) void ln_mean_kernel(const float* __restrict__ 
     out[(size_t)blockIdx.x * PIPS_DMIX + c1] = a1 * (1.0f / S);
 }
 
+// any window length: nn.LayerNorm(512) per token, mean over the Sw tokens
+template <int SMAX>
+__global__ __launch_bounds__(256) void ln_mean_any_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ bta, float* __restrict__ out, int Sw) {
+    __shared__ float red[4 * SMAX];
+    const float* xp = x + (size_t)blockIdx.x * Sw * PIPS_DMIX + 2 * threadIdx.x;
+    f2 xv[SMAX];
+    float mean[SMAX], rstd[SMAX];
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t) xv[t] = t < Sw ? *reinterpret_cast<const f2*>(xp + t * PIPS_DMIX) : (f2){0.f, 0.f};
+    ln_stats_any<SMAX>(xv, Sw, mean, rstd, red);
+    const f2 gg = *reinterpret_cast<const f2*>(g + 2 * threadIdx.x), bb = *reinterpret_cast<const f2*>(bta + 2 * threadIdx.x);
+    f2 a = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t)
+        if (t < Sw) a += (xv[t] - (f2){mean[t], mean[t]}) * (f2){rstd[t], rstd[t]} * gg + bb;
+    *reinterpret_cast<f2*>(out + (size_t)blockIdx.x * PIPS_DMIX + 2 * threadIdx.x) = a * (1.0f / (float)Sw);
+}
+
 int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,
-                   hipStream_t st) {
+                   hipStream_t st, int Sw) {
+    if (Sw != PIPS_S) {
+        hipLaunchKernelGGL(ln_mean_any_kernel<PIPS_S_MAX>, dim3(particles), dim3(256), 0, st, x, g, b, out, Sw);
+        PIPS_CHECK_LAUNCH("ln_mean_any_kernel");
+        return PIPS_OK;
+    }
     hipLaunchKernelGGL(ln_mean_kernel, dim3(particles), dim3(256), 0, st, x, g, b, out);
     PIPS_CHECK_LAUNCH("ln_mean_kernel");
     return PIPS_OK;
@@ -713,7 +858,7 @@ __global__ __launch_bounds__(256) void state_update_kernel(const float* __restri
 // vis_predictor alone (nets/pips.py:421-426,559) on the current features: the iters = 0 forward, where
 // the reference returns the visibility logits of the INITIAL features.  One wave per mixer row.
 __global__ __launch_bounds__(256) void vis_head_kernel(const float* __restrict__ arena, size_t o_wv, size_t o_bv,
-                                                       const float* __restrict__ ffeats, int N, int M,
+                                                       const float* __restrict__ ffeats, int N, int M, int Sw,
                                                        float* __restrict__ out_vis) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= M) return;
@@ -722,22 +867,119 @@ __global__ __launch_bounds__(256) void vis_head_kernel(const float* __restrict__
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     if (lane == 0) {
-        const int t = m % S, pn = m / S, b = pn / N, n = pn - b * N;
-        out_vis[((size_t)b * S + t) * N + n] = v + arena[o_bv];
+        const int t = m % Sw, pn = m / Sw, b = pn / N, n = pn - b * N;
+        out_vis[((size_t)b * Sw + t) * N + n] = v + arena[o_bv];
     }
 }
 
-int launch_vis_head(const float* arena, const float* ffeats, int B, int N, float* out_vis, hipStream_t st) {
+int launch_vis_head(const float* arena, const float* ffeats, int B, int N, float* out_vis, hipStream_t st, int Sw) {
     const ArenaLayout& A = arena_layout();
-    const int M = B * N * S;
-    hipLaunchKernelGGL(vis_head_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, arena, A.w_vis, A.b_vis, ffeats, N, M, out_vis);
+    const int M = B * N * Sw;
+    hipLaunchKernelGGL(vis_head_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, arena, A.w_vis, A.b_vis, ffeats, N, M, Sw, out_vis);
     PIPS_CHECK_LAUNCH("vis_head_kernel");
     return PIPS_OK;
 }
 
+// any window length: the same update, the particle's Sw rows in groups of 8; delta rows are ldd floats apart
+__global__ __launch_bounds__(256) void state_update_any_kernel(const float* __restrict__ arena,
+                                                               size_t o_ng, size_t o_nb, size_t o_wt, size_t o_b,
+                                                               size_t o_wv, size_t o_bv,
+                                                               const float* __restrict__ delta, int ldd,
+                                                               float* __restrict__ ffeats, float* __restrict__ coords,
+                                                               const float* __restrict__ coords0, int N, int Sw, float stride,
+                                                               float* __restrict__ out_traj, float* __restrict__ out_vis) {
+    __shared__ __attribute__((aligned(16))) float hs[C][8];      // normalised dfeat, [k][row of the group]
+    __shared__ float vred[4][4];
+    const int pn = blockIdx.x, tid = threadIdx.x;
+    const int b = pn / N, n = pn - b * N;
+    const float* dp = delta + (size_t)pn * ldd;
+    const int o = tid & 127, r0 = (tid >> 7) * 4;
+    const float bo = arena[o_b + o];
+    const float* wt = arena + o_wt + o;
+    const float wv = out_vis != nullptr ? arena[o_wv + o] : 0.f;
+    for (int g0 = 0; g0 < Sw; g0 += 8) {
+        {   // LayerNorm over the 128 delta-feature channels of rows g0 .. g0+7
+            const int row = tid >> 5, l = tid & 31;
+            const bool live = g0 + row < Sw;
+            const float* d = dp + (g0 + (live ? row : 0)) * (C + 2) + 2 + l * 4;
+            float v[4] = {d[0], d[1], d[2], d[3]};
+            float sum = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+            for (int of = 16; of >= 1; of >>= 1) sum += __shfl_xor(sum, of);
+            const float mean = sum * (1.0f / C);
+            float sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = v[k] - mean; sq += t * t; }
+#pragma unroll
+            for (int of = 16; of >= 1; of >>= 1) sq += __shfl_xor(sq, of);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = l * 4 + k;
+                hs[c][row] = live ? (v[k] - mean) * rstd * arena[o_ng + c] + arena[o_nb + c] : 0.f;
+            }
+        }
+        __syncthreads();
+        float acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = bo;
+#pragma unroll 8
+        for (int k = 0; k < C; ++k) {
+            const float w = wt[(size_t)k * C];
+            const float4 h = *reinterpret_cast<const float4*>(&hs[k][r0]);
+            acc[0] = fmaf(h.x, w, acc[0]); acc[1] = fmaf(h.y, w, acc[1]);
+            acc[2] = fmaf(h.z, w, acc[2]); acc[3] = fmaf(h.w, w, acc[3]);
+        }
+        float vis_part[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            vis_part[r] = 0.f;
+            if (g0 + r0 + r < Sw) {
+                float* fp = ffeats + ((size_t)pn * Sw + g0 + r0 + r) * C + o;
+                const float nf = gelu_exact(acc[r]) + *fp;
+                *fp = nf;
+                vis_part[r] = nf * wv;
+            }
+        }
+        if (out_vis != nullptr) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vis_part[r] += __shfl_xor(vis_part[r], off);
+            if ((tid & 63) == 0)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vred[tid >> 6][r] = vis_part[r];
+            __syncthreads();
+            if (tid < 8 && g0 + tid < Sw) {
+                const int grp = tid >> 2, r = tid & 3;                  // rows 0-3: waves 0,1; rows 4-7: waves 2,3
+                out_vis[((size_t)b * Sw + g0 + tid) * N + n] = vred[grp * 2][r] + vred[grp * 2 + 1][r] + arena[o_bv];
+            }
+        }
+        __syncthreads();                     // hs / vred are re-used by the next group
+    }
+    if (tid < Sw) {
+        const int t = tid;
+        const size_t ci = ((size_t)pn * Sw + t) * 2;
+        float cx = coords[ci] + dp[t * (C + 2) + 0];
+        float cy = coords[ci + 1] + dp[t * (C + 2) + 1];
+        if (t == 0) { cx = coords0[ci]; cy = coords0[ci + 1]; }      // lock frame 0 (:535-536)
+        coords[ci] = cx; coords[ci + 1] = cy;
+        float* ot = out_traj + (((size_t)b * Sw + t) * N + n) * 2;
+        ot[0] = cx * stride; ot[1] = cy * stride;                     // :538
+    }
+}
+
 int launch_state_update(const float* arena, const float* delta, float* ffeats, float* coords,
                         const float* coords0, int B, int N, float stride, float* out_traj,
-                        float* out_vis, hipStream_t st) {
+                        float* out_vis, hipStream_t st, int Sw) {
+    if (Sw != PIPS_S) {
+        const ArenaLayout& A = arena_layout(Sw);
+        hipLaunchKernelGGL(state_update_any_kernel, dim3(B * N), dim3(256), 0, st, arena,
+                           A.norm_g, A.norm_b, A.w_upd_t, A.b_upd, A.w_vis, A.b_vis, delta, A.nout_pad, ffeats, coords,
+                           coords0, N, Sw, stride, out_traj, out_vis);
+        PIPS_CHECK_LAUNCH("state_update_any_kernel");
+        return PIPS_OK;
+    }
     const ArenaLayout& A = arena_layout();
     hipLaunchKernelGGL(state_update_kernel, dim3(B * N), dim3(256), 0, st, arena,
                        A.norm_g, A.norm_b, A.w_upd_t, A.b_upd, A.w_vis, A.b_vis, delta, ffeats, coords,

@@ -57,6 +57,7 @@ def skip_scan(vis):
 def track_chained(model, rgbs, xy0, iters=6):
     """rgbs (1,T,3,H,W), xy0 (1,N,2) px at frame 0 -> trajs_e (1,T,N,2) (chain_demo.run_model)."""
     assert rgbs.shape[0] == 1, "the reference chains one video at a time (chain_demo.py:24)"
+    assert model.S == 8, "chain_demo.py's visibility scan (frames 7..2 of an 8-frame window) is written for S = 8"
     dev = rgbs.device
     T, N, S = rgbs.shape[1], xy0.shape[1], 8
     cache = model.encode(rgbs)

@@ -31,34 +31,41 @@ def _f32(t):
 PACK_FP32, PACK_BF16, PACK_SPLIT, PACK_FFN = 1, 2, 4, 8
 
 
-def pack_more(arena, sections):
-    """Build further sections (PACK_BF16 / PACK_SPLIT) of an arena whose fp32 section is already packed."""
+def pack_more(arena, sections, S=8):
+    """Build further sections (PACK_BF16 / PACK_SPLIT) of an arena whose fp32 section is already packed (for window length S)."""
     lib = _lib.load()
     with torch.cuda.device(arena.device):
-        _lib.check(lib.pips_repack_weights_ex(None, 0, _lib.ptr(arena), int(sections) & ~PACK_FP32, _stream()),
-                   "pips_repack_weights_ex")
+        _lib.check(lib.pips_repack_weights_s(None, 0, _lib.ptr(arena), int(S), int(sections) & ~PACK_FP32, _stream()),
+                   "pips_repack_weights_s")
     return arena
 
 
-def pack_weights(state_dict, device, sections=PACK_FP32 | PACK_BF16 | PACK_SPLIT | PACK_FFN) -> torch.Tensor:
-    """state dict (reference key names/layouts) -> packed device arena (pips_repack_weights_ex); ``sections``: which of the
-    fp32 / bf16-copy / split-plane sections to build now (pack_more adds the others later)."""
+def pack_weights(state_dict, device, sections=PACK_FP32 | PACK_BF16 | PACK_SPLIT | PACK_FFN, S=8) -> torch.Tensor:
+    """state dict (reference key names/layouts, of a ``Pips(S=S)``) -> packed device arena (pips_repack_weights_s);
+    ``sections``: which of the fp32 / bf16-copy / split-plane sections to build now (pack_more adds the others later)."""
     lib = _lib.load()
-    names = list(param_table().keys())
+    table = param_table(S)
+    names = list(table.keys())
     missing = [k for k in names if k not in state_dict]
     if missing:
         raise KeyError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+    for k in names:           # the C side sees bare pointers: a checkpoint of another window length must not get that far
+        if tuple(state_dict[k].shape) != tuple(table[k][0]):
+            raise ValueError(f"{k}: shape {tuple(state_dict[k].shape)}, a Pips(S={S}) holds {tuple(table[k][0])}")
+    nbytes = lib.pips_weight_arena_bytes_s(int(S))
+    if nbytes == 0:
+        raise ValueError(f"window length S={S} is outside 1..16")
     with torch.cuda.device(device):
         srcs = [_f32(state_dict[k].detach().to(device)) for k in names]
-        arena = torch.empty(lib.pips_weight_arena_bytes() // 4, dtype=torch.float32, device=device)
+        arena = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
         arr = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
-        _lib.check(lib.pips_repack_weights_ex(arr, len(srcs), _lib.ptr(arena), int(sections) | PACK_FP32, _stream()),
-                   "pips_repack_weights_ex")
+        _lib.check(lib.pips_repack_weights_s(arr, len(srcs), _lib.ptr(arena), int(S), int(sections) | PACK_FP32, _stream()),
+                   "pips_repack_weights_s")
         torch.cuda.current_stream().synchronize()      # srcs may be temporaries
     return arena
 
 
-def times_table(device) -> torch.Tensor:
+def times_table(device, S=8) -> torch.Tensor:
     # torch.linspace(0, S, S) exactly as nets/pips.py:519 builds it
     return torch.linspace(0, S, S, device=device, dtype=torch.float32)
 
@@ -185,13 +192,23 @@ def score_map_terms(pyr, B, H8, W8, ffeats, tgt):
     return out
 
 
-def mixer_fwd(arena, X, bf16=False, split=False, fused=False):
-    """X (M,544) -> delta (M/8, 1040).  bf16: bf16 MFMA operands in the channel-mix/head GEMMs;
+def mixer_fwd(arena, X, bf16=False, split=False, fused=False, S=8):
+    """X (M,544) -> delta (M/S, S*130).  bf16: bf16 MFMA operands in the channel-mix/head GEMMs;
     split: every GEMM on the fp32-grade split-bf16 path; fused (with bf16, M % 64 == 0): each channel-mix FeedForward as
-    one launch (pips_mixer_fwd_bf16_fused; the arena needs its PACK_FFN section)."""
+    one launch (pips_mixer_fwd_bf16_fused; the arena needs its PACK_FFN section).  S != 8 (arena packed for that S):
+    pips_mixer_fwd_s, whose rows are pips_delta_stride(S) apart (cut back to S*130 here)."""
     lib = _lib.load()
     X = _f32(X)
     M = X.shape[0]
+    if S != 8:
+        ld = lib.pips_delta_stride(int(S))
+        delta = torch.empty(M // S, ld, dtype=torch.float32, device=X.device)
+        nb = lib.pips_mixer_workspace_bytes_s(M, int(S))
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
+        with torch.cuda.device(X.device):
+            _lib.check(lib.pips_mixer_fwd_s(_lib.ptr(arena), _lib.ptr(X), M, int(S), 16 if split else (2 if bf16 else 0),
+                                            _lib.ptr(delta), _lib.ptr(ws), nb, _stream()), "pips_mixer_fwd_s")
+        return delta[:, :S * 130]
     delta = torch.empty(M // S, NOUT, dtype=torch.float32, device=X.device)
     nb = lib.pips_mixer_workspace_bytes(M)
     ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)

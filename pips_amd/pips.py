@@ -11,8 +11,9 @@ losses)`` or, with ``return_feat=True``, ``(..., vis_e, ffeat (B,N,128), losses)
 Inference only: ``is_train=True`` raises; a summary writer whose ``save_this`` is set raises
 (the tensorboard drawings of nets/pips.py:477-497,541-557,564-598 need the dense score maps this
 path never stores); ``losses`` carries the reference's ``(seq_loss, vis_loss, ce_loss)`` when ``trajs_g`` is given
-(nets/pips.py:600-606; the score-map loss is reduced on the fly by ``pips_forward_ce``).  ``S`` must be 8 (the HIP
-kernels are specialised for the window every shipped checkpoint and caller uses).  There is no
+(nets/pips.py:600-606; the score-map loss is reduced on the fly by ``pips_forward_ce``).  ``S`` = 8 (the window of every
+shipped checkpoint and caller) runs kernels specialised for it; any other ``1 <= S <= 16`` runs the token mixing, the
+final LayerNorm and the state update on generic HIP kernels (``pips_*_s`` entry points).  There is no
 PyTorch fallback: without the HIP library or a GPU the forward raises.
 
 Weights are repacked for the kernels when a parameter's storage or version counter changes
@@ -53,11 +54,11 @@ class _Node(nn.Module):
 class Pips(nn.Module):
     def __init__(self, S: int = 8, stride: int = 8):
         super().__init__()
-        if S != 8:
-            # the reference builds S-dependent mixer weights (nets/pips.py:295-301); the HIP
-            # kernels are specialised for the S=8 every shipped checkpoint/caller uses
-            raise ValueError("pips_amd.Pips supports S=8 only")
-        self.S = S
+        if not 1 <= int(S) <= 16:
+            # the reference builds S-dependent mixer weights for any S (nets/pips.py:295-301); here S = 8 (every shipped
+            # checkpoint / caller) runs specialised kernels and 1..16 (PIPS_S_MAX) generic ones
+            raise ValueError("pips_amd.Pips supports window lengths S = 1..16")
+        self.S = S = int(S)
         self.stride = stride
         self.hidden_dim = 256
         self.latent_dim = 128
@@ -123,12 +124,12 @@ class Pips(nn.Module):
         live = [d[leaf] for d, leaf in self._plist]
         key = (str(device),) + tuple((id(p), p.data_ptr(), p._version) for p in live)
         if self._arena is None or key != self._arena_key:
-            self._arena = ops.pack_weights(dict(zip(self._names, live)), device, sections=need)
+            self._arena = ops.pack_weights(dict(zip(self._names, live)), device, sections=need, S=self.S)
             self._arena_key = key
             self._arena_sections = need | ops.PACK_FP32
             self._arena_params = live          # keeps the ids in the key from being recycled
         elif need & ~self._arena_sections:
-            ops.pack_more(self._arena, need & ~self._arena_sections)
+            ops.pack_more(self._arena, need & ~self._arena_sections, S=self.S)
             self._arena_sections |= need
         return self._arena
 
@@ -189,7 +190,7 @@ class Pips(nn.Module):
         with torch.cuda.device(dev):
             arena = self._packed(dev)
             if self._times is None or self._times.device != dev:
-                self._times = ops.times_table(dev)
+                self._times = ops.times_table(dev, self.S)
             ws = self._workspace(lib, (B, S, H, W, N, int(self.stride)), dev)
             trajs = torch.empty(iters + 1, B, S, N, 2, dtype=f32, device=dev)
             vis_e = torch.empty(B, S, N, dtype=f32, device=dev)
@@ -277,8 +278,8 @@ class Pips(nn.Module):
         with torch.cuda.device(dev):
             arena = self._packed(dev)
             if self._times is None or self._times.device != dev:
-                self._times = ops.times_table(dev)
-            nb = lib.pips_track_workspace_bytes(B, N)
+                self._times = ops.times_table(dev, self.S)
+            nb = lib.pips_track_workspace_bytes_s(B, N, S)
             # ONE tracker workspace per device, grown on demand: chained tracking calls this with
             # a different (shrinking) N at every hop
             key = ("track", str(dev))
@@ -288,11 +289,11 @@ class Pips(nn.Module):
             trajs = torch.empty(iters + 1, B, S, N, 2, dtype=f32, device=dev)
             vis_e = torch.empty(B, S, N, dtype=f32, device=dev)
             ffeat = torch.empty(B, N, self.latent_dim, dtype=f32, device=dev)
-            rc = lib.pips_track(_lib.ptr(arena), _lib.ptr(cache.pyr), B, cache.T, H8, W8, _lib.ptr(xys_c), _lib.ptr(ci),
-                                _lib.ptr(fi), _lib.ptr(ws_i), _lib.ptr(self._times), N, int(cache.stride), int(iters),
-                                self._flags(), _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
-                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
-            _lib.check(rc, "pips_track")
+            rc = lib.pips_track_s(_lib.ptr(arena), _lib.ptr(cache.pyr), B, cache.T, H8, W8, _lib.ptr(xys_c), _lib.ptr(ci),
+                                  _lib.ptr(fi), _lib.ptr(ws_i), _lib.ptr(self._times), N, int(cache.stride), int(iters),
+                                  self._flags(), S, _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e),
+                                  _lib.ptr(ffeat), None, None, None, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(rc, "pips_track_s")
         preds = [trajs[i + 1] for i in range(iters)]
         preds2 = [trajs[0], trajs[0]] + preds + [trajs[iters], trajs[iters]]
         if return_feat:

@@ -22,9 +22,18 @@ CASES = {
     "demo_half_s4_i2": dict(B=1, N=16, H=180, W=320, stride=4, iters=2, tamed=True, border=False, demo=True),
 }
 
+# Pips(S != 8): the reference sizes the token-mixing weights and the head by S (nets/pips.py:295-301, 401-402).  An odd S
+# (head rows 650 = not a multiple of 4), one beyond 8 (two row groups in the state update) and a short one at stride 4.
+WINDOW_CASES = {
+    "w5_tamed_i3": dict(S=5, B=1, N=6, H=128, W=160, stride=8, iters=3, tamed=True, border=False),
+    "w12_tamed_i2": dict(S=12, B=1, N=5, H=128, W=160, stride=8, iters=2, tamed=True, border=False),
+    "w4_raw_s4_i2": dict(S=4, B=2, N=7, H=96, W=128, stride=4, iters=2, tamed=False, border=True),
+}
+
 
 def make_inputs(case: dict, seed: int = 1, S: int = 8):
-    """(xys, rgbs, coords_init, feat_init) on CPU, fp32."""
+    """(xys, rgbs, coords_init, feat_init) on CPU, fp32.  The window length is case["S"] when the case names one."""
+    S = case.get("S", S)
     B, N, H, W = case["B"], case["N"], case["H"], case["W"]
     g = torch.Generator().manual_seed(seed)
     if case.get("demo"):
@@ -53,6 +62,7 @@ def make_inputs(case: dict, seed: int = 1, S: int = 8):
 
 def make_targets(case: dict, seed: int = 7, S: int = 8):
     """Ground-truth-like targets for the losses of nets/pips.py:600-606: (trajs_g (B,S,N,2) px, vis_g, valids (B,S,N))."""
+    S = case.get("S", S)
     B, N = case["B"], case["N"]
     xys = make_inputs(case)[0]
     g = torch.Generator().manual_seed(seed)

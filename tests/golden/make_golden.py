@@ -1,6 +1,6 @@
 """Generate the golden vectors by running the UNMODIFIED reference (build container only).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py              (--windows: only the Pips(S != 8) cases)
 
 For every case of cases.py: load seeded weights into /root/reference/nets/pips.py's Pips,
 run forward on the seeded inputs, store coord_predictions / vis_e / ffeat as float32 in
@@ -35,40 +35,55 @@ def make_demo_frames():
     np.savez_compressed(os.path.join(HERE, "demo_half_frames.npz"), frames=np.stack(frames).astype(np.uint8))
 
 
+def run_case(name, case):
+    """one forward of the unmodified reference -> tests/golden/<name>.npz; returns the reference module"""
+    S = case.get("S", 8)
+    sd = init_state_dict(0, S=S, tamed=case["tamed"])
+    xys, rgbs, ci, fi = G.make_inputs(case)
+    ref = R.load_reference_pips(sd, stride=case["stride"], S=S)
+    with torch.no_grad():
+        preds, preds2, vis, ffeat, losses = ref(xys, rgbs, coords_init=ci, feat_init=fi, iters=case["iters"],
+                                                return_feat=True)
+    assert losses is None and len(preds2) == case["iters"] + 4
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        trajs=torch.stack(preds).numpy().astype(np.float32),
+                        traj0=preds2[0].numpy().astype(np.float32),
+                        vis=vis.numpy().astype(np.float32),
+                        ffeat=ffeat.numpy().astype(np.float32))
+    print(name, "trajs", tuple(torch.stack(preds).shape), "max|disp| px",
+          float((preds[-1] - preds2[0]).abs().max()))
+    return ref
+
+
 def main():
     assert R.available(), "reference not mounted at /root/reference"
     make_demo_frames()
     keys = None
     for name, case in G.CASES.items():
-        sd = init_state_dict(0, tamed=case["tamed"])
-        xys, rgbs, ci, fi = G.make_inputs(case)
-        ref = R.load_reference_pips(sd, stride=case["stride"])
+        ref = run_case(name, case)
         if keys is None:
             keys = {k: list(v.shape) for k, v in ref.state_dict().items()}
-        with torch.no_grad():
-            preds, preds2, vis, ffeat, losses = ref(xys, rgbs, coords_init=ci, feat_init=fi, iters=case["iters"],
-                                                    return_feat=True)
-        assert losses is None and len(preds2) == case["iters"] + 4
-        np.savez_compressed(os.path.join(HERE, name + ".npz"),
-                            trajs=torch.stack(preds).numpy().astype(np.float32),
-                            traj0=preds2[0].numpy().astype(np.float32),
-                            vis=vis.numpy().astype(np.float32),
-                            ffeat=ffeat.numpy().astype(np.float32))
-        print(name, "trajs", tuple(torch.stack(preds).shape), "max|disp| px",
-              float((preds[-1] - preds2[0]).abs().max()))
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(keys, f, indent=0)
+
+
+def main_windows():
+    """Pips(S != 8) cases (cases.WINDOW_CASES)"""
+    assert R.available(), "reference not mounted at /root/reference"
+    for name, case in G.WINDOW_CASES.items():
+        run_case(name, case)
 
 
 def main_losses(name="s8_raw_i3"):
     """(seq_loss, vis_loss, ce_loss) of the reference forward called with trajs_g / vis_g / valids
     (nets/pips.py:600-606, the way test_on_flt.py:87 calls it) -> <case>_losses.npz."""
     assert R.available(), "reference not mounted at /root/reference"
-    case = G.CASES[name]
-    sd = init_state_dict(0, tamed=case["tamed"])
+    case = G.CASES[name] if name in G.CASES else G.WINDOW_CASES[name]
+    S = case.get("S", 8)
+    sd = init_state_dict(0, S=S, tamed=case["tamed"])
     xys, rgbs, ci, fi = G.make_inputs(case)
     trajs_g, vis_g, valids = G.make_targets(case)
-    ref = R.load_reference_pips(sd, stride=case["stride"])
+    ref = R.load_reference_pips(sd, stride=case["stride"], S=S)
     with torch.no_grad():
         out = ref(xys, rgbs, coords_init=ci, feat_init=fi, iters=case["iters"], trajs_g=trajs_g, vis_g=vis_g, valids=valids)
     seq, vis, ce = out[3]
@@ -78,7 +93,13 @@ def main_losses(name="s8_raw_i3"):
 
 
 if __name__ == "__main__":
+    if "--windows" in sys.argv:              # only the Pips(S != 8) fixtures
+        main_windows()
+        main_losses("w5_tamed_i3")
+        sys.exit(0)
     if "--losses" not in sys.argv:
         main()
+        main_windows()
     main_losses("s8_raw_i3")
     main_losses("s8_tamed_i6")
+    main_losses("w5_tamed_i3")

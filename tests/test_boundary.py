@@ -49,7 +49,13 @@ def test_library_exports_every_declared_symbol():
     assert lib.pips_weight_arena_bytes() > 28677713 * 4
     # sizing queries are pure host functions
     assert lib.pips_workspace_bytes(1, 8, 368, 496, 256, 8) > 0
-    assert lib.pips_workspace_bytes(1, 7, 368, 496, 256, 8) == 0          # S is fixed to 8
+    assert lib.pips_workspace_bytes(1, 7, 368, 496, 256, 8) > 0           # any window length 1..PIPS_S_MAX
+    assert lib.pips_workspace_bytes(1, 17, 368, 496, 256, 8) == 0 and lib.pips_weight_arena_bytes_s(17) == 0
+    assert lib.pips_weight_arena_bytes_s(8) == lib.pips_weight_arena_bytes()
+    assert lib.pips_weight_arena_bytes_s(5) < lib.pips_weight_arena_bytes() < lib.pips_weight_arena_bytes_s(12)
+    assert lib.pips_delta_stride(8) == 1040 and lib.pips_delta_stride(5) == 652 and lib.pips_delta_stride(0) == 0
+    assert lib.pips_track_workspace_bytes_s(2, 64, 8) == lib.pips_track_workspace_bytes(2, 64)
+    assert lib.pips_mixer_workspace_bytes_s(1024, 8) == lib.pips_mixer_workspace_bytes(1024)
     assert lib.pips_pyramid_offset(8, 368, 496, 8, 1) == 8 * 46 * 62 * 128
     assert lib.pips_pyramid_floats(8, 368, 496, 8) >= 8 * 128 * (46 * 62 + 23 * 31 + 11 * 15 + 5 * 7)
 
@@ -133,7 +139,7 @@ def test_packed_weights_follow_parameter_changes():
     import pips_amd.ops as ops
     packed = []
     orig = ops.pack_weights
-    ops.pack_weights = lambda sd, dev, sections=7: packed.append({k: v for k, v in sd.items()}) or object()
+    ops.pack_weights = lambda sd, dev, sections=7, S=8: packed.append({k: v for k, v in sd.items()}) or object()
     try:
         m._packed("cpu")
         m._packed("cpu")

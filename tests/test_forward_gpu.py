@@ -25,9 +25,9 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MATMUL = ["exact", "split"]      # fp32 MFMA / fp32-grade split-bf16 matrix path: one set of tolerances
 
 
-def _model(sd, stride, matmul="exact"):
+def _model(sd, stride, matmul="exact", S=8):
     from pips_amd import Pips
-    m = Pips(S=8, stride=stride)
+    m = Pips(S=S, stride=stride)
     missing = m.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     m.matmul = matmul
@@ -63,6 +63,59 @@ def test_golden_reference_outputs(name, matmul, weights_raw, weights_tamed):
         assert err[0] < TOL_PX, err              # first iterate: the reference's own noise floor is 6.6e-5 px
         if len(err) > 1:
             assert err[1] < 5e-2, err            # second: floor 1.8e-3 px (chaotic regime beyond)
+
+
+@pytest.mark.parametrize("matmul", MATMUL)
+@pytest.mark.parametrize("name", list(G.WINDOW_CASES))
+def test_golden_reference_outputs_window_lengths(name, matmul):
+    """Pips(S != 8) (nets/pips.py:295-301, 401-402) against vectors of the unmodified reference built with the same S: odd S
+    (padded head rows), S > 8 (two row groups in the state update), S = 4 at stride 4 with border queries."""
+    from pips_amd.weights import init_state_dict
+    case = G.WINDOW_CASES[name]
+    S = case["S"]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    sd = init_state_dict(0, S=S, tamed=case["tamed"])
+    xys, rgbs, ci, fi = G.make_inputs(case)
+    preds, preds2, vis, ffeat, losses = _run(_model(sd, case["stride"], matmul, S=S), xys, rgbs, ci, fi, case["iters"])
+    trajs = torch.stack(preds).cpu().numpy()
+    assert trajs.shape == gold["trajs"].shape and trajs.shape[2] == S and tuple(vis.shape) == (case["B"], S, case["N"])
+    err = np.abs(trajs - gold["trajs"]).reshape(case["iters"], -1).max(axis=1)
+    print(name, matmul, "per-iteration max |dtraj| px:", err)
+    assert np.abs(preds2[0].cpu().numpy() - gold["traj0"]).max() < 1e-5
+    assert np.abs(ffeat.cpu().numpy() - gold["ffeat"]).max() < 2e-4
+    if case["tamed"]:
+        assert err.max() < TOL_PX, err
+        assert np.abs(vis.cpu().numpy() - gold["vis"]).max() < TOL_PX
+    else:
+        assert err[0] < TOL_PX, err
+        assert err[1] < 5e-2, err
+
+
+def test_window_length_other_modes_and_split_api():
+    """S = 5: the bf16-operand modes run on the same generic kernels (2e-2 px against the fp32 result, the config-3 gate);
+    encode + track on the cache equals the one-call forward; the losses match the reference's."""
+    from pips_amd.weights import init_state_dict
+    case = G.WINDOW_CASES["w5_tamed_i3"]
+    S = case["S"]
+    sd = init_state_dict(0, S=S, tamed=True)
+    xys, rgbs, _, _ = G.make_inputs(case)
+    m = _model(sd, 8, S=S)
+    ref = _run(m, xys, rgbs, iters=3)
+    cache = m.encode(rgbs.to(DEV))
+    tr = m.track(cache, xys.to(DEV), iters=3, return_feat=True)
+    assert torch.equal(tr[0][-1], ref[0][-1]) and torch.equal(tr[2], ref[2])
+    m.mixer_dtype = m.encoder_dtype = torch.bfloat16
+    lo = _run(m, xys, rgbs, iters=3)
+    d = float((lo[0][-1] - ref[0][-1]).abs().max())
+    print("S=5 bf16 operands vs fp32: %.2e px" % d)
+    assert 0 < d < 2e-2
+    m.mixer_dtype = m.encoder_dtype = torch.float32
+    gold = np.load(os.path.join(GOLD, "w5_tamed_i3_losses.npz"))
+    trajs_g, vis_g, valids = G.make_targets(case)
+    out = m(xys.to(DEV), rgbs.to(DEV), iters=3, trajs_g=trajs_g.to(DEV), vis_g=vis_g.to(DEV), valids=valids.to(DEV))
+    seq, visl, ce = out[3]
+    for got, key in ((seq, "seq_loss"), (visl, "vis_loss"), (ce, "ce_loss")):
+        assert abs(float(got) - float(gold[key])) <= 2e-4 * max(1.0, abs(float(gold[key]))), (key, float(got), float(gold[key]))
 
 
 @pytest.mark.parametrize("matmul", MATMUL)
@@ -219,7 +272,7 @@ def test_errors_and_signature(weights_tamed):
     with pytest.raises(NotImplementedError):
         m(xys.to(DEV), rgbs.to(DEV), iters=1, is_train=True)
     with pytest.raises(ValueError):
-        Pips(S=4)
+        Pips(S=17)                                               # window lengths 1..16 (PIPS_S_MAX)
     # trajs_g given (test_on_flt.py:87): losses tuple is produced, outputs unchanged
     tg = torch.zeros(1, 8, 4, 2, device=DEV)
     ones = torch.ones(1, 8, 4, device=DEV)

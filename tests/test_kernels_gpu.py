@@ -515,6 +515,31 @@ def test_mixer_bf16_operands(P, weights_raw, arenas):
     assert 1e-5 < e_bf16 < 3e-2          # bf16 operand rounding (2^-9 per product) through 25 GEMMs
 
 
+@pytest.mark.parametrize("S,P", [(1, 5), (3, 64), (5, 33), (12, 40), (16, 7)])
+def test_mixer_any_window_length(S, P):
+    """pips_mixer_fwd_s: MLPMixer of a Pips(S != 8) (nets/pips.py:93-123 with S tokens) against the oracle -- token MLP S -> 4S -> S,
+    head S*130 (zero-padded to a multiple of 4 rows in the arena), exact and split matrix modes."""
+    from pips_amd import ops
+    from pips_amd.weights import init_state_dict
+    O = _oracle()
+    sd = init_state_dict(0, S=S, tamed=False)
+    arena = ops.pack_weights(sd, torch.device(DEV), S=S)
+    g = torch.Generator().manual_seed(100 * S + P)
+    x = torch.randn(P, S, 519, generator=g)
+    ref = O.mixer(sd, x)
+    assert tuple(ref.shape) == (P, S * 130)
+    X = torch.zeros(P * S, 544)
+    X[:, :519] = x.reshape(P * S, 519)
+    scale = max(1.0, float(ref.abs().max()))
+    for split in (False, True):
+        out = ops.mixer_fwd(arena, X.to(DEV), split=split, S=S).cpu()
+        e = float((out - ref).abs().max()) / scale
+        print(f"S={S} P={P} split={split}: rel err {e:.2e}")
+        assert tuple(out.shape) == (P, S * 130) and e < 1e-4
+    lo = ops.mixer_fwd(arena, X.to(DEV), bf16=True, S=S).cpu()
+    assert 1e-6 < float((lo - ref).abs().max()) / scale < 3e-2
+
+
 @pytest.mark.parametrize("P", [8, 256, 2048])
 def test_mixer_bf16_fused_feedforward_route(P, weights_raw, arenas):
     """pips_mixer_fwd_bf16_fused (one launch per channel-mix FeedForward, ffn_fused.hip) against the two-GEMM bf16 route: the

@@ -34,6 +34,24 @@ def test_oracle_matches_golden(name, weights_raw, weights_tamed):
     assert np.abs(preds2[0].numpy() - gold["traj0"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("name", list(G.WINDOW_CASES))
+def test_oracle_matches_golden_window_lengths(name):
+    """Pips(S != 8): the reference sizes the token-mixing weights and the head by S (nets/pips.py:295-301)."""
+    from pips_amd.weights import init_state_dict
+    case = G.WINDOW_CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    sd = init_state_dict(0, S=case["S"], tamed=case["tamed"])
+    xys, rgbs, ci, fi = G.make_inputs(case)
+    assert rgbs.shape[1] == case["S"]
+    preds, preds2, vis, ffeat = O.forward(sd, xys, rgbs, iters=case["iters"], stride=case["stride"])
+    err = np.abs(torch.stack(preds).numpy() - gold["trajs"]).reshape(case["iters"], -1).max(axis=1)
+    assert gold["trajs"].shape[2] == case["S"] and err[0] < 1e-3
+    if case["tamed"]:
+        assert err.max() < 1e-3
+        assert np.abs(vis.numpy() - gold["vis"]).max() < 1e-3
+    assert np.abs(ffeat.numpy() - gold["ffeat"]).max() < 1e-4
+
+
 @pytest.mark.skipif(not R.available(), reason="reference not mounted (GPU box)")
 def test_oracle_equals_live_reference(weights_raw):
     case = dict(B=1, N=9, H=128, W=160, stride=8)
