@@ -84,6 +84,38 @@ def test_config4_teacher_forced_iteration(weights_raw):
     assert float((ffeat.cpu()[:, sub] - ref_ff).abs().max()) < 2e-4
 
 
+def test_config4_end_to_end_b4_i6_against_oracle_on_device(weights_tamed):
+    """BASELINE configs[3] whole, the geometry bench.py's config4 leg times: B=4 clips of 8 x 720x1280 frames, the 64x64 query
+    grid (N=4096), I=6 -- every one of the 131 072 tracks through the product path (encoder -> tiled gather -> mixer -> update)
+    against the oracle run on the SAME GPU with torch-ROCm fp32 ops (MIOpen convolutions, rocBLAS matmuls, the dense correlation
+    volumes materialised: 7.5 GB at level 0).  The oracle is the checker here, not the product; tamed weights, whose own fp32
+    noise floor over six iterations is 8e-5 px (tests/test_forward_gpu.py docstring), gate 1e-3 px."""
+    from pips_amd import Pips
+    from oracle import pips_oracle as O
+    B, H, W, N = 4, 720, 1280, 4096
+    g = torch.Generator().manual_seed(5)
+    rgbs = torch.randint(0, 256, (B, 8, 3, H, W), generator=g).float().to(DEV)
+    xys = (_grid(N, H, W).unsqueeze(0).repeat(B, 1, 1) + torch.rand(B, N, 2, generator=g) * 4.0).to(DEV)
+    sd = {k: v.to(DEV) for k, v in weights_tamed.items()}
+    with torch.no_grad():
+        ref_p, _, ref_vis, ref_ff = O.forward(sd, xys, rgbs, iters=6, stride=8)
+    ref_p = [p.cpu() for p in ref_p]
+    ref_vis, ref_ff = ref_vis.cpu(), ref_ff.cpu()
+    del sd
+    torch.cuda.empty_cache()
+    m = Pips(stride=8)
+    m.load_state_dict(weights_tamed)
+    m = m.to(DEV).eval()
+    preds, _, vis, ffeat, _ = m(xys, rgbs, iters=6, return_feat=True)
+    err = [float((p.cpu() - r).abs().max()) for p, r in zip(preds, ref_p)]
+    verr = float((vis.cpu() - ref_vis).abs().max())
+    moved = float((ref_p[-1] - xys.cpu().unsqueeze(1)).abs().max())
+    print(f"config 4 end to end (B=4, N=4096, I=6): per-iteration max |dtraj| px {['%.1e' % e for e in err]}, |dvis| {verr:.1e}, "
+          f"tracks move up to {moved:.2f} px")
+    assert max(err) < 1e-3 and verr < 1e-3
+    assert float((ffeat.cpu() - ref_ff).abs().max()) < 2e-4
+
+
 def test_config5_chained_tracking_stride4(weights_tamed):
     """chain_demo.py geometry: 360x640 frames, stride 4, S=8 windows chained on visibility over T=24 frames, N=64
     particles, against the loop restatement (frame maps cached in the oracle too: oracle/chain_oracle.py)."""
