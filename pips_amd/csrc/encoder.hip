@@ -157,8 +157,58 @@ int launch_stem(const void* rgbs, int rgb_u8, const float* w, const float* bias,
 // kernel) -> mean_rstd [F][C][2].  All partials of a channel are re-based in fp64 on ONE reference r (the first partial's
 // pivot, a value of the data): with d = p - r,  sum(x-r) = sum_t [s_t + n_t d_t],  sum(x-r)^2 = sum_t [q_t + 2 d_t s_t +
 // n_t d_t^2];  mean = r + S1/N,  var = S2/N - (S1/N)^2 -- one pass, and what cancellation is left happens in fp64 about
-// a value within the data's range.  Block = (frame, 16 channels) x 64 partial subsets.
-__global__ __launch_bounds__(1024) void inorm_finalize_pivot_kernel(const float4* __restrict__ partial, int parts, int C,
+// a value within the data's range.
+// Block = (frame, 4 channels) x SUBS partial subsets: F x C/4 blocks instead of F x C/16, eight loads per thread in flight at
+// once -- the kernel is one memory round trip plus the launch (round 3; the (frame, 16 channels) x 64 subsets form took 6.2 us
+// per launch at 8 frames, 21 launches per forward: 131 -> 107 us per forward).  Taken up to 16 frames.
+template <int SUBS>
+__global__ __launch_bounds__(4 * SUBS) void inorm_finalize_pivot_kernel(const float4* __restrict__ partial, int parts, int C,
+                                                                        float* __restrict__ mean_rstd) {
+    constexpr int NW = 4 * SUBS / 64;
+    __shared__ double red[3][NW][4];                   // per wave and channel
+    const int f = blockIdx.x, cl = threadIdx.x & 3, c = blockIdx.y * 4 + cl, sub = threadIdx.x >> 2;
+    const float4* p = partial + (size_t)f * parts * C + c;
+    const double r = (double)p[0].z;
+    double n = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int t0 = sub; t0 < parts; t0 += 8 * SUBS) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + SUBS * u;
+            v[u] = t < parts ? p[(size_t)t * C] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u].w > 0.f) {
+                const double nt = v[u].w, d = (double)v[u].z - r;
+                n += nt;
+                s1 += (double)v[u].x + nt * d;
+                s2 += (double)v[u].y + d * (2.0 * (double)v[u].x + nt * d);
+            }
+    }
+    // lanes of a wave: 16 subsets x 4 channels; fold the subsets (lane bits 2..5), then the waves through LDS
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+        n += __shfl_xor(n, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 4) { red[0][wave][cl] = n; red[1][wave][cl] = s1; red[2][wave][cl] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        n = 0.0; s1 = 0.0; s2 = 0.0;
+        for (int i = 0; i < NW; ++i) { n += red[0][i][cl]; s1 += red[1][i][cl]; s2 += red[2][i][cl]; }
+        const double m1 = n > 0.0 ? s1 / n : 0.0;
+        double var = n > 0.0 ? s2 / n - m1 * m1 : 0.0;
+        if (var < 0.0) var = 0.0;
+        mean_rstd[((size_t)f * C + c) * 2 + 0] = (float)(r + m1);
+        mean_rstd[((size_t)f * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+// Many frames (BASELINE configs[2]: 64): block = (frame, 16 channels) x 64 partial subsets, four loads in flight per thread -- with
+// 64 frames there are enough blocks, and the small-block form above costs more in block launches than it saves (222 against 198 us
+// over the 21 layers of a forward).
+__global__ __launch_bounds__(1024) void inorm_finalize_pivot16_kernel(const float4* __restrict__ partial, int parts, int C,
                                                                     float* __restrict__ mean_rstd) {
     __shared__ double red[3][64][16];
     const int f = blockIdx.x, cl = threadIdx.x & 15, c = blockIdx.y * 16 + cl, sub = threadIdx.x >> 4;
@@ -196,8 +246,12 @@ __global__ __launch_bounds__(1024) void inorm_finalize_pivot_kernel(const float4
 
 int launch_inorm_finalize_pivot(const float* partial, int F, int parts, int C, float* mean_rstd, hipStream_t st) {
     PIPS_CHECK_ARG(C % 16 == 0, "inorm_finalize: C=%d must be a multiple of 16", C);
-    hipLaunchKernelGGL(inorm_finalize_pivot_kernel, dim3(F, C / 16), dim3(1024), 0, st, reinterpret_cast<const float4*>(partial),
-                       parts, C, mean_rstd);
+    if (F <= 16)
+        hipLaunchKernelGGL(inorm_finalize_pivot_kernel<256>, dim3(F, C / 4), dim3(1024), 0, st, reinterpret_cast<const float4*>(partial),
+                           parts, C, mean_rstd);
+    else
+        hipLaunchKernelGGL(inorm_finalize_pivot16_kernel, dim3(F, C / 16), dim3(1024), 0, st, reinterpret_cast<const float4*>(partial),
+                           parts, C, mean_rstd);
     PIPS_CHECK_LAUNCH("inorm_finalize_pivot_kernel");
     return PIPS_OK;
 }

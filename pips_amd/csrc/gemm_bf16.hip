@@ -398,6 +398,10 @@ int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st
     const long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.N, bn) * frames;
     const int bm = blocks128 >= 512 ? 128 : 64;
     if (tiles_m) *tiles_m = cdiv(a.M, bm) * 2;       // partials per frame: m tiles x wave rows (WGM = 2)
+    // Cout = 256 (conv2, 416 -> 256): one 256-wide tile per 128 rows -- every A element is fetched once per tap instead of twice
+    if (bm == 128 && a.N % 256 == 0 && !k64 && PIPS_TUNE("PIPS_CONV_BN256", 1) &&
+        (long)cdiv(a.M, 128) * (a.N / 256) * frames >= 512)
+        return launch_conv_tile<128, 256, 32>(a, frames, st, types);
     if (bm == 128) {
         if (bn == 128) return k64 ? launch_conv_tile<128, 128, 64>(a, frames, st, types) : launch_conv_tile<128, 128, 32>(a, frames, st, types);
         return k64 ? launch_conv_tile<128, 64, 64>(a, frames, st, types) : launch_conv_tile<128, 64, 32>(a, frames, st, types);

@@ -201,6 +201,8 @@ def test_conv_nhwc_bf16(F_, H, W, Cin, Cout):
     (8, 93, 125, 64, 96, 3, 2, False, True),     # stride 2, odd size
     (8, 92, 124, 64, 96, 1, 2, False, True),     # the 1x1 stride-2 shortcut
     (8, 46, 62, 256, 128, 1, 1, False, False),   # conv3: bf16 map in, fp32 pyramid out
+    (24, 46, 62, 416, 256, 3, 1, False, True),   # conv2 with enough frames for the 128 x 256 tile (ragged last row tile)
+    (4, 46, 62, 416, 256, 3, 1, False, True),    # conv2 below that: 128-wide tiles
 ])
 def test_conv_nhwc_bf16_maps(F_, H, W, Cin, Cout, k, s, norm, out_bf16):
     """Convolutions of the bf16 encoder mode: bf16 map in (optionally normalised + ReLU'd while staged), bf16 or fp32 map out,
