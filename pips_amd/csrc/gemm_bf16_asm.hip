@@ -284,6 +284,82 @@ __global__ __launch_bounds__(512) void gemm_bf16_res_asm_kernel(GemmArgs p, int 
                  : PIPS_TILE_RES_CLOBBER);
 }
 
+#ifdef PIPS_TUNING        // an experiment kept for the tuning build (PIPS_BF16_RES4=1): measured 49.6 against 46.9 us, DESIGN.md 4b
+// The same tile on FOUR waves, one per SIMD (PIPS_TILE_TEXT_RES4): wave tile 128 x 64 -- 6 fragment reads per 8 MFMAs instead of
+// 4 per 4, no SIMD partner to wait for at the barrier -- and a ring of three 64-K stages with 128-byte LDS rows: a DMA instruction
+// brings 8 rows x 128 B = eight full cache lines (the 32-K stages above: 16 rows x 64 B; the K loop's time is the number of
+// vector-memory instructions x ~52 clocks, i.e. the texture addresser's rate per row segment -- see the generator).  LDS image of a
+// stage: rows 0..255 = A, 256..383 = W, 128 bytes each, physical 16-byte slot = slot ^ ((row >> 1) & 7), applied on the global
+// side (lane -> row lane >> 3 of the piece, physical slot lane & 7).  Wave w brings A pieces 8w..8w+7 and W pieces 4w..4w+3.
+__global__ __launch_bounds__(256) void gemm_bf16_res4_asm_kernel(GemmArgs p, int tiles_m, int ntiles) {
+    constexpr int BM = 256, BN = 128, WGN = 2;
+    constexpr int ROWB = 128, SUP = (BM + BN) * ROWB, NSUP = 3, NA = 8, NW = 4, NP = NA + NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+    const char* Abase = sgpr(reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2);
+    const char* Wbase = sgpr(reinterpret_cast<const char*>(p.W) + (size_t)n0 * p.K * 2);
+
+    unsigned rowoff[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const bool is_a = q < NA;
+        const int row = (is_a ? (wave * NA + q) : (wave * NW + q - NA)) * 8 + (lane >> 3);     // row of the A tile / of the W tile
+        const int lrow = is_a ? row : BM + row;                                                 // row of the LDS image
+        const int slot = (lane & 7) ^ ((lrow >> 1) & 7);
+        rowoff[q] = (unsigned)row * (unsigned)(is_a ? p.lda : p.K) * 2u + slot * 16;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned wvoffa = wave * (NA * 1024), wvoffw = BM * ROWB + wave * (NW * 1024), ringend = lds0 + NSUP * SUP;
+    // prologue: stages 0 and 1 in full, the first six pieces of stage 2 (the statement issues the rest)
+#pragma unroll
+    for (int X = 0; X < 3; ++X)
+#pragma unroll
+        for (int q = 0; q < (X < 2 ? NP : 6); ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)((q < NA ? Abase : Wbase) + rowoff[q] + X * 128),
+                                             (lptr_t)(smem + X * SUP + (q < NA ? wvoffa + q * 1024 : wvoffw + (q - NA) * 1024)), 16, 0, 0);
+
+    const unsigned a_off = (wm * 128 + l31) * ROWB + ((half ^ ((l31 >> 1) & 7)) * 16);
+    unsigned b_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int brow = BM + wn * 64 + j * 32 + l31;
+        b_off[j] = brow * ROWB + ((half ^ ((brow >> 1) & 7)) * 16);
+    }
+    const unsigned boff = 4 * half * 4;
+    const unsigned roff = (unsigned)(((size_t)l31 * p.ldr + 4 * half) * 4), soff = (unsigned)(((size_t)l31 * p.ldc + 4 * half) * 4);
+    const float* bias = p.bias + n0 + wn * 64;
+    const char* rb[4];
+    const char* cb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rb[i] = reinterpret_cast<const char*>(p.R) + ((size_t)(m0 + wm * 128 + i * 32) * p.ldr + n0 + wn * 64) * 4;
+        cb[i] = reinterpret_cast<const char*>(p.C) + ((size_t)(m0 + wm * 128 + i * 32) * p.ldc + n0 + wn * 64) * 4;
+    }
+    const int nks = p.K / 64;
+#define PIPS_LO(ptr) sgpr((unsigned)(unsigned long long)reinterpret_cast<uintptr_t>(ptr))
+#define PIPS_HI(ptr) sgpr((unsigned)((unsigned long long)reinterpret_cast<uintptr_t>(ptr) >> 32))
+    asm volatile(PIPS_TILE_TEXT_RES4
+                 :
+                 : [ro0] "v"(rowoff[0]), [ro1] "v"(rowoff[1]), [ro2] "v"(rowoff[2]), [ro3] "v"(rowoff[3]), [ro4] "v"(rowoff[4]),
+                   [ro5] "v"(rowoff[5]), [ro6] "v"(rowoff[6]), [ro7] "v"(rowoff[7]), [ro8] "v"(rowoff[8]), [ro9] "v"(rowoff[9]),
+                   [ro10] "v"(rowoff[10]), [ro11] "v"(rowoff[11]), [aoff] "v"(a_off), [b0off] "v"(b_off[0]), [b1off] "v"(b_off[1]),
+                   [roff] "v"(roff), [soff] "v"(soff), [boff] "v"(boff), [rd] "s"(sgpr(lds0)), [ringend] "s"(sgpr(ringend)),
+                   [lds0] "s"(sgpr(lds0)), [wvoffa] "s"(sgpr(wvoffa)), [wvoffw] "s"(sgpr(wvoffw)), [nks] "s"(sgpr((unsigned)nks)),
+                   [cqa] "s"(PIPS_LO(Abase)), [cqah] "s"(PIPS_HI(Abase)), [cqw] "s"(PIPS_LO(Wbase)), [cqwh] "s"(PIPS_HI(Wbase)),
+                   [bias] "s"(sgpr(bias)), [rb0] "s"(sgpr(rb[0])), [rb1] "s"(sgpr(rb[1])), [rb2] "s"(sgpr(rb[2])), [rb3] "s"(sgpr(rb[3])),
+                   [cb0] "s"(sgpr(cb[0])), [cb1] "s"(sgpr(cb[1])), [cb2] "s"(sgpr(cb[2])), [cb3] "s"(sgpr(cb[3]))
+                 : PIPS_TILE_RES4_CLOBBER);
+#undef PIPS_LO
+#undef PIPS_HI
+}
+#endif
+
 // Which kernel a bf16-operand GEMM goes to: 0 = the register-staged gemm_bf16_kernel, 1 = gemm_bf16_res_asm_kernel
 // (down-projection + residual), 2 = gemm_bf16_gelu_asm_kernel (up-projection + GELU).  Pure function of the problem --
 // also behind pips_gemm_bf16_route(), which lets a test assert that a forward's geometry reaches the assembly kernels.
@@ -305,6 +381,16 @@ int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_
     if (route == 0) return 1;
     const int tiles_m = a.M / 256, ntiles = tiles_m * (a.N / 128);
     const size_t ring = (size_t)6 * (256 + 128) * 64;
+#ifdef PIPS_TUNING
+    if (route == 1 && PIPS_TUNE("PIPS_BF16_RES4", 0)) {
+        static std::atomic<unsigned long long> raised_r4{0};
+        const int rc = ensure_dynamic_lds(raised_r4, (const void*)gemm_bf16_res4_asm_kernel, ring);
+        if (rc != PIPS_OK) return rc;
+        hipLaunchKernelGGL(gemm_bf16_res4_asm_kernel, dim3(ntiles), dim3(256), ring, st, a, tiles_m, ntiles);
+        PIPS_CHECK_LAUNCH("gemm_bf16_res4_asm_kernel");
+        return PIPS_OK;
+    }
+#endif
     if (route == 1) {
         static std::atomic<unsigned long long> raised_r{0};
         const int rc = ensure_dynamic_lds(raised_r, (const void*)gemm_bf16_res_asm_kernel, ring);

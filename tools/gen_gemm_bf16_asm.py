@@ -402,6 +402,182 @@ def tile_res():
     return a
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# The down-projection with FOUR waves per block (one per SIMD), wave tile 128 x 64, and a ring of three 64-K STAGES whose LDS
+# rows are 128 bytes: a DMA instruction brings 8 rows x 128 B (eight FULL cache lines) where the 32-K stages of the tiles above
+# bring 16 rows x 64 B.  Measured (tools/bf16_res_probe.py, the 4-wave tile with 64-byte rows): the K loop's time is the number of
+# vector-memory wave-instructions x ~52 clocks whatever they carry -- adding 6 (12) one-dword "touch" loads per super-stage to the 12
+# DMA instructions took the loop from 1.08 to 1.56 (2.1) us per super-stage -- i.e. the texture addresser spends ~3.3 clocks per
+# 64-byte row segment and delivers 47 GB/s per CU, while fully contiguous 1 KiB instructions reach 82 GB/s (tools/l2_stream_rate.hip).
+# All per-iteration address arithmetic of the DMA is scalar.
+# Registers: a[0:127] accumulators acc4(i, j) = 16 * (2i + j), i < 4; v[96:127] A fragments fa4(kk, i); v[128:143] W fragments;
+# v[144:146] fragment addresses; v[148:156] the K-quarter offsets 1..3 of A / W0 / W1; v[160:175] epilogue; v[176:207] bias.
+FA4, FB4 = 96, 128
+X4, BIAS4 = 160, 176
+OFFQ = 148                         # v[148 + 3*(kq-1) + {0,1,2}]: aoff / b0off / b1off ^ (kq * 32), kq = 1..3
+S_Q = 62                           # s[62:63]: 64-bit source base of a DMA instruction
+S_TA, S_TW = 64, 65                # LDS address of the target stage + this wave's A / W piece 0
+NA4, NW4 = 8, 4                    # DMA pieces per wave and stage: 8 of A (8 rows x 128 B each), 4 of W
+SUP4 = (256 + 128) * 128           # bytes of a 64-K stage
+
+
+def acc4(i, j):
+    return 16 * (2 * i + j)
+
+
+def fa4(kk, i):
+    return FA4 + 16 * kk + 4 * i
+
+
+def fb4(kk, j):
+    return FB4 + 8 * kk + 4 * j
+
+
+def off4(kq, which):
+    """register (or operand) holding the per-lane fragment offset of K quarter kq: which = 0 A, 1 W tile 0, 2 W tile 1"""
+    if kq == 0:
+        return ("%[aoff]", "%[b0off]", "%[b1off]")[which]
+    return "v%d" % (OFFQ + 3 * (kq - 1) + which)
+
+
+ABL = int(os.environ.get("PIPS_GEN_ABL", "0"))     # tuning: 1 = no fragment reads, 2 = no DMA in the loop, 4 = no MFMAs (4-wave tile)
+
+
+def reads4(a, kq, nxt=False):
+    """6 fragment reads of K quarter kq (fragment set kq & 1) from the stage at s[S_RD]"""
+    kk = kq & 1
+    if ABL & 1:
+        return
+    a("v_add_u32 v%d, s%d, %s" % (RA, S_RD, off4(kq, 0)))
+    a("v_add_u32 v%d, s%d, %s" % (RB0, S_RD, off4(kq, 1)))
+    a("v_add_u32 v%d, s%d, %s" % (RB1, S_RD, off4(kq, 2)))
+    a("ds_read_b128 v[%d:%d], v%d" % (fa4(kk, 0), fa4(kk, 0) + 3, RA))
+    a("ds_read_b128 v[%d:%d], v%d" % (fb4(kk, 0), fb4(kk, 0) + 3, RB0))
+    a("ds_read_b128 v[%d:%d], v%d offset:4096" % (fa4(kk, 1), fa4(kk, 1) + 3, RA))
+    a("ds_read_b128 v[%d:%d], v%d" % (fb4(kk, 1), fb4(kk, 1) + 3, RB1))
+    a("ds_read_b128 v[%d:%d], v%d offset:8192" % (fa4(kk, 2), fa4(kk, 2) + 3, RA))
+    a("ds_read_b128 v[%d:%d], v%d offset:12288" % (fa4(kk, 3), fa4(kk, 3) + 3, RA))
+
+
+def mfma4(a, kk, i, j):
+    c = acc4(i, j)
+    if ABL & 4:
+        return
+    a("v_mfma_f32_32x32x16_bf16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]" %
+      (c, c + 15, fb4(kk, j), fb4(kk, j) + 3, fa4(kk, i), fa4(kk, i) + 3, c, c + 15))
+
+
+def dma4(a, ahead, p):
+    """piece p (0..7: A, 8..11: W) of this wave, stage ks + ahead: LDS side s[S_TA] / s[S_TW] + 1024 * index (through m0), source
+    %[cqa] / %[cqw] + s[S_K] + ahead*128 (scalar), lane offsets %[ro<p>]"""
+    is_a = p < NA4
+    if ABL & 2:
+        return
+    a("s_add_u32 m0, s%d, %d" % (S_TA if is_a else S_TW, (p if is_a else p - NA4) * 1024))
+    a("s_add_u32 s%d, s%d, %d" % (S_T, S_K, ahead * 128))
+    a("s_add_u32 s%d, %%[%s], s%d" % (S_Q, "cqa" if is_a else "cqw", S_T))
+    a("s_addc_u32 s%d, %%[%s], 0" % (S_Q + 1, "cqah" if is_a else "cqwh"))
+    a("global_load_lds_dwordx4 %%[ro%d], s[%d:%d]" % (p, S_Q, S_Q + 1))
+
+
+def mfma_group4(a, kk, dmas):
+    """the 8 MFMAs of one K quarter (fragment set kk); dmas: list of (ahead, piece) issued one behind each of the first MFMAs"""
+    k = 0
+    for i in range(4):
+        for j in range(2):
+            mfma4(a, kk, i, j)
+            if k < len(dmas):
+                dma4(a, *dmas[k])
+            k += 1
+
+
+def target4(a, ahead_buffers):
+    """s[S_TA], s[S_TW] <- the buffer ahead_buffers stages further round the ring than s[S_RD] (+ this wave's piece offsets)"""
+    a("s_add_u32 s%d, s%d, %d" % (S_T2, S_RD, ahead_buffers * SUP4))
+    a("s_sub_u32 s%d, s%d, %d" % (S_T, S_T2, NSUP * SUP4))
+    a("s_cmp_ge_u32 s%d, %%[ringend]" % S_T2)
+    a("s_cselect_b32 s%d, s%d, s%d" % (S_T2, S_T, S_T2))
+    a("s_add_u32 s%d, s%d, %%[wvoffa]" % (S_TA, S_T2))
+    a("s_add_u32 s%d, s%d, %%[wvoffw]" % (S_TW, S_T2))
+
+
+FIRST4 = list(range(0, 6))         # the pieces of a stage that go out right behind the barrier that frees its buffer ...
+SECOND4 = list(range(6, 12))       # ... and the ones that follow in the next iteration
+
+
+def super_block4(a, do_a, do_b, nxt_reads, vmcnt):
+    """one 64-K stage of the 4-wave tile: K quarters 0..3, fragment sets alternate"""
+    if do_a:
+        target4(a, 2)
+    a("s_waitcnt lgkmcnt(6)")
+    mfma_group4(a, 0, [(2, p) for p in SECOND4] if do_a else [])
+    a("s_waitcnt lgkmcnt(0)")
+    reads4(a, 2)
+    mfma_group4(a, 1, [])
+    reads4(a, 3)
+    a("s_waitcnt lgkmcnt(6)")
+    mfma_group4(a, 0, [])
+    a("s_waitcnt lgkmcnt(0)")
+    a("s_waitcnt vmcnt(%d)" % vmcnt)
+    a("s_barrier")
+    if do_b:                                          # the buffer this stage just left is refilled with stage ks + 3
+        a("s_add_u32 s%d, s%d, %%[wvoffa]" % (S_TA, S_RD))
+        a("s_add_u32 s%d, s%d, %%[wvoffw]" % (S_TW, S_RD))
+    a("s_add_u32 s%d, s%d, %d" % (S_RD, S_RD, SUP4))
+    a("s_cmp_ge_u32 s%d, %%[ringend]" % S_RD)
+    a("s_cselect_b32 s%d, %%[lds0], s%d" % (S_RD, S_RD))
+    if nxt_reads:
+        reads4(a, 0)
+    mfma_group4(a, 1, [(3, p) for p in FIRST4] if do_b else [])
+    if nxt_reads:
+        reads4(a, 1)
+
+
+def tile_res4():
+    """ONE 256x128 tile of the down-projection on four waves (wave tile 128 x 64): K loop over %[nks] stages of 64 (>= 4),
+    accumulators start from the residual tile, bias added at the end, fp32 stores, natural column order."""
+    a = Asm()
+    for kq in (1, 2, 3):
+        for which, name in enumerate(("%[aoff]", "%[b0off]", "%[b1off]")):
+            a("v_xor_b32 v%d, %d, %s" % (OFFQ + 3 * (kq - 1) + which, kq * 32, name))
+    a("s_mov_b32 s%d, %%[rd]" % S_RD)
+    for i in range(4):
+        for j in range(2):
+            for g in range(4):
+                r = acc4(i, j) + 4 * g
+                a("global_load_dwordx4 a[%d:%d], %%[roff], %%[rb%d] offset:%d" % (r, r + 3, i, (j * 32 + 8 * g) * 4))
+    for j in range(2):
+        for g in range(4):
+            r = BIAS4 + 16 * j + 4 * g
+            a("global_load_dwordx4 v[%d:%d], %%[boff], %%[bias] offset:%d" % (r, r + 3, (j * 32 + 8 * g) * 4))
+    a("s_waitcnt vmcnt(0)")                           # the residual tile, the bias AND the C++ prologue's stages
+    a("s_barrier")
+    reads4(a, 0)
+    reads4(a, 1)
+    a("s_mov_b32 s%d, 0" % S_K)
+    a("s_sub_u32 s%d, %%[nks], 3" % S_CNT)
+    a("1:")
+    super_block4(a, True, True, True, 12)
+    a("s_add_u32 s%d, s%d, 128" % (S_K, S_K))
+    a("s_sub_u32 s%d, s%d, 1" % (S_CNT, S_CNT))
+    a("s_cmp_lg_u32 s%d, 0" % S_CNT)
+    a("s_cbranch_scc1 1b")
+    super_block4(a, True, False, True, 12)            # ks = nks-3: the second half of the last stage goes out
+    super_block4(a, False, False, True, 0)            # ks = nks-2
+    super_block4(a, False, False, False, 0)           # ks = nks-1
+    a("s_nop 15")
+    a("s_nop 15")
+    for i in range(4):
+        for j in range(2):
+            for r in range(16):
+                a("v_accvgpr_read_b32 v%d, a%d" % (X4 + r, acc4(i, j) + r))
+            for r in range(16):
+                a("v_add_f32 v%d, v%d, v%d" % (X4 + r, X4 + r, BIAS4 + 16 * j + r))
+            for g in range(4):
+                a("global_store_dwordx4 %%[soff], v[%d:%d], %%[cb%d] offset:%d" % (X4 + 4 * g, X4 + 4 * g + 3, i, (j * 32 + 8 * g) * 4))
+    return a
+
+
 def main():
     out = ["// GENERATED by tools/gen_gemm_bf16_asm.py -- do not edit.", ""]
     for gel in ((0, 1) if DEFER else (0,)):
@@ -423,6 +599,15 @@ def main():
     print("looped residual tile: %d instructions" % len(a.lines))
     clob = ['"a%d"' % i for i in range(64)] + ['"v%d"' % i for i in range(96, 192)] + ['"s%d"' % i for i in range(40, 62)]
     out.append('#define PIPS_TILE_RES_CLOBBER "memory", "scc", "vcc", ' + ", ".join(clob))
+    out.append("")
+    a = tile_res4()
+    out.append("#define PIPS_TILE_TEXT_RES4 \\")
+    for i, ins in enumerate(a.lines):
+        out.append('    "%s\\n\\t"' % ins + (" \\" if i + 1 < len(a.lines) else ""))
+    out.append("")
+    print("looped residual tile, four waves: %d instructions" % len(a.lines))
+    clob = ['"a%d"' % i for i in range(128)] + ['"v%d"' % i for i in range(96, 208)] + ['"s%d"' % i for i in range(40, 66)]
+    out.append('#define PIPS_TILE_RES4_CLOBBER "memory", "scc", "vcc", ' + ", ".join(clob))
     out.append("")
     with open(OUT, "w") as f:
         f.write("\n".join(out))
