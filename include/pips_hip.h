@@ -65,6 +65,10 @@ extern "C" {
 #define PIPS_FLAG_BF16_MIXER  2   /* bf16 MFMA operands in the channel-mix and head Linear layers (BASELINE
                                      config 3); accumulation, norms, GELU, residual stream, gather stay fp32 */
 
+#define PIPS_FLAG_BF16_MAPS   32  /* pips_track / pips_mixer_input_build_ex: the correlation gather reads the bf16 MIRROR of the
+                                     pyramid (behind the fp32 levels, pips_pyramid_mirror_offset; written by the bf16 encoder or
+                                     pips_pyramid_mirror) -- the reference's rounding point under autocast, where the encoder's
+                                     output is a bf16 tensor; pips_forward sets it itself when both BF16 flags are given */
 #define PIPS_FLAG_SPLIT_BF16  16  /* fp32-grade "split-bf16" matrix path: every fp32 operand is split exactly into
                                      three bf16 terms (round-to-nearest at each step), six exact bf16 products per fp32 product, fp32 accumulation
                                      (pips_gemm_f32x3) -- all mixer Linear layers and the convolutions where it is
@@ -163,6 +167,9 @@ int    pips_track(const void* arena, const float* pyramid, int B, int T, int H8,
 size_t pips_encoder_workspace_bytes(int F, int H, int W, int stride);
 size_t pips_pyramid_floats(int F, int H, int W, int stride);
 size_t pips_pyramid_offset(int F, int H, int W, int stride, int level);   /* in floats */
+/* pips_pyramid_floats = the four fp32 levels + their bf16 mirror (same element offsets, half the bytes) behind them */
+size_t pips_pyramid_mirror_offset(int F, int H, int W, int stride);       /* in floats: where the mirror starts = size of the fp32 levels */
+int    pips_pyramid_mirror(float* pyramid, int F, int H, int W, int stride, void* stream);   /* (re)write the mirror from the fp32 levels */
 int    pips_encoder_fwd(const void* arena, const float* rgbs, int F, int H, int W, int stride,
                         float* pyramid, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -191,6 +198,9 @@ int    pips_point_sample(const float* level0, int B, int S, int H8, int W8,
 int    pips_mixer_input_build(const float* pyramid, int B, int S, int H8, int W8,
                               const float* ffeats, const float* coords, const float* times,
                               int N, float* X, void* stream);
+/* the same with per-particle window starts (pips_track's win_start, may be NULL) and flags = 0 | PIPS_FLAG_BF16_MAPS */
+int    pips_mixer_input_build_ex(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats, const float* coords,
+                                 const float* times, int N, const int* win_start, int flags, float* X, void* stream);
 
 /* Same result as pips_mixer_input_build through the LDS-tiled kernels meant for dense query sets
  * (BASELINE configs[3], test_on_davis.py:103-130): particles binned by 16x16 map tile, the tile's

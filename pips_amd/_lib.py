@@ -46,6 +46,9 @@ SIGNATURES = {
     "pips_encoder_workspace_bytes": (c_size_t, [c_int] * 4),
     "pips_pyramid_floats": (c_size_t, [c_int] * 4),
     "pips_pyramid_offset": (c_size_t, [c_int] * 5),
+    "pips_pyramid_mirror_offset": (c_size_t, [c_int] * 4),
+    "pips_pyramid_mirror": (c_int, [fp, c_int, c_int, c_int, c_int, c_void_p]),
+    "pips_mixer_input_build_ex": (c_int, [fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, c_void_p, c_int, fp, c_void_p]),
     "pips_encoder_fwd": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_encoder_fwd_bf16": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_encoder_fwd_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, fp, c_void_p, c_size_t,

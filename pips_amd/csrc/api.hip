@@ -560,6 +560,8 @@ int encoder_bf16_acts(const float* arena, const ArenaLayout& A, const void* rgbs
     for (int l = 1; l < PIPS_LEVELS; ++l)
         RUN(launch_avgpool2(pyramid + pips_pyramid_offset(F, H, W, stride, l - 1), F, lh[l - 1], lw[l - 1], PIPS_C,
                             pyramid + pips_pyramid_offset(F, H, W, stride, l), st));
+    // the bf16 mirror the gather of the bf16 mode reads (PIPS_FLAG_BF16_MAPS)
+    RUN(pips_pyramid_mirror(pyramid, F, H, W, stride, st));
     return PIPS_OK;
 }
 
@@ -570,12 +572,23 @@ size_t pips_encoder_workspace_bytes(int F, int H, int W, int stride) {
     return plan_encoder(F, H, W, stride).total * sizeof(float);
 }
 
-size_t pips_pyramid_floats(int F, int H, int W, int stride) {
+// fp32 levels (pips_pyramid_offset) + the bf16 mirror of all of them behind (pips_pyramid_mirror_offset; written by the
+// bf16 encoder or pips_pyramid_mirror, read by the gather under PIPS_FLAG_BF16_MAPS)
+size_t pips_pyramid_mirror_offset(int F, int H, int W, int stride) {
     int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
     pyramid_dims(H, W, stride, lh, lw);
     size_t n = 0;
     for (int l = 0; l < PIPS_LEVELS; ++l) n += ((size_t)F * lh[l] * lw[l] * PIPS_C + 63) / 64 * 64;
     return n;
+}
+size_t pips_pyramid_floats(int F, int H, int W, int stride) {
+    const size_t n = pips_pyramid_mirror_offset(F, H, W, stride);
+    return n + (n / 2 + 63) / 64 * 64;
+}
+int pips_pyramid_mirror(float* pyramid, int F, int H, int W, int stride, void* stream) {
+    PIPS_CHECK_ARG(pyramid != nullptr && F > 0, "pyramid_mirror: bad argument");
+    const size_t n = pips_pyramid_mirror_offset(F, H, W, stride);
+    return launch_pyramid_mirror(pyramid, n, pyramid + n, (hipStream_t)stream);
 }
 
 size_t pips_pyramid_offset(int F, int H, int W, int stride, int level) {
@@ -684,7 +697,8 @@ int pips_point_sample(const float* level0, int B, int S, int H8, int W8, const f
 static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats, const float* coords,
                        const float* times, int N, const int* win_start, float* X, hipStream_t st,
                        void* scratch = nullptr, size_t scratch_bytes = 0, int force_tiled = -1, hipEvent_t* ev = nullptr,
-                       int Sw = PIPS_S) {       // S: frames per clip in the pyramid; Sw: window length = mixer rows per particle
+                       int Sw = PIPS_S,         // S: frames per clip in the pyramid; Sw: window length = mixer rows per particle
+                       bool bf16_maps = false) {   // the direct gather reads the bf16 mirror behind the fp32 levels
     size_t off[PIPS_LEVELS];
     int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
     lh[0] = H8; lw[0] = W8;
@@ -702,6 +716,7 @@ static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const
         return launch_mixer_input_tiled(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, scratch, scratch_bytes, st, ev);
     PIPS_CHECK_ARG(force_tiled != 1, "tiled gather needs scratch of %zu bytes, no win_start and 8 frames per clip",
                    tiled_gather_scratch_bytes(B, N, H8, W8));
+    if (bf16_maps) return launch_mixer_input_bf16maps(pyramid + o, off, lh, lw, B, S, ffeats, coords, times, N, win_start, X, st, Sw);
     return launch_mixer_input(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, win_start, X, st, Sw);
 }
 
@@ -710,6 +725,14 @@ int pips_mixer_input_build(const float* pyramid, int B, int S, int H8, int W8, c
     PIPS_CHECK_ARG(pyramid && ffeats && coords && times && X, "mixer_input: null pointer");
     PIPS_CHECK_ARG(S >= 1 && B > 0 && N > 0, "mixer_input: empty problem");
     return mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, nullptr, X, (hipStream_t)stream);
+}
+
+int pips_mixer_input_build_ex(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats, const float* coords,
+                              const float* times, int N, const int* win_start, int flags, float* X, void* stream) {
+    PIPS_CHECK_ARG(pyramid && ffeats && coords && times && X, "mixer_input: null pointer");
+    PIPS_CHECK_ARG(S >= 1 && B > 0 && N > 0, "mixer_input: empty problem");
+    return mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, win_start, X, (hipStream_t)stream, nullptr, 0, 0, nullptr,
+                       PIPS_S, (flags & PIPS_FLAG_BF16_MAPS) != 0);
 }
 
 size_t pips_gather_scratch_bytes(int B, int N, int H8, int W8) {
@@ -1101,7 +1124,7 @@ static int track_impl(const void* arena, const float* pyramid, int B, int T, int
             RUN(launch_score_terms((const float*)ce_ws, B, S, H8, W8, ffeats, N, ce_tgt, ce_terms + (size_t)it * M * 2, st));
         // the mixer workspace is idle while the gather runs: it doubles as the binning scratch
         RUN(mixer_input(pyramid, B, T, H8, W8, ffeats, coords, times, N, win_start, ws + P.X, st, ws + P.mixer,
-                        pips_mixer_workspace_bytes_s(M, S), -1, nullptr, S));
+                        pips_mixer_workspace_bytes_s(M, S), -1, nullptr, S, (flags & PIPS_FLAG_BF16_MAPS) != 0));
         RUN(mixer_impl(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes_s(M, S), stream, nullptr,
                        (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0), S));
         RUN(launch_state_update((const float*)arena, ws + P.delta, ffeats, coords, coords0, B, N, (float)stride,
@@ -1148,6 +1171,12 @@ int pips_forward_ce(const void* arena, const float* rgbs, const float* xys, cons
                          pips_encoder_workspace_bytes(B * S, H, W, stride), stream,
                          ((flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0) | ((flags & PIPS_FLAG_RGB_U8) ? 2 : 0) |
                              ((flags & PIPS_FLAG_SPLIT_BF16) ? 4 : 0)));
+    // both bf16 modes on and the encoder of this call wrote the mirror: the gather reads bf16 maps (with REUSE_MAPS the caller
+    // says so itself -- the mirror is as old as the maps)
+    if (!(flags & PIPS_FLAG_REUSE_MAPS) && !(flags & PIPS_FLAG_SPLIT_BF16) &&
+        (flags & (PIPS_FLAG_BF16_ENCODER | PIPS_FLAG_BF16_MIXER)) == (PIPS_FLAG_BF16_ENCODER | PIPS_FLAG_BF16_MIXER) &&
+        PIPS_TUNE("PIPS_BF16_MAPS", 1))
+        flags |= PIPS_FLAG_BF16_MAPS;
     return track_impl(arena, pyramid, B, S, H / stride, W / stride, xys, coords_init, feat_init, nullptr, times, N,
                       stride, iters, flags, S, ws + P.track, plan_track(B, N, S).total * sizeof(float), out_trajs, out_vis,
                       out_ffeat0, ce_tgt, ce_terms, ce_ws, ce_ws_bytes, stream);

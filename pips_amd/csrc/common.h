@@ -320,6 +320,11 @@ int launch_init_ffeats(const float* ffeat0, int BN, float* ffeats, hipStream_t s
 int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW,
                        int B, int S, const float* ffeats, const float* coords, const float* times,
                        int N, const int* win_start, float* X, hipStream_t st, int Sw = PIPS_S);
+// the direct gather on the bf16 mirror of the pyramid (PIPS_FLAG_BF16_MAPS), and the pass that writes the mirror
+int launch_mixer_input_bf16maps(const void* mirror, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B, int S,
+                                const float* ffeats, const float* coords, const float* times, int N, const int* win_start,
+                                float* X, hipStream_t st, int Sw = PIPS_S);
+int launch_pyramid_mirror(const float* pyramid, size_t floats, void* mirror, hipStream_t st);
 // LDS-tiled gather for dense query sets (gather_tiled.hip)
 size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8);
 bool tiled_gather_wanted(int B, int N, int H8, int W8);

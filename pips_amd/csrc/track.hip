@@ -239,6 +239,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
 }
 
+// The same gather on the bf16 MIRROR of the pyramid (bf16 mode, PIPS_FLAG_BF16_MAPS): under torch.autocast the encoder's output
+// is a bf16 tensor and CorrBlock.corr multiplies bf16 operands (nets/pips.py:394-395), so bf16 map values are the reference's own
+// rounding point; features, products and sums stay fp32 here.  What it buys is INSTRUCTIONS, not bytes: the direct gather is bound by
+// the rate of its vector-memory instructions (16 384 blocks x 4 waves x 32 loads at ~30 clocks each = the 107 us it takes at
+// BASELINE configs[2]); with 8 channels per lane a wave load covers FOUR pixels, 16 loads per level instead of 32.
+// Lane = (pixel of the group lane >> 4, channel octet lane & 15); 16 partial dot products per lane, transpose-reduced over the 16
+// lanes of a pixel group: lane r of group g ends with window row r >> 1, column 4 * (r & 1) + g.
+template <int SCT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void mixer_input_bf16maps_kernel(
+    const unsigned short* __restrict__ mirror, LevelTable lv, int S_, int Srt, const float* __restrict__ ffeats,
+    const float* __restrict__ coords, const float* __restrict__ times, int N, const int* __restrict__ win_start, float* __restrict__ X) {
+    __shared__ float Dw[PIPS_LEVELS][64];
+    const int S = SCT ? SCT : Srt;
+    const int m = blockIdx.x;
+    const int s = m % S, pn = m / S;
+    const int b = pn / N;
+    const int fstart = win_start != nullptr ? win_start[pn] : 0;
+    const int frame = b * S_ + min(max(fstart + s, 0), S_ - 1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int lvl = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float cxm = coords[(size_t)m * 2 + 0], cym = coords[(size_t)m * 2 + 1];
+    float* xrow = X + (size_t)m * PIPS_KIN_PAD;
+    const float* ff = ffeats + (size_t)m * C;
+    {
+        const int H = lv.H[lvl], W = lv.W[lvl];
+        const float inv = 1.0f / (float)(1 << lvl);
+        const float cx = cxm * inv, cy = cym * inv;
+        const float gx = __fsub_rn(__fdiv_rn(2.0f * cx, (float)(W - 1)), 1.0f);
+        const float gy = __fsub_rn(__fdiv_rn(2.0f * cy, (float)(H - 1)), 1.0f);
+        const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), (float)(W - 1) / 2.0f);
+        const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), (float)(H - 1) / 2.0f);
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const float wx = ix - fx0, wy = iy - fy0;
+        const int bx = (int)fx0 - PIPS_RADIUS, by = (int)fy0 - PIPS_RADIUS;
+
+        const int psel = lane >> 4, c8 = lane & 15;
+        const float4 fa = *reinterpret_cast<const float4*>(ff + c8 * 8), fb = *reinterpret_cast<const float4*>(ff + c8 * 8 + 4);
+        const unsigned short* base = mirror + lv.off[lvl] + (size_t)frame * H * W * C + c8 * 8;
+        uint4 t[16];
+        bool ok[16];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int py = by + jj;
+            const bool yok = (unsigned)py < (unsigned)H;
+            const int pyc = min(max(py, 0), H - 1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int px = bx + 4 * q + psel;
+                ok[jj * 2 + q] = yok && (unsigned)px < (unsigned)W;
+                const int pxc = min(max(px, 0), W - 1);
+                t[jj * 2 + q] = *reinterpret_cast<const uint4*>(base + ((size_t)pyc * W + pxc) * C);
+            }
+        }
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint4 u = t[e];
+            float d = bf16_lo(u.x) * fa.x;
+            d = fmaf(bf16_hi(u.x), fa.y, d);
+            d = fmaf(bf16_lo(u.y), fa.z, d);
+            d = fmaf(bf16_hi(u.y), fa.w, d);
+            d = fmaf(bf16_lo(u.z), fb.x, d);
+            d = fmaf(bf16_hi(u.z), fb.y, d);
+            d = fmaf(bf16_lo(u.w), fb.z, d);
+            d = fmaf(bf16_hi(u.w), fb.w, d);
+            v[e] = ok[e] ? d : 0.f;
+        }
+#define PIPS_TR_STEP(O, NH)                                                    \
+        {                                                                      \
+            const bool up = (lane & (O)) != 0;                                 \
+            _Pragma("unroll") for (int k = 0; k < (NH); ++k) {                 \
+                const float send = up ? v[k] : v[k + (NH)];                    \
+                const float keep = up ? v[k + (NH)] : v[k];                    \
+                v[k] = keep + __shfl_xor(send, (O));                           \
+            }                                                                  \
+        }
+        PIPS_TR_STEP(8, 8) PIPS_TR_STEP(4, 4) PIPS_TR_STEP(2, 2) PIPS_TR_STEP(1, 1)
+#undef PIPS_TR_STEP
+        const float scale = sqrtf((float)C);
+        Dw[lvl][(c8 >> 1) * 8 + 4 * (c8 & 1) + psel] = v[0] / scale;
+        __syncthreads();
+        if (lane < 49) {
+            const int ti = lane / 7, tj = lane - ti * 7;
+            const float e = 1.0f - wx, so = 1.0f - wy;
+            const float nw = Dw[lvl][tj * 8 + ti], ne = Dw[lvl][tj * 8 + ti + 1];
+            const float sw = Dw[lvl][(tj + 1) * 8 + ti], se = Dw[lvl][(tj + 1) * 8 + ti + 1];
+            float o = nw * (so * e);
+            o += ne * (so * wx);
+            o += sw * (wy * e);
+            o += se * (wy * wx);
+            xrow[C + lvl * 49 + lane] = o;
+        }
+    }
+    if (tid < C / 4)
+        reinterpret_cast<float4*>(xrow)[tid] = reinterpret_cast<const float4*>(ff)[tid];
+    const float dx = cxm - coords[(size_t)pn * S * 2 + 0];
+    const float dy = cym - coords[(size_t)pn * S * 2 + 1];
+    const float tt = times[s];
+    if (tid < 192) {
+        const int a = tid >> 6, i = tid & 63;
+        const float val = a == 0 ? dx : (a == 1 ? dy : tt);
+        const float freq = (float)(i >> 1) * 31.25f;
+        const float arg = __fmul_rn(val, freq);
+        xrow[C + PIPS_NCORR + tid] = (i & 1) ? cosf(arg) : sinf(arg);
+    } else if (tid < 192 + 3) {
+        const int a = tid - 192;
+        xrow[C + PIPS_NCORR + 192 + a] = a == 0 ? dx : (a == 1 ? dy : tt);
+    } else if (tid < 192 + 3 + (PIPS_KIN_PAD - PIPS_KIN)) {
+        xrow[PIPS_KIN + (tid - 195)] = 0.f;
+    }
+}
+
+int launch_mixer_input_bf16maps(const void* mirror, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B, int S_,
+                                const float* ffeats, const float* coords, const float* times, int N, const int* win_start,
+                                float* X, hipStream_t st, int Sw) {
+    LevelTable lv;
+    for (int l = 0; l < PIPS_LEVELS; ++l) { lv.off[l] = lvl_off[l]; lv.H[l] = lvlH[l]; lv.W[l] = lvlW[l]; }
+    const unsigned short* mp = reinterpret_cast<const unsigned short*>(mirror);
+    if (Sw == PIPS_S)
+        hipLaunchKernelGGL(mixer_input_bf16maps_kernel<PIPS_S>, dim3(B * N * S), dim3(256), 0, st, mp, lv, S_, Sw, ffeats,
+                           coords, times, N, win_start, X);
+    else
+        hipLaunchKernelGGL(mixer_input_bf16maps_kernel<0>, dim3(B * N * Sw), dim3(256), 0, st, mp, lv, S_, Sw, ffeats,
+                           coords, times, N, win_start, X);
+    PIPS_CHECK_LAUNCH("mixer_input_bf16maps_kernel");
+    return PIPS_OK;
+}
+
+// fp32 pyramid -> its bf16 mirror (same element offsets), 8 values per thread
+__global__ void pyramid_mirror_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const float4 a = src[2 * i], b = src[2 * i + 1];
+    dst[i] = make_uint4(pack2_bf16(a.x, a.y), pack2_bf16(a.z, a.w), pack2_bf16(b.x, b.y), pack2_bf16(b.z, b.w));
+}
+
+int launch_pyramid_mirror(const float* pyramid, size_t floats, void* mirror, hipStream_t st) {
+    const size_t n8 = floats / 8;                       // the pyramid's sections are multiples of 64 floats
+    hipLaunchKernelGGL(pyramid_mirror_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(pyramid), reinterpret_cast<uint4*>(mirror), n8);
+    PIPS_CHECK_LAUNCH("pyramid_mirror_kernel");
+    return PIPS_OK;
+}
+
 int launch_mixer_input(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW,
                        int B, int S_, const float* ffeats, const float* coords, const float* times,
                        int N, const int* win_start, float* X, hipStream_t st, int Sw) {

@@ -127,9 +127,20 @@ def point_sample(level0, B, xy):
     return out
 
 
-def mixer_input_build(pyr, B, H8, W8, ffeats, coords):
-    """ffeats (B*N*S,128), coords (B*N*S,2) particle-major -> X (B*N*S, 544)."""
+def mixer_input_build(pyr, B, H8, W8, ffeats, coords, bf16_maps=False):
+    """ffeats (B*N*S,128), coords (B*N*S,2) particle-major -> X (B*N*S, 544).  bf16_maps: the gather reads the bf16 mirror
+    behind the fp32 levels of ``pyr`` (PIPS_FLAG_BF16_MAPS; pyramid_mirror() writes it)."""
     lib = _lib.load()
+    if bf16_maps:
+        ffeats, coords = _f32(ffeats), _f32(coords)
+        M = ffeats.shape[0]
+        N = M // (B * S)
+        X = torch.empty(M, KIN_PAD, dtype=torch.float32, device=ffeats.device)
+        tt = times_table(ffeats.device)
+        with torch.cuda.device(ffeats.device):
+            _lib.check(lib.pips_mixer_input_build_ex(_lib.ptr(pyr), B, S, H8, W8, _lib.ptr(ffeats), _lib.ptr(coords), _lib.ptr(tt),
+                                                     N, None, 32, _lib.ptr(X), _stream()), "pips_mixer_input_build_ex")
+        return X
     ffeats, coords = _f32(ffeats), _f32(coords)
     M = ffeats.shape[0]
     N = M // (B * S)
@@ -139,6 +150,14 @@ def mixer_input_build(pyr, B, H8, W8, ffeats, coords):
         _lib.check(lib.pips_mixer_input_build(_lib.ptr(pyr), B, S, H8, W8, _lib.ptr(ffeats), _lib.ptr(coords),
                                               _lib.ptr(tt), N, _lib.ptr(X), _stream()), "pips_mixer_input_build")
     return X
+
+
+def pyramid_mirror(pyr, F, H, W, stride):
+    """(re)write the bf16 mirror of a packed pyramid buffer from its fp32 levels (pips_pyramid_mirror)"""
+    lib = _lib.load()
+    with torch.cuda.device(pyr.device):
+        _lib.check(lib.pips_pyramid_mirror(_lib.ptr(pyr), F, H, W, stride, _stream()), "pips_pyramid_mirror")
+    return pyr
 
 
 def mixer_input_build_tiled(pyr, B, H8, W8, ffeats, coords, out=None):

@@ -39,8 +39,9 @@ class FeatureCache:
     ``Pips.track``.  Per-frame InstanceNorm (nets/pips.py:153-157) makes a frame's maps
     independent of which clip/window it sits in, so the cache is exact for any window."""
 
-    def __init__(self, pyr, B, T, H, W, stride):
+    def __init__(self, pyr, B, T, H, W, stride, bf16_maps=False):
         self.pyr, self.B, self.T, self.H, self.W, self.stride = pyr, B, T, H, W, stride
+        self.bf16_maps = bf16_maps          # the buffer's bf16 mirror is valid (written by the bf16 encoder): PIPS_FLAG_BF16_MAPS
 
     @property
     def map_size(self):
@@ -253,7 +254,10 @@ class Pips(nn.Module):
                     part = ops.encoder_fwd(arena, frames[f0:f1], st, bf16=eb, split=sp)
                     for d, p in zip(dst, ops.pyramid_levels(part, f1 - f0, H, W, st)):
                         d[f0:f1].copy_(p)
-        return FeatureCache(pyr, B, T, H, W, st)
+                if eb:          # the parts' mirrors were laid out for their own frame counts: rewrite the whole one
+                    _lib.check(lib.pips_pyramid_mirror(_lib.ptr(pyr), F, H, W, st, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                               "pips_pyramid_mirror")
+        return FeatureCache(pyr, B, T, H, W, st, bf16_maps=eb and not sp)
 
     @torch.no_grad()
     def track(self, cache: FeatureCache, xys, coords_init=None, feat_init=None, iters=3, win_start=None,
@@ -279,6 +283,9 @@ class Pips(nn.Module):
             arena = self._packed(dev)
             if self._times is None or self._times.device != dev:
                 self._times = ops.times_table(dev, self.S)
+            fl = self._flags()
+            if cache.bf16_maps and (fl & 2) and not (fl & 16):
+                fl |= 32        # PIPS_FLAG_BF16_MAPS: bf16 mixer on maps of the bf16 encoder -> the gather reads their bf16 mirror
             nb = lib.pips_track_workspace_bytes_s(B, N, S)
             # ONE tracker workspace per device, grown on demand: chained tracking calls this with
             # a different (shrinking) N at every hop
@@ -291,7 +298,7 @@ class Pips(nn.Module):
             ffeat = torch.empty(B, N, self.latent_dim, dtype=f32, device=dev)
             rc = lib.pips_track_s(_lib.ptr(arena), _lib.ptr(cache.pyr), B, cache.T, H8, W8, _lib.ptr(xys_c), _lib.ptr(ci),
                                   _lib.ptr(fi), _lib.ptr(ws_i), _lib.ptr(self._times), N, int(cache.stride), int(iters),
-                                  self._flags(), S, _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e),
+                                  fl, S, _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e),
                                   _lib.ptr(ffeat), None, None, None, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "pips_track_s")
         preds = [trajs[i + 1] for i in range(iters)]

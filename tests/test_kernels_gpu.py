@@ -423,6 +423,30 @@ def test_mixer_input_build(B, N, H8, W8):
     assert torch.equal(X[..., 516:519], X_ref[..., 516:519])                            # raw flow + time
 
 
+@pytest.mark.parametrize("B,N,H8,W8", [(1, 24, 16, 20), (2, 9, 17, 25), (1, 5, 46, 62)])
+def test_mixer_input_build_bf16_maps(B, N, H8, W8):
+    """The gather of the bf16 mode (PIPS_FLAG_BF16_MAPS): the kernel reads the bf16 mirror of the pyramid, features and sums stay
+    fp32 -- against the oracle's CorrBlock on maps rounded to bf16 the same way (fp32 tolerance), border windows included, and
+    within bf16 rounding of the fp32 gather."""
+    from pips_amd import ops
+    O = _oracle()
+    fmaps, ffeats, coords = _random_state(B, N, H8, W8, seed=3)
+    coords[0, :, 0] = torch.tensor([-2.0, 1.5])                          # window partly outside the map
+    coords[0, :, 1] = torch.tensor([W8 - 1.0, H8 - 1.0])
+    pyr_ref = O.build_pyramid(fmaps)
+    pyr_bf = [p.bfloat16().float() for p in pyr_ref]                     # the mirror holds bf16(level), level by level
+    X_ref = O.mixer_input(ffeats, O.corr_sample(pyr_bf, ffeats, coords), coords)
+    pyr = ops.pyramid_mirror(_pack_pyramid(pyr_ref, B, H8 * 8, W8 * 8, 8), B * 8, H8 * 8, W8 * 8, 8)
+    ff, co = _pm(ffeats).to(DEV), _pm(coords).to(DEV)
+    X = ops.mixer_input_build(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu().view(B * N, 8, 544)
+    X32 = ops.mixer_input_build(pyr, B, H8, W8, ff, co).cpu().view(B * N, 8, 544)
+    assert torch.equal(X[..., :128], X_ref[..., :128]) and torch.equal(X[..., 324:], X32[..., 324:])
+    err = float((X[..., 128:324] - X_ref[..., 128:324]).abs().max())
+    d32 = float((X[..., 128:324] - X32[..., 128:324]).abs().max())
+    print(f"bf16-map gather vs oracle on bf16-rounded maps {err:.2e}; vs the fp32 gather {d32:.2e}")
+    assert err < 5e-5 and 1e-4 < d32 < 0.2
+
+
 @pytest.mark.parametrize("B,N,H8,W8,spread", [(1, 300, 46, 62, 0.7), (2, 1024, 33, 40, 3.0), (1, 77, 16, 20, 0.0)])
 def test_mixer_input_build_tiled(B, N, H8, W8, spread):
     """LDS-tiled gather (dense query sets) vs the oracle and vs the direct kernel."""
