@@ -30,9 +30,23 @@ def test_encode_in_passes_matches_single_pass(weights_raw):
     m = _model(weights_raw)
     _, rgbs, _, _ = G.make_inputs(dict(B=1, N=1, H=128, W=160))
     video = torch.cat([rgbs, rgbs.flip(1), rgbs[:, :4]], dim=1).to(DEV)          # T = 20
-    a = m.encode(video, frames_per_pass=64).pyr
-    b = m.encode(video, frames_per_pass=8).pyr
+    from pips_amd import _lib
+    n = _lib.load().pips_pyramid_mirror_offset(20, 128, 160, 8)      # the fp32 levels (the bf16 mirror behind them is written in the bf16 mode only)
+    a = m.encode(video, frames_per_pass=64).pyr[:n]
+    b = m.encode(video, frames_per_pass=8).pyr[:n]
     assert float((a - b).abs().max()) < 1e-4            # per-frame InstanceNorm: only tile-order noise
+    # bf16 mode: the mirror of a cache encoded in passes equals the mirror of the single pass (rewritten for the whole buffer)
+    m.encoder_dtype = m.mixer_dtype = torch.bfloat16
+    ca, cb = m.encode(video, frames_per_pass=64), m.encode(video, frames_per_pass=8)
+    assert ca.bf16_maps and cb.bf16_maps
+    for c in (ca, cb):                                               # the mirror IS bf16(fp32 levels), bit for bit
+        assert torch.equal(c.pyr[n:n + n // 2].view(torch.bfloat16), c.pyr[:n].bfloat16())
+    rel = float((ca.pyr[:n] - cb.pyr[:n]).pow(2).mean().sqrt() / cb.pyr[:n].pow(2).mean().sqrt())
+    assert rel < 2e-2                                                # different tile shapes at 20 / 8 frames: bf16 rounding noise
+    xys = torch.tensor([[[40.0, 50.0], [100.0, 64.0]]], device=DEV)
+    ta = m.track(ca, xys, iters=2, win_start=torch.tensor([[3, 9]]))
+    tb = m.track(cb, xys, iters=2, win_start=torch.tensor([[3, 9]]))
+    assert float((ta[0][-1] - tb[0][-1]).abs().max()) < 0.5          # raw weights, bf16 mode: same track up to bf16 noise
 
 
 def test_dense_chunks_match_single_call(weights_tamed):

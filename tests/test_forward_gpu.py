@@ -244,8 +244,10 @@ def test_uint8_frames_are_bit_identical(weights_raw):
     b = m(xys.to(DEV), rgbs.to(torch.uint8).to(DEV), iters=2, return_feat=True)
     for x, y in zip(a[0] + [a[2], a[3]], b[0] + [b[2], b[3]]):
         assert torch.equal(x, y)
+    from pips_amd import _lib
     ca, cb = m.encode(rgbs.to(DEV)), m.encode(rgbs.to(torch.uint8).to(DEV))
-    assert torch.equal(ca.pyr, cb.pyr)
+    n = _lib.load().pips_pyramid_mirror_offset(2 * 8, 128, 160, 8)     # the fp32 levels (the bf16 mirror behind them: bf16 mode only)
+    assert torch.equal(ca.pyr[:n], cb.pyr[:n])
 
 
 def test_clips_are_independent(weights_tamed):
