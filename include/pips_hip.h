@@ -55,7 +55,8 @@ extern "C" {
 #define PIPS_NPARAMS  200      /* tensors in the reference state dict                */
 
 /* flags of pips_forward / pips_track */
-#define PIPS_FLAG_REUSE_MAPS  1   /* pips_forward: skip the encoder, the workspace already holds the maps */
+#define PIPS_FLAG_REUSE_MAPS  1   /* pips_forward: skip the encoder, the workspace already holds the maps (of a call with the
+                                     same B,S,H,W,stride AND the same encoder flags: they describe the maps) */
 #define PIPS_FLAG_BF16_ENCODER 4  /* the encoder the way torch.autocast(bfloat16) runs it: bf16 MFMA operands in all 22
                                      convolutions (7x7 stem included) and bf16 activation maps between the layers;
                                      statistics from the fp32 accumulators, normalisation / ReLU / adds / resizes in

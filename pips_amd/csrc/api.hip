@@ -1171,9 +1171,9 @@ int pips_forward_ce(const void* arena, const float* rgbs, const float* xys, cons
                          pips_encoder_workspace_bytes(B * S, H, W, stride), stream,
                          ((flags & PIPS_FLAG_BF16_ENCODER) ? 1 : 0) | ((flags & PIPS_FLAG_RGB_U8) ? 2 : 0) |
                              ((flags & PIPS_FLAG_SPLIT_BF16) ? 4 : 0)));
-    // both bf16 modes on and the encoder of this call wrote the mirror: the gather reads bf16 maps (with REUSE_MAPS the caller
-    // says so itself -- the mirror is as old as the maps)
-    if (!(flags & PIPS_FLAG_REUSE_MAPS) && !(flags & PIPS_FLAG_SPLIT_BF16) &&
+    // both bf16 modes on: the bf16 encoder wrote the mirror with the maps and the gather reads it (with REUSE_MAPS the flags
+    // describe the call that produced the maps, so the same forward gives the same result with and without the encoder pass)
+    if (!(flags & PIPS_FLAG_SPLIT_BF16) &&
         (flags & (PIPS_FLAG_BF16_ENCODER | PIPS_FLAG_BF16_MIXER)) == (PIPS_FLAG_BF16_ENCODER | PIPS_FLAG_BF16_MIXER) &&
         PIPS_TUNE("PIPS_BF16_MAPS", 1))
         flags |= PIPS_FLAG_BF16_MAPS;

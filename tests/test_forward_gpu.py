@@ -236,6 +236,43 @@ def test_bf16_mixer_operands_config3_tolerance(weights_tamed):
     assert torch.equal(preds_ac[-1], preds[-1])
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_reuse_maps_flag_gives_the_same_forward(bf16, weights_tamed):
+    """PIPS_FLAG_REUSE_MAPS (pips_forward straight through the C ABI): the second call skips the encoder and tracks on the maps -- and,
+    in the bf16 mode, on their bf16 mirror -- the first call left in the workspace: bit-identical outputs, other queries accepted."""
+    import ctypes as C
+    from pips_amd import _lib, ops
+    lib = _lib.load()
+    m = _model(weights_tamed, 8)
+    if bf16:
+        m.mixer_dtype = m.encoder_dtype = torch.bfloat16
+    xys, rgbs = _config2_inputs(B=2, N=12, H=128, W=160)
+    xys, rgbs = xys.to(DEV), rgbs.to(DEV)
+    ref = m(xys, rgbs, iters=3, return_feat=True)                    # fills the module's forward workspace
+    B, S, _, H, W = rgbs.shape
+    N = xys.shape[1]
+    arena = m._packed(torch.device(DEV))
+    ws = m._workspace(lib, (B, S, H, W, N, 8), torch.device(DEV))
+    times = ops.times_table(torch.device(DEV))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def again(q):
+        trajs = torch.empty(4, B, S, N, 2, device=DEV)
+        vis = torch.empty(B, S, N, device=DEV)
+        ff = torch.empty(B, N, 128, device=DEV)
+        rc = lib.pips_forward(_lib.ptr(arena), None, _lib.ptr(q), None, None, _lib.ptr(times), B, S, H, W, N, 8, 3,
+                              m._flags() | 1, _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis), _lib.ptr(ff), st)
+        _lib.check(rc, "pips_forward(REUSE_MAPS)")
+        torch.cuda.synchronize()
+        return trajs, vis, ff
+    trajs, vis, ff = again(xys.contiguous())
+    assert torch.equal(trajs[3], ref[0][-1]) and torch.equal(vis, ref[2]) and torch.equal(ff, ref[3])
+    other = (xys + 3.0).contiguous()
+    t2, _, _ = again(other)                                          # new queries on the kept maps = a fresh forward with them
+    ref2 = m(other, rgbs, iters=3)
+    assert torch.equal(t2[3], ref2[0][-1])
+
+
 def test_uint8_frames_are_bit_identical(weights_raw):
     """Decoded frames can be handed over as uint8 (PIPS_FLAG_RGB_U8): same values, a quarter of the bytes."""
     m = _model(weights_raw, 8)
