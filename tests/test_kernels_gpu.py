@@ -639,3 +639,55 @@ def test_resize_frames_matches_interpolate(src_hw, dst_hw, u8):
     assert err < 1e-4, err
     if src_hw == dst_hw:
         assert torch.equal(got, src.float())
+
+
+def test_fixed_window_entry_points_equal_the_general_ones(weights_raw):
+    """The S = 8 / fixed-mode entry points are thin forms of the general ones: pips_repack_weights(_ex) = pips_repack_weights_s(8),
+    pips_encoder_fwd / _bf16 = pips_encoder_fwd_ex(flags), pips_track_ce = pips_track_s(S = 8) -- bit-identical results."""
+    import ctypes as C
+    from pips_amd import _lib, ops
+    from pips_amd.weights import param_table
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    names = list(param_table().keys())
+    srcs = [weights_raw[k].to(dev).contiguous().float() for k in names]
+    arr = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+    n = lib.pips_weight_arena_bytes() // 4
+    a0 = ops.pack_weights(weights_raw, dev)                                  # pips_repack_weights_s(S = 8, all sections)
+    a1 = torch.zeros(n, device=dev)
+    a2 = torch.zeros(n, device=dev)
+    _lib.check(lib.pips_repack_weights(arr, len(srcs), _lib.ptr(a1), st()), "pips_repack_weights")
+    _lib.check(lib.pips_repack_weights_ex(arr, len(srcs), _lib.ptr(a2), 15, st()), "pips_repack_weights_ex")
+    torch.cuda.synchronize()
+    used = a1 != 0                                                           # (alignment gaps are never written)
+    assert torch.equal(a1[used], a0[used]) and torch.equal(a2, a1)
+    # encoder
+    F_, H, W = 8, 128, 160
+    rgbs = torch.randint(0, 256, (F_, 3, H, W), generator=torch.Generator().manual_seed(4)).float().to(dev)
+    nb = lib.pips_encoder_workspace_bytes(F_, H, W, 8)
+    ws = torch.empty(nb // 4, device=dev)
+    nlev = lib.pips_pyramid_mirror_offset(F_, H, W, 8)
+    for bf16, fn in ((False, lib.pips_encoder_fwd), (True, lib.pips_encoder_fwd_bf16)):
+        p1 = torch.zeros(lib.pips_pyramid_floats(F_, H, W, 8), device=dev)
+        _lib.check(fn(_lib.ptr(a0), _lib.ptr(rgbs), F_, H, W, 8, _lib.ptr(p1), _lib.ptr(ws), nb, st()), "pips_encoder_fwd")
+        p2 = ops.encoder_fwd(a0, rgbs, 8, bf16=bf16)                         # pips_encoder_fwd_ex
+        assert torch.equal(p1[:nlev], p2[:nlev]) and float(p1[:nlev].abs().max()) > 0
+    # tracker
+    B, N = 1, 6
+    xys = (torch.rand(B, N, 2, generator=torch.Generator().manual_seed(5)) * 100 + 10).to(dev)
+    times = ops.times_table(dev)
+    nbt = lib.pips_track_workspace_bytes(B, N)
+    assert nbt == lib.pips_track_workspace_bytes_s(B, N, 8)
+    outs = []
+    for which in (0, 1):
+        wst = torch.empty(nbt // 4, device=dev)
+        trajs = torch.empty(3, B, 8, N, 2, device=dev); vis = torch.empty(B, 8, N, device=dev); ff = torch.empty(B, N, 128, device=dev)
+        args = [_lib.ptr(a0), _lib.ptr(p2), B, 8, H // 8, W // 8, _lib.ptr(xys), None, None, None, _lib.ptr(times), N, 8, 2, 0]
+        tail = [_lib.ptr(wst), nbt, _lib.ptr(trajs), _lib.ptr(vis), _lib.ptr(ff), None, None, None, 0, st()]
+        rc = lib.pips_track_ce(*args, *tail) if which == 0 else lib.pips_track_s(*args, 8, *tail)
+        _lib.check(rc, "pips_track")
+        torch.cuda.synchronize()
+        outs.append((trajs, vis, ff))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
