@@ -219,6 +219,97 @@ __global__ __launch_bounds__(512) void gemm_bf16_gelu_asm_kernel(GemmArgs p, int
     }
 }
 
+// The up-projection on 256 x 256 tiles (PIPS_TILE_TEXT_UP256_R0 / _R1): eight waves, wave tile 64 x 128.  Per MFMA a third fewer
+// operand bytes cross L2 -> LDS than with the 256 x 128 tile and a quarter fewer fragment reads -- the loop's cost is the MFMAs PLUS its
+// vector-memory instructions and fragment reads, so fewer of those is what makes a tile faster.  Ring of four 32-K
+// stages ((256 + 256) rows x 64 B = 32 KiB each) three stages ahead, one barrier per stage, run-on into the block's next tile; the
+// epilogue (bf16 rounding, table GELU, 16-byte stores) is part of the statement and reads the accumulators directly.
+__global__ __launch_bounds__(512) void gemm_bf16_gelu256_asm_kernel(GemmArgs p, int tiles_m, int ntiles) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int ROWB = 64, STAGE = (BM + BN) * ROWB, NST = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    char* Cb = reinterpret_cast<char*>(p.C);
+    const int tpb = p.swz;                            // tiles per block (set by the launcher), consecutive in m
+    const int tile_first = blockIdx.x * tpb, tile_end = min(tile_first + tpb, ntiles);
+    if (tile_first >= ntiles) return;
+
+    // loader: per stage wave w brings A rows [32w, 32w+32) and W rows [32w, 32w+32) as two 16-row pieces each;
+    // lane -> row lane >> 2 of the piece, physical 16-byte slot lane & 3 = slot ^ ((row >> 2) & 3)
+    unsigned rowoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wave * 32 + (q & 1) * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((row >> 2) & 3);
+        rowoff[q] = (unsigned)row * (unsigned)(q < 2 ? p.lda : p.K) * 2u + slot * 16;
+    }
+    auto a_base = [&](int tile) { return sgpr(Ab + (size_t)((tile % tiles_m) * BM) * p.lda * 2); };
+    auto w_base = [&](int tile) { return sgpr(Wb + (size_t)((tile / tiles_m) * BN) * p.K * 2); };
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned wva = lds0 + wave * 2048, wvw = lds0 + BM * ROWB + wave * 2048;
+
+    // ---- the GELU table (behind the ring), published by the first statement's barrier
+    float2* tab = reinterpret_cast<float2*>(smem + NST * STAGE);
+    for (int k = tid; k < GELU_TAB_N; k += 512) {
+        const float x = (float)(k - GELU_TAB_N / 2) * (1.0f / 64.0f);
+        const float v0 = gelu_exact(x), v1 = gelu_exact(x + 1.0f / 64.0f);
+        tab[k] = make_float2(v0, v1 - v0);
+    }
+    const unsigned tab_lds = lds0 + NST * STAGE;
+    // ---- prologue: stages 0 .. 2 of the first tile
+    {
+        const char* a0 = a_base(tile_first);
+        const char* w0 = w_base(tile_first);
+#pragma unroll
+        for (int X = 0; X < 3; ++X)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)((q < 2 ? a0 : w0) + rowoff[q] + X * 64),
+                                                 (lptr_t)(smem + X * STAGE + (q < 2 ? 0 : BM * ROWB) + wave * 2048 + (q & 1) * 1024), 16, 0, 0);
+    }
+    // fragment byte offsets (LDS base included; K half 1 = ^ 32 inside the statement)
+    const unsigned a_off = lds0 + (wm * 64 + l31) * ROWB + ((half ^ ((l31 >> 2) & 3)) * 16);
+    unsigned b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int brow = wn * 128 + (j >> 1) * 64 + gelu_col(j & 1, l31);
+        b_off[j] = lds0 + (BM + brow) * ROWB + ((half ^ ((brow >> 2) & 3)) * 16);
+    }
+    const unsigned boff = 8 * half * 4;                               // per-lane part of the bias column offset (bytes)
+    const unsigned stoff = (unsigned)(((size_t)l31 * p.ldc + 8 * half) * 2);
+#define PIPS_LO(ptr) sgpr((unsigned)(unsigned long long)reinterpret_cast<uintptr_t>(ptr))
+#define PIPS_HI(ptr) sgpr((unsigned)((unsigned long long)reinterpret_cast<uintptr_t>(ptr) >> 32))
+    for (int tile = tile_first; tile < tile_end; ++tile) {
+        const bool last = tile + 1 >= tile_end;
+        const int ntile = last ? tile : tile + 1;
+        const char* ca = a_base(tile);  const char* cw = w_base(tile);
+        const char* na = a_base(ntile); const char* nw = w_base(ntile);
+        const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+        const float* bias = p.bias + n0 + wn * 128;
+        const char* cb0 = Cb + ((size_t)(m0 + wm * 64) * p.ldc + n0 + wn * 128) * 2;
+        const char* cb1 = cb0 + (size_t)32 * p.ldc * 2;
+#define PIPS_TILE256(TEXT_)                                                                                                 \
+        asm volatile(TEXT_                                                                                                  \
+                     :                                                                                                      \
+                     : [ro0] "v"(rowoff[0]), [ro1] "v"(rowoff[1]), [ro2] "v"(rowoff[2]), [ro3] "v"(rowoff[3]), [aoff] "v"(a_off),  \
+                       [b0off] "v"(b_off[0]), [b1off] "v"(b_off[1]), [b2off] "v"(b_off[2]), [b3off] "v"(b_off[3]),           \
+                       [stoff] "v"(stoff), [boff] "v"(boff), [wva] "s"(sgpr(wva)), [wvw] "s"(sgpr(wvw)), [tab] "s"(sgpr(tab_lds)), \
+                       [cqa] "s"(PIPS_LO(ca)), [cqah] "s"(PIPS_HI(ca)), [cqw] "s"(PIPS_LO(cw)), [cqwh] "s"(PIPS_HI(cw)),     \
+                       [nqa] "s"(PIPS_LO(na)), [nqah] "s"(PIPS_HI(na)), [nqw] "s"(PIPS_LO(nw)), [nqwh] "s"(PIPS_HI(nw)),     \
+                       [bias] "s"(sgpr(bias)), [cb0] "s"(sgpr(cb0)), [cb1] "s"(sgpr(cb1))                                    \
+                     : PIPS_TILE_UP256_CLOBBER)
+        if (last) PIPS_TILE256(PIPS_TILE_TEXT_UP256_R0); else PIPS_TILE256(PIPS_TILE_TEXT_UP256_R1);
+#undef PIPS_TILE256
+    }
+#undef PIPS_LO
+#undef PIPS_HI
+}
+
 // The down-projection -- the FeedForward's second Linear, nets/pips.py:107, and the residual of PreNormResidual :100
 // (K = 2048, fp32 output): one 256x128 tile per block, the same ring / fragment / MFMA
 // schedule as a LOOP over the super-stages inside one assembly statement (PIPS_TILE_TEXT_RES); the accumulators start
@@ -397,6 +488,21 @@ int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_
         if (rc != PIPS_OK) return rc;
         hipLaunchKernelGGL(gemm_bf16_res_asm_kernel, dim3(ntiles), dim3(512), ring, st, a, tiles_m, ntiles);
         PIPS_CHECK_LAUNCH("gemm_bf16_res_asm_kernel");
+        return PIPS_OK;
+    }
+    const int cus0 = device_cus();
+    if (PIPS_TUNE("PIPS_BF16_UP256", 1) && a.N % 256 == 0 && cus0 > 0 && (long)(a.M / 256) * (a.N / 256) >= cus0) {
+        const int nt = (a.M / 256) * (a.N / 256);
+        int t2 = PIPS_TUNE("PIPS_BF16_UP256_TPB", 2);
+        while (t2 > 1 && (nt + t2 - 1) / t2 < cus0) --t2;
+        GemmArgs b2 = a;
+        b2.swz = t2;
+        const size_t lds2 = (size_t)4 * 512 * 64 + GELU_TAB_N * 8;
+        static std::atomic<unsigned long long> raised2{0};
+        const int rc2 = ensure_dynamic_lds(raised2, (const void*)gemm_bf16_gelu256_asm_kernel, lds2);
+        if (rc2 != PIPS_OK) return rc2;
+        hipLaunchKernelGGL(gemm_bf16_gelu256_asm_kernel, dim3((nt + t2 - 1) / t2), dim3(512), lds2, st, b2, a.M / 256, nt);
+        PIPS_CHECK_LAUNCH("gemm_bf16_gelu256_asm_kernel");
         return PIPS_OK;
     }
     int tpb = PIPS_TUNE("PIPS_BF16_ASM_TPB", 4);  // tuning hook: tiles per block (config 3: 1 / 2 / 4 -> 22.1 / 21.0 / 20.7 ms)
