@@ -602,30 +602,7 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
     const int l31 = lane & 31, half = lane >> 5;
     const int p = blockIdx.x * 4 + wave;                                      // (wave-uniform)
     if (p >= particles) return;
-    // ---- weights as MFMA A fragments
-    uint4 a1, a2[2];
-    {
-        const float* w0 = arena + L.tw0 + l31 * 8 + 4 * half;                 // w0[hidden = l31][token 4*half + i]
-        a1 = make_uint4(pack2_bf16(w0[0], w0[1]), pack2_bf16(w0[2], w0[3]), 0u, 0u);
-        const float* w3 = arena + L.tw3 + (l31 & 7) * 32;                     // w3[token = l31 (< 8)][hidden]
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            unsigned d[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r0 = 8 * kc + 2 * i, r1 = r0 + 1;
-                const float v0 = w3[(r0 & 3) + 8 * (r0 >> 2) + 4 * half], v1 = w3[(r1 & 3) + 8 * (r1 >> 2) + 4 * half];
-                d[i] = l31 < 8 ? pack2_bf16(v0, v1) : 0u;
-            }
-            a2[kc] = make_uint4(d[0], d[1], d[2], d[3]);
-        }
-    }
-    float b0r[16], b3r[4];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) b0r[r] = arena[L.tb0 + (r & 3) + 8 * (r >> 2) + 4 * half];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) b3r[r] = arena[L.tb3 + 4 * half + r];
-
+    // ---- the particle's tile first: its 16 loads are the long ones (HBM / Infinity Cache), the weights below hit L2
     float* xp = x + ((size_t)p * S + 4 * half) * PIPS_DMIX + 4 * l31;         // + r * 512 + g * 128
     float xv[4][16];                                                          // [token r][g * 4 + q]
 #pragma unroll
@@ -635,6 +612,31 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
             const float4 v = *reinterpret_cast<const float4*>(xp + r * PIPS_DMIX + g * 128);
             xv[r][4 * g] = v.x; xv[r][4 * g + 1] = v.y; xv[r][4 * g + 2] = v.z; xv[r][4 * g + 3] = v.w;
         }
+    // ---- weights as MFMA A fragments
+    uint4 a1, a2[2];
+    {
+        const float* w0 = arena + L.tw0 + l31 * 8 + 4 * half;                 // w0[hidden = l31][token 4*half + i]
+        a1 = make_uint4(pack2_bf16(w0[0], w0[1]), pack2_bf16(w0[2], w0[3]), 0u, 0u);
+        // w3[token = l31 (< 8)][hidden]: register r of the lane = hidden unit (r & 3) + 8 (r >> 2) + 4 half, i.e. four runs of four
+        // consecutive floats.  Four UNCONDITIONAL 16-byte loads, masked afterwards: written as `l31 < 8 ? pack(w3[..]) : 0` hipcc
+        // sank every load into its own predicated block -- eight load -> s_waitcnt vmcnt(0) round trips in a row at the head of
+        // every wave, before the particle's own tile was even requested
+        const float4* w3 = reinterpret_cast<const float4*>(arena + L.tw3 + (l31 & 7) * 32 + 4 * half);
+        const float4 wq[4] = {w3[0], w3[2], w3[4], w3[6]};
+        const unsigned keep = l31 < 8 ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const float4 p0 = wq[2 * kc], p1 = wq[2 * kc + 1];
+            a2[kc] = make_uint4(pack2_bf16(p0.x, p0.y) & keep, pack2_bf16(p0.z, p0.w) & keep, pack2_bf16(p1.x, p1.y) & keep,
+                                pack2_bf16(p1.z, p1.w) & keep);
+        }
+    }
+    float b0r[16], b3r[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b0r[r] = arena[L.tb0 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b3r[r] = arena[L.tb3 + 4 * half + r];
+
     // per-token mean / rstd of the lane's four tokens: one pass of sums, reduced over the wave
     auto ln_stats = [&](const float (&v)[4][16], float (&mean)[4], float (&rstd)[4]) __attribute__((always_inline)) {
         float s1[4], s2[4];
