@@ -527,13 +527,9 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float red[S][4];
     __shared__ float wsm[32 * 8 + 32 + 8 * 32 + 8];
     const int tid = threadIdx.x;
-    // stage the tiny token-MLP weights: w0[32][8], b0[32], w3[8][32], b3[8]
-    wsm[tid] = arena[L.tw0 + tid];
-    wsm[288 + tid] = arena[L.tw3 + tid];
-    if (tid < 32) wsm[256 + tid] = arena[L.tb0 + tid];
-    if (tid >= 64 && tid < 72) wsm[544 + (tid - 64)] = arena[L.tb3 + (tid - 64)];
-
-    // thread -> channels 2*tid, 2*tid+1 (one 8-byte access per token row)
+    // thread -> channels 2*tid, 2*tid+1 (one 8-byte access per token row).  The particle's tile is requested FIRST: hipcc turns
+    // the four small weight copies below into load -> wait -> ds_write one after the other, and with them in front the tile's
+    // loads (the long ones) left three L2 round trips late -- in a kernel that is all latency at 256 particles.
     float* xp = x + (size_t)blockIdx.x * S * PIPS_DMIX + 2 * tid;
     float* xnp = xn + (size_t)blockIdx.x * S * PIPS_DMIX + 2 * tid;
     f2 xv[S];
@@ -542,6 +538,15 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
     for (int t = 0; t < S; ++t) xv[t] = *reinterpret_cast<const f2*>(xp + t * PIPS_DMIX);
     const f2 g1 = *reinterpret_cast<const f2*>(arena + L.ln1g + 2 * tid), be1 = *reinterpret_cast<const f2*>(arena + L.ln1b + 2 * tid);
     const f2 g2 = *reinterpret_cast<const f2*>(arena + L.ln2g + 2 * tid), be2 = *reinterpret_cast<const f2*>(arena + L.ln2b + 2 * tid);
+    // stage the tiny token-MLP weights: w0[32][8], b0[32], w3[8][32], b3[8] (all four values requested before the first is stored)
+    {
+        const float w0v = arena[L.tw0 + tid], w3v = arena[L.tw3 + tid];
+        const float b0v = arena[L.tb0 + (tid & 31)], b3v = arena[L.tb3 + (tid & 7)];
+        wsm[tid] = w0v;
+        wsm[288 + tid] = w3v;
+        if (tid < 32) wsm[256 + tid] = b0v;
+        if (tid >= 64 && tid < 72) wsm[544 + (tid - 64)] = b3v;
+    }
     ln_stats2(xv, mean, rstd, red);          // (its barriers also publish wsm)
 
     f2 h[S], y[S];
