@@ -487,9 +487,12 @@ def test_mixer(P, split, weights_raw, arenas):
 
 
 @pytest.mark.parametrize("M,N,K,epi,out_bf16", [
-    (16384, 2048, 512, 1, True),       # config-3 up-projection: the generated-assembly kernel (gemm_bf16_asm.hip), 4 tiles per block
-    (8192, 2048, 512, 1, True),        # 512 tiles: the same kernel with 2 tiles per block
-    (1280, 2048, 512, 1, True),        # 80 tiles: below its threshold -> register-staged kernel, same contract
+    (16384, 2048, 512, 1, True),       # config-3 up-projection: 256 x 256 tiles, two per block (gemm_bf16_gelu256_asm_kernel)
+    (8192, 2048, 512, 1, True),        # 256 such tiles: one per block (no run-on)
+    (16640, 2048, 512, 1, True),       # 65 row blocks: a block's tile pair straddles two column blocks (run-on across W panels)
+    (32768, 1024, 512, 1, True),       # 512 tiles on 256 blocks, four column blocks
+    (16384, 1920, 512, 1, True),       # N % 256 != 0: the 256 x 128 kernel (gemm_bf16_gelu_asm_kernel), 4 tiles per block
+    (1280, 2048, 512, 1, True),        # below either threshold -> register-staged kernel, same contract
     (16384, 512, 2048, 2, False),      # config-3 down-projection
     (4096, 512, 544, 0, False),        # input projection: fp32 A, 32-element K blocks
 ])
