@@ -69,3 +69,59 @@ def chain(sd, rgbs, xy0, iters=6, stride=8, cache_frames=False):
         trajs_e[:, :, n] = traj_e
         hops.append(seq)
     return trajs_e, hops
+
+
+@torch.no_grad()
+def chain_lockstep(sd, rgbs, xy0, iters=6, stride=8):
+    """The same loop as ``chain`` (chain_demo.py:40-83) with all particles advanced side by side, for videos at the size
+    of BASELINE configs[4] (T = 100, N = 256) where ``chain`` -- one oracle forward per particle and hop -- takes hours.
+
+    Every live particle is ONE CLIP of the oracle forward (batch row = particle, N = 1): its own 8-frame window of the
+    cached per-frame maps (``cache_frames`` of ``chain``: exact, InstanceNorm is per frame), its own start position and
+    carried ``feat_init``; nothing in ``pips_oracle.forward`` mixes batch rows, so each row computes what ``chain``
+    computes for that particle.  The threshold scan of :63-77 runs per particle in Python, as written.  Runs on
+    whatever device ``sd`` / ``rgbs`` live on.  tests/test_oracle_golden.py::test_chain_lockstep_equals_chain holds it to
+    ``chain`` (identical hop sequences, trajectories to fp32 round-off of the batched ATen ops)."""
+    B, T = rgbs.shape[:2]
+    assert B == 1
+    N = xy0.shape[1]
+    dev = rgbs.device
+    H, W = rgbs.shape[-2:]
+    frame_maps = torch.cat([O.encoder(sd, 2 * (rgbs[0, t:t + 1] / 255.0) - 1.0, stride) for t in range(T)], dim=0)
+    trajs_e = torch.zeros(1, T, N, 2, device=dev)
+    trajs_e[0, 0] = xy0[0]
+    cur = [0] * N
+    hops = [[] for _ in range(N)]
+    feat = [None] * N
+    active = list(range(N))
+    shape_only = rgbs[:, :1].expand(1, 8, 3, H, W)                                # forward reads rgbs for its SHAPE only when fmaps is given
+    while active:
+        n_act = len(active)
+        idx = torch.tensor([[min(cur[n] + s, T - 1) for s in range(8)] for n in active], device=dev)   # :50-52 padding = last frame repeated
+        fmaps = frame_maps[idx]                                                   # (n_act,8,128,H/s,W/s)
+        start = torch.stack([trajs_e[0, cur[n], n] for n in active]).reshape(n_act, 1, 2)
+        fi = None if feat[active[0]] is None else torch.stack([feat[n] for n in active]).reshape(n_act, 1, -1)
+        preds, _, vis, ffeat = O.forward(sd, start, shape_only.expand(n_act, 8, 3, H, W), iters=iters, stride=stride,
+                                         feat_init=fi, fmaps=fmaps)
+        vis = torch.sigmoid(vis).cpu()                                            # (n_act,8,1)
+        xys = preds[-1]                                                           # (n_act,8,1,2)
+        nxt = []
+        for j, n in enumerate(active):
+            feat[n] = ffeat[j, 0]                                                 # :57 (the forward returns feat_init when given)
+            S_local = min(8, T - cur[n])
+            trajs_e[0, cur[n]:cur[n] + S_local, n] = xys[j, :S_local, 0]
+            assert torch.isfinite(vis[j]).all()
+            thr, si = 0.9, 7                                                      # :63-77
+            while True:
+                if vis[j, si, 0] > thr:
+                    break
+                si -= 1
+                if si == 1:
+                    thr -= 0.02
+                    si = 7
+            hops[n].append(si)
+            cur[n] += si
+            if cur[n] < T:
+                nxt.append(n)
+        active = nxt
+    return trajs_e, hops

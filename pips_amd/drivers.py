@@ -54,8 +54,10 @@ def skip_scan(vis):
 
 
 @torch.no_grad()
-def track_chained(model, rgbs, xy0, iters=6):
-    """rgbs (1,T,3,H,W), xy0 (1,N,2) px at frame 0 -> trajs_e (1,T,N,2) (chain_demo.run_model)."""
+def track_chained(model, rgbs, xy0, iters=6, return_hops=False):
+    """rgbs (1,T,3,H,W), xy0 (1,N,2) px at frame 0 -> trajs_e (1,T,N,2) (chain_demo.run_model).
+    ``return_hops=True``: also the list, per particle, of the frame steps ``si`` its windows advanced by
+    (chain_demo.py:63-79) -- what a parity test compares hop for hop."""
     assert rgbs.shape[0] == 1, "the reference chains one video at a time (chain_demo.py:24)"
     assert model.S == 8, "chain_demo.py's visibility scan (frames 7..2 of an 8-frame window) is written for S = 8"
     dev = rgbs.device
@@ -69,6 +71,7 @@ def track_chained(model, rgbs, xy0, iters=6):
     cur = torch.zeros(N, dtype=torch.int64, device=dev)
     active = torch.arange(N, device=dev)
     feat = None
+    log = []
     while active.numel() > 0:
         c = cur[active]
         start_xy = trajs[0, c, active].unsqueeze(0)                               # traj_e[:,cur_frame]
@@ -81,5 +84,14 @@ def track_chained(model, rgbs, xy0, iters=6):
         trajs[0, c.unsqueeze(0) + offs, active.unsqueeze(0).expand(S, -1)] = xys   # traj_e[cur:cur+8] = xys[:S_local]
         si = skip_scan(torch.sigmoid(vis[0]))
         cur[active] = c + si
+        if return_hops:
+            log.append((active, si))
         active = active[cur[active] < T]                                          # (one host sync per hop: the live count)
-    return trajs[:, :T].contiguous()
+    out = trajs[:, :T].contiguous()
+    if not return_hops:
+        return out
+    hops = [[] for _ in range(N)]
+    for act, si in log:
+        for n, k in zip(act.tolist(), si.tolist()):
+            hops[n].append(k)
+    return out, hops

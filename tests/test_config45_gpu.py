@@ -135,3 +135,38 @@ def test_config5_chained_tracking_stride4(weights_tamed):
     err = float((got - ref).abs().max())
     print("config-5 geometry chained: max |dtraj| px", err, " hops/particle", sum(len(h) for h in hops) / N)
     assert tuple(got.shape) == (1, T, N, 2) and err < 1e-3
+
+
+def test_config5_full_size_t100_n256_against_oracle_on_device(weights_tamed):
+    """BASELINE configs[4] at its OWN size (chain_demo.py:40-83): 100 frames of 360x640, stride 4, N = 256 (a 16x16 grid at
+    frame 0), I = 6, S = 8 windows chained on visibility -- ``drivers.track_chained`` against the chaining oracle run on the
+    SAME GPU with torch-ROCm fp32 ops (oracle/chain_oracle.chain_lockstep: the loop of ``chain``, which is pinned to the
+    reference's own text, with every particle as one clip of the oracle forward; held to ``chain`` on the CPU by
+    tests/test_oracle_golden.py::test_chain_lockstep_equals_chain).  Gate: identical hop sequences for every particle and
+    1e-3 px on all 100 x 256 positions (tamed weights)."""
+    from pips_amd import Pips, drivers
+    from oracle import chain_oracle
+    g = torch.Generator().manual_seed(9)
+    T, H, W, N = 100, 360, 640, 256
+    base = torch.randint(0, 256, (1, 1, 3, H, W), generator=g).float()
+    video = torch.cat([(base * (1 - 0.005 * t) + 1.2 * t).clamp(0, 255).round() for t in range(T)], dim=1)
+    video = (video + torch.randint(0, 30, video.shape, generator=g).float()).clamp(0, 255).to(DEV)
+    xy0 = _grid(N, H, W, margin=16.0).unsqueeze(0).to(DEV)
+    sd = {k: v.to(DEV) for k, v in weights_tamed.items()}
+    ref, ref_hops = chain_oracle.chain_lockstep(sd, video, xy0, iters=6, stride=4)
+    ref = ref.cpu()
+    del sd
+    torch.cuda.empty_cache()
+    m = Pips(stride=4)
+    m.load_state_dict(weights_tamed)
+    m = m.to(DEV).eval()
+    got, hops = drivers.track_chained(m, video, xy0, iters=6, return_hops=True)
+    got = got.cpu()
+    err = float((got - ref).abs().max())
+    nh = sum(len(h) for h in ref_hops)
+    diff = [n for n in range(N) if hops[n] != ref_hops[n]]
+    print(f"config 5 at full size (T=100, N=256, 360x640 s4, I=6): max |dtraj| {err:.2e} px over {T * N} positions, "
+          f"{nh} window forwards ({nh / N:.1f} hops per particle), particles with a different hop sequence: {len(diff)}")
+    assert tuple(got.shape) == (1, T, N, 2)
+    assert not diff
+    assert err < 1e-3

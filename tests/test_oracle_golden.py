@@ -89,6 +89,22 @@ def test_chain_oracle_frame_cache_equals_faithful_loop(weights_tamed):
     assert float((a - b).abs().max()) < 1e-4
 
 
+def test_chain_lockstep_equals_chain(weights_tamed):
+    """oracle/chain_oracle.chain_lockstep (all particles side by side, one clip of the oracle forward each -- the form
+    that finishes at T=100 / N=256 on the device, tests/test_config45_gpu.py) against chain(cache_frames=True), which is
+    pinned to the reference's own loop text: identical hop sequences, trajectories to the round-off of batched ATen ops."""
+    from oracle import chain_oracle
+    g = torch.Generator().manual_seed(12)
+    T, H, W, N = 19, 128, 160, 5
+    base = torch.randint(0, 256, (1, 1, 3, H, W), generator=g).float()
+    video = torch.cat([(base * (1 - 0.03 * t) + 7.0 * t).clamp(0, 255).round() for t in range(T)], dim=1)
+    xy0 = torch.rand(1, N, 2, generator=g) * torch.tensor([W - 17.0, H - 17.0]) + 8.0
+    a, ha = chain_oracle.chain(weights_tamed, video, xy0, iters=3, stride=8, cache_frames=True)
+    b, hb = chain_oracle.chain_lockstep(weights_tamed, video, xy0, iters=3, stride=8)
+    assert ha == hb
+    assert float((a - b).abs().max()) < 1e-4
+
+
 def test_chain_oracle_against_reference_loop_text(weights_tamed):
     """oracle/chain_oracle.chain against the output of the reference's OWN loop text (chain_demo.py:39-83 executed
     verbatim with the unmodified reference model by tests/golden/make_chain_golden.py): same window starts, same hops,
