@@ -24,8 +24,8 @@ Weights are repacked for the kernels when a parameter's storage or version count
 from __future__ import annotations
 
 import ctypes as C
-
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -94,6 +94,11 @@ class Pips(nn.Module):
         self._arena_sections = 0
         self._ws = {}
         self._times = None
+        # The reference module is stateless between calls; this one caches the packed weights and its scratch memory.
+        # Both are guarded: the lock covers (re)packing and the workspace tables, and scratch is kept PER STREAM, so
+        # Python threads driving one module on different streams never share a workspace (kernels of two streams run
+        # concurrently on the device; a lock around the launch would not keep them apart).
+        self._lock = threading.RLock()
 
     # ------------------------------------------------------------------ weights
     def invalidate_weights(self):
@@ -151,16 +156,25 @@ class Pips(nn.Module):
         return bf if bf or self.matmul == "exact" else 16                 # PIPS_FLAG_SPLIT_BF16
 
     def _workspace(self, lib, dims, device):
-        k = (str(device),) + dims
-        ws = self._ws.get(k)
-        if ws is None:
-            nb = lib.pips_workspace_bytes(*dims)
-            if nb == 0:
-                raise _lib.PipsHipError(f"unsupported problem size {dims}")
-            self._ws = {k2: v for k2, v in self._ws.items() if k2[0] == "track"}   # one forward workspace per module
-            ws = torch.empty(nb // 4, dtype=torch.float32, device=device)
-            self._ws[k] = ws
-        return ws
+        """Scratch of one forward: one buffer per (device, stream), replaced when the problem size changes."""
+        slot = ("fwd", str(device), int(torch.cuda.current_stream(device).cuda_stream))
+        with self._lock:
+            ent = self._ws.get(slot)
+            if ent is None or ent[0] != dims:
+                nb = lib.pips_workspace_bytes(*dims)
+                if nb == 0:
+                    raise _lib.PipsHipError(f"unsupported problem size {dims}")
+                self._ws.pop(slot, None)
+                ent = self._ws[slot] = (dims, torch.empty(nb // 4, dtype=torch.float32, device=device))
+            return ent[1]
+
+    def _aux(self, dev):
+        """(packed weights, frame-time table) for ``dev`` -- built or refreshed under the module lock."""
+        with self._lock:
+            arena = self._packed(dev)
+            if self._times is None or self._times.device != dev:
+                self._times = ops.times_table(dev, self.S)
+            return arena, self._times
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -195,9 +209,7 @@ class Pips(nn.Module):
         if fi is not None:
             assert tuple(fi.shape) == (B, N, self.latent_dim)
         with torch.cuda.device(dev):
-            arena = self._packed(dev)
-            if self._times is None or self._times.device != dev:
-                self._times = ops.times_table(dev, self.S)
+            arena, times = self._aux(dev)
             ws = self._workspace(lib, (B, S, H, W, N, int(self.stride)), dev)
             trajs = torch.empty(iters + 1, B, S, N, 2, dtype=f32, device=dev)
             vis_e = torch.empty(B, S, N, dtype=f32, device=dev)
@@ -211,7 +223,7 @@ class Pips(nn.Module):
                 ce_terms = torch.empty(iters, B * N * S, 2, dtype=f32, device=dev)
                 ce_ws = torch.empty(lib.pips_score_map_workspace_bytes(B, S, H8, W8) // 4, dtype=f32, device=dev)
             rc = lib.pips_forward_ce(_lib.ptr(arena), _lib.ptr(rgbs_c), _lib.ptr(xys_c), _lib.ptr(ci), _lib.ptr(fi),
-                                     _lib.ptr(self._times), B, S, H, W, N, int(self.stride), int(iters),
+                                     _lib.ptr(times), B, S, H, W, N, int(self.stride), int(iters),
                                      self._flags() | (8 if u8 else 0),
                                      _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e), _lib.ptr(ffeat),
                                      _lib.ptr(ce_tgt), _lib.ptr(ce_terms), _lib.ptr(ce_ws),
@@ -245,7 +257,7 @@ class Pips(nn.Module):
         dev, st = rgbs.device, int(self.stride)
         F = B * T
         with torch.cuda.device(dev):
-            arena = self._packed(dev)
+            arena = self._aux(dev)[0]
             frames = (rgbs.contiguous() if rgbs.dtype == torch.uint8 else rgbs.contiguous().to(torch.float32))
             frames = frames.reshape(F, 3, H, W)
             eb = bool(self._flags() & 4)
@@ -286,24 +298,23 @@ class Pips(nn.Module):
         elif cache.T != S:
             ws_i = torch.zeros(B, N, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            arena = self._packed(dev)
-            if self._times is None or self._times.device != dev:
-                self._times = ops.times_table(dev, self.S)
+            arena, times = self._aux(dev)
             fl = self._flags()
             if cache.bf16_maps and (fl & 2) and not (fl & 16):
                 fl |= 32        # PIPS_FLAG_BF16_MAPS: bf16 mixer on maps of the bf16 encoder -> the gather reads their bf16 mirror
             nb = lib.pips_track_workspace_bytes_s(B, N, S)
-            # ONE tracker workspace per device, grown on demand: chained tracking calls this with
+            # ONE tracker workspace per (device, stream), grown on demand: chained tracking calls this with
             # a different (shrinking) N at every hop
-            key = ("track", str(dev))
-            ws = self._ws.get(key)
-            if ws is None or ws.numel() * 4 < nb:
-                ws = self._ws[key] = torch.empty(nb // 4, dtype=f32, device=dev)
+            key = ("track", str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
+            with self._lock:
+                ws = self._ws.get(key)
+                if ws is None or ws.numel() * 4 < nb:
+                    ws = self._ws[key] = torch.empty(nb // 4, dtype=f32, device=dev)
             trajs = torch.empty(iters + 1, B, S, N, 2, dtype=f32, device=dev)
             vis_e = torch.empty(B, S, N, dtype=f32, device=dev)
             ffeat = torch.empty(B, N, self.latent_dim, dtype=f32, device=dev)
             rc = lib.pips_track_s(_lib.ptr(arena), _lib.ptr(cache.pyr), B, cache.T, H8, W8, _lib.ptr(xys_c), _lib.ptr(ci),
-                                  _lib.ptr(fi), _lib.ptr(ws_i), _lib.ptr(self._times), N, int(cache.stride), int(iters),
+                                  _lib.ptr(fi), _lib.ptr(ws_i), _lib.ptr(times), N, int(cache.stride), int(iters),
                                   fl, S, _lib.ptr(ws), ws.numel() * 4, _lib.ptr(trajs), _lib.ptr(vis_e),
                                   _lib.ptr(ffeat), None, None, None, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "pips_track_s")

@@ -444,3 +444,40 @@ def test_bf16_against_bf16_autocast_oracle(weights_tamed):
     print(f"bf16: HIP vs autocast oracle {e_hip_bf:.2e} px, HIP vs fp32 oracle {e_hip_32:.2e} px, "
           f"autocast oracle vs fp32 oracle {e_ref:.2e} px")
     assert e_hip_bf < 2e-2 and e_hip_32 < 2e-2
+
+
+def test_two_threads_two_streams_one_module(weights_tamed):
+    """The reference module is stateless between calls (single-threaded, but nothing forbids more): one
+    pips_amd.Pips driven from two Python threads on two streams must give each thread exactly what a serial call gives --
+    scratch memory is per (device, stream), packing and the workspace tables are under the module's lock."""
+    import threading
+    m = _model(weights_tamed, 8)
+    ins = []
+    for seed in (3, 4):
+        xys, rgbs = _config2_inputs(B=1, N=32, H=128, W=160, seed=seed)
+        ins.append((xys.to(DEV), rgbs.to(DEV)))
+    serial = [m(x, r, iters=4) for x, r in ins]
+    torch.cuda.synchronize()
+    got = [[], []]
+    errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(12):
+                    out = m(ins[i][0], ins[i][1], iters=4)
+                    got[i].append((out[0][-1], out[2]))
+            st.synchronize()
+        except Exception as e:          # surfaced below: an exception in a thread must fail the test
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert len(got[i]) == 12
+        for tr, vis in got[i]:
+            assert torch.equal(tr, serial[i][0][-1]) and torch.equal(vis, serial[i][2])
