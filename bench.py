@@ -456,8 +456,13 @@ def main(argv=None):
                     help="run ONE of the extra legs alone and print its JSON (what the rocprofv3 passes under profiles/ wrap)")
     ap.add_argument("--matmul", default="exact", choices=("exact", "split"),
                     help="config 2 only: exact-fp32 MFMA (default, the headline) or the fp32-grade split-bf16 path")
+    ap.add_argument("--lib", default=None, help="tuning only: bind pips_amd to this build of the library (tools/ab_c3.sh); the "
+                                                "driver's runs never pass it")
     args = ap.parse_args(argv)
     gpus = max(1, args.gpus)
+    if args.lib:
+        from pips_amd import _lib as _pl
+        _pl.use_library(args.lib)
     if args.leg:
         import torch
         device = torch.device("cuda", 0)

@@ -10,7 +10,7 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PIPS_LIB_PATH", os.path.join(HERE, "libpips_hip.so"))   # override: tuning builds only
+LIB_PATH = os.path.join(HERE, "libpips_hip.so")
 
 c_void_p, c_int, c_size_t, c_float = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 fp = c_void_p  # device float pointer
@@ -92,6 +92,15 @@ _lib = None
 
 class PipsHipError(RuntimeError):
     pass
+
+
+def use_library(path: str):
+    """Bind to another build of the library (tuning / trace builds of tools/).  Must be called before the first
+    ``load()``; the product never reads an environment variable for this -- tools/_tunelib.py does, for the tools."""
+    global LIB_PATH
+    if _lib is not None:
+        raise PipsHipError("pips_amd._lib.use_library: the library is already loaded")
+    LIB_PATH = path
 
 
 def load():

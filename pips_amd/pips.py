@@ -24,7 +24,6 @@ Weights are repacked for the kernels when a parameter's storage or version count
 from __future__ import annotations
 
 import ctypes as C
-import os
 import threading
 
 import torch
@@ -83,7 +82,7 @@ class Pips(nn.Module):
         # "exact": fp32 MFMA (products and sums bitwise an fmaf chain).  "split": the fp32-grade
         # split-bf16 matrix path (PIPS_FLAG_SPLIT_BF16: three exact bf16 terms per fp32 operand, six
         # bf16 products per fp32 product, fp32 accumulation) -- same accuracy class, ~1.2x faster.
-        self.matmul = os.environ.get("PIPS_MATMUL", "exact")      # process-wide default, e.g. for unmodified callers
+        self.matmul = "exact"
         self._names = list(param_table(S).keys())
         self._plist = None
         self._warned_precedence = False

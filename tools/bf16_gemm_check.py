@@ -3,6 +3,7 @@ roundings (fp32 accumulate, bf16 round, exact GELU, bf16 round): where the two d
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import _tunelib  # noqa: F401  (PIPS_LIB_PATH -> pips_amd._lib.use_library)
 from pips_amd import ops
 dev = "cuda:0"
 M, N, K = int(os.environ.get("M", 16384)), int(os.environ.get("N", 2048)), 512

@@ -3,6 +3,7 @@ PIPS_BF16_BIG hook selects, next to torch.matmul in bf16 (hipBLASLt) on the same
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import _tunelib  # noqa: F401  (PIPS_LIB_PATH -> pips_amd._lib.use_library)
 from pips_amd import ops
 from pips_amd.weights import init_state_dict
 dev = "cuda:0"

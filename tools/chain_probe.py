@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import _tunelib  # noqa: F401  (PIPS_LIB_PATH -> pips_amd._lib.use_library)
 from pips_amd import Pips, drivers
 T, H, W, N = (int(a) for a in (sys.argv[1:5] if len(sys.argv) > 4 else (100, 360, 640, 256)))
 dev = "cuda:0"

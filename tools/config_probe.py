@@ -3,6 +3,7 @@ usage: python tools/config_probe.py B H W N [grid|rand] [iters]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import _tunelib  # noqa: F401  (PIPS_LIB_PATH -> pips_amd._lib.use_library)
 from pips_amd import Pips, ops
 B, H, W, N = map(int, sys.argv[1:5])
 mode = sys.argv[5] if len(sys.argv) > 5 else "rand"

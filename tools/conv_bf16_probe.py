@@ -1,5 +1,6 @@
 import os, sys, math, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import _tunelib  # noqa: F401  (PIPS_LIB_PATH -> pips_amd._lib.use_library)
 from pips_amd import ops
 dev = "cuda:0"
 F_, H, W = 64, 184, 248

@@ -11,6 +11,7 @@ try:
     print(open("/sys/fs/cgroup/cpu.max").read().strip())
 except Exception as e:
     print("no cgroup cpu.max", e)
+import _tunelib  # noqa: F401  (PIPS_LIB_PATH -> pips_amd._lib.use_library)
 from pips_amd import Pips
 from pips_amd.weights import init_state_dict
 sd = init_state_dict(0, tamed=True); lap("init_state_dict")

@@ -3,6 +3,7 @@ launches (bin / embed / gather) on synthetic maps -- the quick form of bench.py'
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import _tunelib  # noqa: F401  (PIPS_LIB_PATH -> pips_amd._lib.use_library)
 from pips_amd import ops, _lib
 lib = _lib.load()
 dev = torch.device("cuda:0")

@@ -1,6 +1,7 @@
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
+import _tunelib  # noqa: F401  (PIPS_LIB_PATH -> pips_amd._lib.use_library)
 from pips_amd import ops
 from pips_amd.weights import init_state_dict
 arena = ops.pack_weights(init_state_dict(0, tamed=True), torch.device("cuda:0"))

@@ -2,6 +2,7 @@
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import _tunelib  # noqa: F401  (PIPS_LIB_PATH -> pips_amd._lib.use_library)
 from pips_amd import ops
 M, N, K, epi, reps = (int(v) for v in sys.argv[1:6]) if len(sys.argv) >= 6 else (2048, 2048, 512, 1, 50)
 g = torch.Generator().manual_seed(0)
