@@ -171,7 +171,7 @@ using namespace pips;
 extern "C" {
 
 const char* pips_last_error(void) { return g_err; }
-int pips_abi_version(void) { return 1; }
+int pips_abi_version(void) { return 2; }
 
 size_t pips_weight_arena_bytes(void) { return pips_weight_arena_bytes_s(PIPS_S); }
 int pips_delta_stride(int S) { return (S < 1 || S > PIPS_S_MAX) ? 0 : arena_layout(S).nout_pad; }
@@ -802,6 +802,8 @@ int pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16)
     return gemm_bf16_asm_route(g, a_bf16, out_bf16);
 }
 
+int pips_mixer_layer_route(int M) { return M > 0 ? mixer_layer_route(M) : 0; }
+
 // bf16 == 1: bf16 MFMA operands for every Linear of the mixer (weights pre-converted; the LayerNorm-2 output and the
 // 2048-wide hidden activation stored as bf16, everything else fp32); the 544-wide input projection rides
 // 32-element K blocks (544 = 17 x 32).
@@ -809,8 +811,10 @@ int pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16)
 static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                       size_t workspace_bytes, void* stream, hipEvent_t* ev, int bf16 = 0, int S = PIPS_S) {
     const bool force_fused = bf16 == 3;            // pips_mixer_fwd_bf16_fused: the fused FeedForward whatever the size
-    if (force_fused) {
-        PIPS_CHECK_ARG(M % 64 == 0, "mixer (fused FeedForward): M=%d must be a multiple of 64", M);
+    const bool force_layer = bf16 == 4;            // pips_mixer_fwd_bf16_layer: one launch per mixer layer whatever the size
+    if (force_fused || force_layer) {
+        PIPS_CHECK_ARG(M % 64 == 0, "mixer (fused layer / FeedForward): M=%d must be a multiple of 64", M);
+        PIPS_CHECK_ARG(S == PIPS_S, "mixer (fused layer / FeedForward): S = %d only", PIPS_S);
         bf16 = 1;
     }
     PIPS_CHECK_ARG(arena_v && X && delta && workspace, "mixer: null pointer");
@@ -865,13 +869,22 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
         TIMED(pips_gemm_f32(X, PIPS_KIN_PAD, arena + A.w_in, arena + A.b_in, x, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
                             EPI_BIAS, nullptr, 0, stream));
     }
+    // bf16 mixer, S = 8, large M: the whole layer (token mixing, LayerNorm-2, up-projection, GELU, down-projection, residual) is
+    // ONE launch on a 64-row block that owns its 8 particles -- xn and the hidden activation never leave the CU
+    // (ffn_fused.hip).  force_fused (pips_mixer_fwd_bf16_fused, any M % 64 == 0): the FeedForward-only form behind the
+    // separate token-mix launch, kept for the parity test of that kernel variant.
+    const int layer_route = (bf16 == 1 && S == PIPS_S && ev == nullptr) ? (force_layer ? 2 : (force_fused ? 1 : mixer_layer_route(M))) : 0;
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
-        RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1, S));
-        if (bf16 && ev == nullptr && (force_fused || ffn_fused_takes(M))) {
-            // large M: up-projection, GELU and down-projection in one launch, the hidden activation stays on the CU
+        if (layer_route == 2) {
             const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
-            RUN(launch_ffn_fused(xn, x, hw + A.f_w1[d], arena + L.b1, hw + A.f_w2[d], arena + L.b2, M, st));
+            RUN(launch_ffn_fused(arena, L, true, nullptr, x, hw + A.f_w1[d], hw + A.f_w2[d], M, st));
+            continue;
+        }
+        RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1, S));
+        if (layer_route == 1) {
+            const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
+            RUN(launch_ffn_fused(arena, L, false, xn, x, hw + A.f_w1[d], hw + A.f_w2[d], M, st));
             continue;
         }
         if (bf16) {
@@ -913,6 +926,11 @@ int pips_mixer_fwd_bf16(const void* arena_v, const float* X, int M, float* delta
 int pips_mixer_fwd_bf16_fused(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                               size_t workspace_bytes, void* stream) {
     return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 3);
+}
+
+int pips_mixer_fwd_bf16_layer(const void* arena_v, const float* X, int M, float* delta, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 4);
 }
 
 int pips_mixer_fwd_x3(const void* arena_v, const float* X, int M, float* delta, void* workspace,

@@ -248,9 +248,11 @@ int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_
 int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16);   // 0 register-staged, 1 / 2 the assembly kernels
 // fused channel-mix FeedForward of the bf16 mixer at large M (ffn_fused.hip): weights in fragment-major packing
 int launch_pack_frag(const void* src_bf16, void* dst, int N, int K, hipStream_t st);
-bool ffn_fused_takes(int M);
-int launch_ffn_fused(const void* xn_bf16, float* x, const void* w1_frag, const float* b1, const void* w2_frag, const float* b2,
-                     int M, hipStream_t st);
+struct MixLayerW;
+// 0 = token-mix launch + two GEMMs, 1 = token-mix launch + fused FeedForward (tuning builds only), 2 = the whole layer in one launch
+int mixer_layer_route(int M);
+int launch_ffn_fused(const float* arena, const MixLayerW& L, bool tokmix, const void* xn_bf16, float* x, const void* w1_frag,
+                     const void* w2_frag, int M, hipStream_t st);
 // split-bf16 (bf16x3) fp32-grade GEMM / conv (gemm_x3.hip): A fp32, W = three bf16 planes [3][N][K]
 int launch_split_bf16x3(const float* src, size_t n, void* dst, hipStream_t st);
 int launch_gemm_x3(const GemmArgs& a, hipStream_t st);

@@ -23,6 +23,7 @@
 // Per CU and layer: 4 MiB of weights from L2 (64 B/clk = 65 k clocks, as many as the 8192 MFMAs take), 64 KiB of xn and
 // 2 x 128 KiB of x from / to HBM.
 #include "common.h"
+#include "token_mix_mfma.h"
 
 namespace pips {
 
@@ -78,8 +79,14 @@ int launch_pack_frag(const void* src_bf16, void* dst, int N, int K, hipStream_t 
     return PIPS_OK;
 }
 
-__global__ __launch_bounds__(256) void ffn_fused_kernel(const unsigned short* __restrict__ xn, float* __restrict__ x,
-                                                        const uint4* __restrict__ w1f, const float* __restrict__ b1,
+// TOKMIX = true: the WHOLE mixer layer (nets/pips.py:115-118) in this launch -- token mixing + LayerNorm-2 as the prologue
+// (token_mix_mfma.h: each of the four waves takes two of the block's eight particles, side by side), the new residual
+// rows go to x (this block re-reads them as the down-projection's accumulator seed: they are its own rows, L2-hot) and the
+// LayerNorm-2 output straight into the LDS tile the up-projection reads -- xn never exists in memory.  The weight ring is
+// requested before the prologue, so the first 64 KiB of W1 arrive under it.  `xn` is unused then.
+template <bool TOKMIX>
+__global__ __launch_bounds__(256) void ffn_fused_kernel(const float* __restrict__ arena, MixLayerW L, const unsigned short* __restrict__ xn,
+                                                        float* __restrict__ x, const uint4* __restrict__ w1f, const float* __restrict__ b1,
                                                         const uint4* __restrict__ w2f, const float* __restrict__ b2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* XN = smem;
@@ -123,15 +130,27 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const unsigned short* __
 #pragma unroll
     for (int f = 0; f < FF_RING; ++f) wq[f] = ld(base_u(0), f, true);
 
-    // ---- xn tile -> LDS (rows padded by 16 B)
+    if (TOKMIX) {
+        // ---- token mixing of particles 2 wave, 2 wave + 1 of the block (tile rows 16 wave .. 16 wave + 15)
+        float* const xp[2] = {x + (row0 + 16 * wave + 4 * half) * FF_D + 4 * l31, x + (row0 + 16 * wave + 8 + 4 * half) * FF_D + 4 * l31};
+        char* const xr = XN + (16 * wave + 4 * half) * FF_XN_PITCH + 8 * l31;
+        token_mix_mfma_particles<2>(arena, L, xp, [&](int i, int r, int g, uint2 v) __attribute__((always_inline)) {
+            *reinterpret_cast<uint2*>(xr + (8 * i + r) * FF_XN_PITCH + g * 256) = v;
+        }, l31, half);
+        // the block's other waves read these rows of x below (the down-projection's seed)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    } else {
+        // ---- xn tile -> LDS (rows padded by 16 B)
 #pragma unroll
-    for (int it = 0; it < FF_ROWS * (FF_D / 8) / 256; ++it) {
-        const int i = tid + it * 256, r = i >> 6, cc = i & 63;
-        *reinterpret_cast<uint4*>(XN + r * FF_XN_PITCH + cc * 16) = *reinterpret_cast<const uint4*>(xn + (row0 + r) * FF_D + cc * 8);
+        for (int it = 0; it < FF_ROWS * (FF_D / 8) / 256; ++it) {
+            const int i = tid + it * 256, r = i >> 6, cc = i & 63;
+            *reinterpret_cast<uint4*>(XN + r * FF_XN_PITCH + cc * 16) = *reinterpret_cast<const uint4*>(xn + (row0 + r) * FF_D + cc * 8);
+        }
     }
     f32x16 ax[2][4];
     float* xrow = x + (row0 + l31) * FF_D + 128 * wave + 4 * half;
     __syncthreads();
+    if (TOKMIX) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     f32x16 au[2][2];
     const char* xa = XN + l31 * FF_XN_PITCH + half * 16;              // A fragment of row tile i, K step kt: + i*32*pitch + kt*32
@@ -243,24 +262,37 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const unsigned short* __
                     make_float4(ax[i][j][4 * g], ax[i][j][4 * g + 1], ax[i][j][4 * g + 2], ax[i][j][4 * g + 3]);
 }
 
-// Whether the bf16 mixer takes the fused FeedForward by itself for M rows.  NOT by default: end to end (same box, same call,
-// BASELINE configs[2]) the two assembly GEMMs are 1-2 % ahead -- 14.52 / 14.57 ms against 14.71 / 14.72 ms per forward -- although
-// rocprofv3 reads 90.7 us for this kernel against 49.9 + 47.5 us for the pair.  pips_mixer_fwd_bf16_fused
-// forces it (parity test, tools/ffn_probe.py).
-bool ffn_fused_takes(int M) {
-    if (!PIPS_TUNE("PIPS_FFN_FUSED", 0) || M % FF_ROWS != 0) return false;
-    const int cus = device_cus(), min_blocks = PIPS_TUNE("PIPS_FFN_MIN_BLOCKS", 0);        // tuning hook: take smaller problems too
-    return cus > 0 && M / FF_ROWS >= (min_blocks > 0 ? min_blocks : cus);
+// Whether the bf16 mixer runs each layer as ONE launch (token mixing + FeedForward, ffn_fused_kernel<true>) for M rows: from one
+// 64-row block per CU (M = 16384 on 256 CUs: BASELINE configs[2]'s per-GPU share).  Tuning builds: PIPS_MIXER_LAYER=0/1 forces
+// the answer, PIPS_FFN_FUSED=1 selects the FeedForward-only form behind the separate token-mix launch (round 3's measured
+// alternative: 1-2 % behind the two assembly GEMMs end to end).
+int mixer_layer_route(int M) {
+    if (M % FF_ROWS != 0) return 0;
+    const int cus = device_cus();
+    const bool big = cus > 0 && M / FF_ROWS >= cus;
+    const int force = PIPS_TUNE("PIPS_MIXER_LAYER", -1);
+    if (force == 1 || (force < 0 && big)) return 2;              // whole layer
+    if (PIPS_TUNE("PIPS_FFN_FUSED", 0)) {
+        const int min_blocks = PIPS_TUNE("PIPS_FFN_MIN_BLOCKS", 0);
+        if (cus > 0 && M / FF_ROWS >= (min_blocks > 0 ? min_blocks : cus)) return 1;   // FeedForward only
+    }
+    return 0;
 }
 
-int launch_ffn_fused(const void* xn_bf16, float* x, const void* w1_frag, const float* b1, const void* w2_frag, const float* b2,
-                     int M, hipStream_t st) {
+int launch_ffn_fused(const float* arena, const MixLayerW& L, bool tokmix, const void* xn_bf16, float* x, const void* w1_frag,
+                     const void* w2_frag, int M, hipStream_t st) {
     PIPS_CHECK_ARG(M > 0 && M % FF_ROWS == 0, "ffn_fused: M=%d must be a multiple of %d", M, FF_ROWS);
-    static std::atomic<unsigned long long> raised{0};
-    const int rc = ensure_dynamic_lds(raised, (const void*)ffn_fused_kernel, FF_LDS);
+    static std::atomic<unsigned long long> raised0{0}, raised1{0};
+    const void* fn = tokmix ? (const void*)ffn_fused_kernel<true> : (const void*)ffn_fused_kernel<false>;
+    const int rc = ensure_dynamic_lds(tokmix ? raised1 : raised0, fn, FF_LDS);
     if (rc != PIPS_OK) return rc;
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3(M / FF_ROWS), dim3(256), FF_LDS, st, reinterpret_cast<const unsigned short*>(xn_bf16), x,
-                       reinterpret_cast<const uint4*>(w1_frag), b1, reinterpret_cast<const uint4*>(w2_frag), b2);
+    if (tokmix)
+        hipLaunchKernelGGL(ffn_fused_kernel<true>, dim3(M / FF_ROWS), dim3(256), FF_LDS, st, arena, L, nullptr, x,
+                           reinterpret_cast<const uint4*>(w1_frag), arena + L.b1, reinterpret_cast<const uint4*>(w2_frag), arena + L.b2);
+    else
+        hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3(M / FF_ROWS), dim3(256), FF_LDS, st, arena, L,
+                           reinterpret_cast<const unsigned short*>(xn_bf16), x, reinterpret_cast<const uint4*>(w1_frag), arena + L.b1,
+                           reinterpret_cast<const uint4*>(w2_frag), arena + L.b2);
     PIPS_CHECK_LAUNCH("ffn_fused_kernel");
     return PIPS_OK;
 }
