@@ -271,7 +271,8 @@ int mixer_layer_route(int M) {
     const int cus = device_cus();
     const bool big = cus > 0 && M / FF_ROWS >= cus;
     const int force = PIPS_TUNE("PIPS_MIXER_LAYER", -1);
-    if (force == 1 || (force < 0 && big)) return 2;              // whole layer
+    (void)big;
+    if (force == 1) return 2;                                    // whole layer (tuning builds only: measured SLOWER)
     if (PIPS_TUNE("PIPS_FFN_FUSED", 0)) {
         const int min_blocks = PIPS_TUNE("PIPS_FFN_MIN_BLOCKS", 0);
         if (cus > 0 && M / FF_ROWS >= (min_blocks > 0 ? min_blocks : cus)) return 1;   // FeedForward only
