@@ -79,7 +79,8 @@ extern "C" {
 const char* pips_last_error(void);
 /* 2 (round 4).  History: 1 -> 2: the pyramid buffer of EVERY encoder mode is pips_pyramid_floats() long (the bf16 encoder writes
  * a bf16 mirror of the four levels behind them, at pips_pyramid_mirror_offset -- a buffer sized from the level offsets alone
- * is too short); the bf16 mixer needs the arena's PIPS_PACK_FFN section; pips_mixer_layer_route / pips_mixer_fwd_bf16_layer. */
+ * is too short); the PIPS_PACK_FFN arena section and pips_mixer_fwd_bf16_fused (round 3's fused FeedForward, measured slower than
+ * the two GEMMs again in round 4 -- tools/experiments/) are gone. */
 int         pips_abi_version(void);
 
 /* ---- weights ------------------------------------------------------------------------
@@ -98,7 +99,6 @@ int    pips_repack_weights(const void* const* params_host, int nparams, void* ar
 #define PIPS_PACK_FP32  1
 #define PIPS_PACK_BF16  2
 #define PIPS_PACK_SPLIT 4
-#define PIPS_PACK_FFN   8   /* the channel-mix weights in the fragment-stream order of pips_mixer_fwd_bf16_fused (implies PIPS_PACK_BF16) */
 int    pips_repack_weights_ex(const void* const* params_host, int nparams, void* arena, int sections, void* stream);
 
 /* ---- any window length: Pips(S != 8) ----------------------------------------------------
@@ -230,24 +230,9 @@ int    pips_mixer_fwd(const void* arena, const float* X, int M, float* delta,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same with bf16 MFMA operands (PIPS_FLAG_BF16_MIXER): weights converted once at pack time,
- * activations rounded to bf16 (RNE) as they are staged, fp32 accumulation and epilogues.  The arena needs its PIPS_PACK_BF16
- * AND PIPS_PACK_FFN sections (pips_repack_weights builds all): from pips_mixer_layer_route(M) == 2 on, every mixer layer
- * (nets/pips.py:115-118: token mixing, LayerNorm, 512 -> 2048 -> 512 FeedForward, both residuals) is ONE launch on a 64-row
- * block that owns its 8 particles (csrc/ffn_fused.hip) and reads the channel-mix weights in the fragment order of that section. */
+ * activations rounded to bf16 (RNE) as they are staged, fp32 accumulation and epilogues. */
 int    pips_mixer_fwd_bf16(const void* arena, const float* X, int M, float* delta,
                            void* workspace, size_t workspace_bytes, void* stream);
-/* Which form the bf16 mixer (pips_mixer_fwd_bf16, pips_forward with PIPS_FLAG_BF16_MIXER, S = 8) takes for M = B*N*8 rows:
- * 0 = per layer a token-mix launch + two GEMMs, 2 = one launch per layer (M % 64 == 0 and at least one 64-row block per
- * compute unit: M >= 16384 on an MI355X).  Host function; needs a current device.  The bf16 numerics depend on M through it. */
-int    pips_mixer_layer_route(int M);
-/* The FeedForward-only form of that kernel behind the separate token-mix launch, whatever the size (M % 64 == 0; arena section
- * PIPS_PACK_FFN): round 3's measured alternative to the two GEMMs, kept as the parity test of that kernel variant. */
-int    pips_mixer_fwd_bf16_fused(const void* arena, const float* X, int M, float* delta,
-                                 void* workspace, size_t workspace_bytes, void* stream);
-/* pips_mixer_fwd_bf16 with the one-launch-per-layer form forced whatever the size (M % 64 == 0): what pips_mixer_fwd_bf16
- * itself takes from pips_mixer_layer_route(M) == 2 on; lets a test reach that kernel with a few particles. */
-int    pips_mixer_fwd_bf16_layer(const void* arena, const float* X, int M, float* delta,
-                                 void* workspace, size_t workspace_bytes, void* stream);
 /* Same with every GEMM on the split-bf16 (bf16x3) path: fp32-grade results, see pips_gemm_f32x3. */
 int    pips_mixer_fwd_x3(const void* arena, const float* X, int M, float* delta,
                          void* workspace, size_t workspace_bytes, void* stream);

@@ -64,8 +64,6 @@ SIGNATURES = {
     "pips_mixer_workspace_bytes": (c_size_t, [c_int]),
     "pips_mixer_fwd": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_bf16": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
-    "pips_mixer_fwd_bf16_fused": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
-    "pips_mixer_fwd_bf16_layer": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_x3": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_timed": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p, C.POINTER(c_float)]),
     "pips_mixer_fwd_timed_ex": (c_int, [c_void_p, fp, c_int, c_int, fp, c_void_p, c_size_t, c_void_p,
@@ -77,7 +75,6 @@ SIGNATURES = {
     "pips_gemm_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, fp, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, fp, c_int,
                        c_void_p]),
     "pips_gemm_bf16_route": (c_int, [c_int] * 6),
-    "pips_mixer_layer_route": (c_int, [c_int]),
     "pips_conv_nhwc_bf16": (c_int, [fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp,
                                     C.POINTER(c_int), c_void_p]),
     "pips_conv_nhwc_bf16_maps": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int,

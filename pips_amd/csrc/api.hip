@@ -91,8 +91,6 @@ static ArenaLayout build_layout(int S) {
     for (int i = 1; i < 22; ++i) A.h_conv[i] = take_h((size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
     A.h_in = take_h((size_t)PIPS_DMIX * PIPS_KIN_PAD);
     for (int d = 0; d < PIPS_DEPTH; ++d) {
-        A.f_w1[d] = take_h((size_t)4 * PIPS_DMIX * PIPS_DMIX);
-        A.f_w2[d] = take_h((size_t)4 * PIPS_DMIX * PIPS_DMIX);
     }
     A.total_h = hoff;
     size_t toff = 0;
@@ -181,7 +179,7 @@ size_t pips_weight_arena_bytes_s(int S) {
 }
 
 int pips_repack_weights(const void* const* params, int nparams, void* arena_v, void* stream) {
-    return pips_repack_weights_s(params, nparams, arena_v, PIPS_S, PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT | PIPS_PACK_FFN, stream);
+    return pips_repack_weights_s(params, nparams, arena_v, PIPS_S, PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT, stream);
 }
 int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v, int sections, void* stream) {
     return pips_repack_weights_s(params, nparams, arena_v, PIPS_S, sections, stream);
@@ -190,8 +188,7 @@ int pips_repack_weights_ex(const void* const* params, int nparams, void* arena_v
 int pips_repack_weights_s(const void* const* params, int nparams, void* arena_v, int S, int sections, void* stream) {
     PIPS_CHECK_ARG(arena_v != nullptr, "repack: null pointer");
     PIPS_CHECK_ARG(S >= 1 && S <= PIPS_S_MAX, "repack: S=%d outside 1..%d", S, PIPS_S_MAX);
-    PIPS_CHECK_ARG(sections != 0 && (sections & ~(PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT | PIPS_PACK_FFN)) == 0, "repack: bad section mask %d", sections);
-    if (sections & PIPS_PACK_FFN) sections |= PIPS_PACK_BF16;        // re-ordered from the bf16 copies
+    PIPS_CHECK_ARG(sections != 0 && (sections & ~(PIPS_PACK_FP32 | PIPS_PACK_BF16 | PIPS_PACK_SPLIT)) == 0, "repack: bad section mask %d", sections);
     hipStream_t st = (hipStream_t)stream;
     const ArenaLayout& A = arena_layout(S);
     float* arena = (float*)arena_v;
@@ -256,14 +253,6 @@ int pips_repack_weights_s(const void* const* params, int nparams, void* arena_v,
 
     for (int i = 1; i < 22; ++i)
         to_h(A.conv[i].w, A.h_conv[i], (size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
-  }
-  if (sections & PIPS_PACK_FFN) {
-    // the channel-mix weights once more, in the fragment-stream order of ffn_fused.hip (from the bf16 copies)
-    __bf16* hb = reinterpret_cast<__bf16*>(arena + A.total);
-    for (int d = 0; d < PIPS_DEPTH; ++d) {
-        (void)launch_pack_frag(hb + A.h_w1[d], hb + A.f_w1[d], 4 * PIPS_DMIX, PIPS_DMIX, st);
-        (void)launch_pack_frag(hb + A.h_w2[d], hb + A.f_w2[d], PIPS_DMIX, 4 * PIPS_DMIX, st);
-    }
   }
   if (sections & PIPS_PACK_SPLIT) {
     // split-bf16 planes of the same weights (fp32-grade matrix path on the bf16 cores), from the fp32 section
@@ -802,21 +791,12 @@ int pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16)
     return gemm_bf16_asm_route(g, a_bf16, out_bf16);
 }
 
-int pips_mixer_layer_route(int M) { return M > 0 ? mixer_layer_route(M) : 0; }
-
 // bf16 == 1: bf16 MFMA operands for every Linear of the mixer (weights pre-converted; the LayerNorm-2 output and the
 // 2048-wide hidden activation stored as bf16, everything else fp32); the 544-wide input projection rides
 // 32-element K blocks (544 = 17 x 32).
 // S: the window length the arena was packed for (tokens per particle); delta rows are nout_pad(S) wide.
 static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                       size_t workspace_bytes, void* stream, hipEvent_t* ev, int bf16 = 0, int S = PIPS_S) {
-    const bool force_fused = bf16 == 3;            // pips_mixer_fwd_bf16_fused: the fused FeedForward whatever the size
-    const bool force_layer = bf16 == 4;            // pips_mixer_fwd_bf16_layer: one launch per mixer layer whatever the size
-    if (force_fused || force_layer) {
-        PIPS_CHECK_ARG(M % 64 == 0, "mixer (fused layer / FeedForward): M=%d must be a multiple of 64", M);
-        PIPS_CHECK_ARG(S == PIPS_S, "mixer (fused layer / FeedForward): S = %d only", PIPS_S);
-        bf16 = 1;
-    }
     PIPS_CHECK_ARG(arena_v && X && delta && workspace, "mixer: null pointer");
     PIPS_CHECK_ARG(S >= 1 && S <= PIPS_S_MAX, "mixer: S=%d outside 1..%d", S, PIPS_S_MAX);
     PIPS_CHECK_ARG(M > 0 && M % S == 0, "mixer: M=%d must be a positive multiple of S=%d", M, S);
@@ -869,24 +849,9 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
         TIMED(pips_gemm_f32(X, PIPS_KIN_PAD, arena + A.w_in, arena + A.b_in, x, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
                             EPI_BIAS, nullptr, 0, stream));
     }
-    // bf16 mixer, S = 8, large M: the whole layer (token mixing, LayerNorm-2, up-projection, GELU, down-projection, residual) is
-    // ONE launch on a 64-row block that owns its 8 particles -- xn and the hidden activation never leave the CU
-    // (ffn_fused.hip).  force_fused (pips_mixer_fwd_bf16_fused, any M % 64 == 0): the FeedForward-only form behind the
-    // separate token-mix launch, kept for the parity test of that kernel variant.
-    const int layer_route = (bf16 == 1 && S == PIPS_S && ev == nullptr) ? (force_layer ? 2 : (force_fused ? 1 : mixer_layer_route(M))) : 0;
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
-        if (layer_route == 2) {
-            const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
-            RUN(launch_ffn_fused(arena, L, true, nullptr, x, hw + A.f_w1[d], hw + A.f_w2[d], M, st));
-            continue;
-        }
         RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1, S));
-        if (layer_route == 1) {
-            const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
-            RUN(launch_ffn_fused(arena, L, false, xn, x, hw + A.f_w1[d], hw + A.f_w2[d], M, st));
-            continue;
-        }
         if (bf16) {
             const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
             TIMED(gemm_h(xn, 1, PIPS_DMIX, hw + A.h_w1[d], arena + L.b1, h, 1, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX,
@@ -921,16 +886,6 @@ int pips_mixer_fwd(const void* arena_v, const float* X, int M, float* delta, voi
 int pips_mixer_fwd_bf16(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                         size_t workspace_bytes, void* stream) {
     return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 1);
-}
-
-int pips_mixer_fwd_bf16_fused(const void* arena_v, const float* X, int M, float* delta, void* workspace,
-                              size_t workspace_bytes, void* stream) {
-    return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 3);
-}
-
-int pips_mixer_fwd_bf16_layer(const void* arena_v, const float* X, int M, float* delta, void* workspace,
-                              size_t workspace_bytes, void* stream) {
-    return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, 4);
 }
 
 int pips_mixer_fwd_x3(const void* arena_v, const float* X, int M, float* delta, void* workspace,

@@ -246,13 +246,6 @@ bool conv3x3_c64_takes(int H, int W, int frames);      // whether that kernel ta
 // the config-3 up-projection as persistent blocks with a generated-assembly tile body (gemm_bf16_asm.hip); 1 = not taken
 int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
 int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16);   // 0 register-staged, 1 / 2 the assembly kernels
-// fused channel-mix FeedForward of the bf16 mixer at large M (ffn_fused.hip): weights in fragment-major packing
-int launch_pack_frag(const void* src_bf16, void* dst, int N, int K, hipStream_t st);
-struct MixLayerW;
-// 0 = token-mix launch + two GEMMs, 1 = token-mix launch + fused FeedForward (tuning builds only), 2 = the whole layer in one launch
-int mixer_layer_route(int M);
-int launch_ffn_fused(const float* arena, const MixLayerW& L, bool tokmix, const void* xn_bf16, float* x, const void* w1_frag,
-                     const void* w2_frag, int M, hipStream_t st);
 // split-bf16 (bf16x3) fp32-grade GEMM / conv (gemm_x3.hip): A fp32, W = three bf16 planes [3][N][K]
 int launch_split_bf16x3(const float* src, size_t n, void* dst, hipStream_t st);
 int launch_gemm_x3(const GemmArgs& a, hipStream_t st);
@@ -272,7 +265,6 @@ struct ArenaLayout {
     // bf16 copies of the big Linear weights for the bf16-operand mixer, in ushort units from
     // the end of the fp32 section (arena + total)
     size_t h_w1[PIPS_DEPTH], h_w2[PIPS_DEPTH], h_head, h_conv[22], h_in, total_h;
-    size_t f_w1[PIPS_DEPTH], f_w2[PIPS_DEPTH];      // the channel-mix weights once more, fragment-major (ffn_fused.hip); same section
     // split-bf16 planes [3][N][K] of every matrix-core weight (gemm_x3.hip), in ushort units from
     // the end of the bf16 section
     size_t t_in, t_w1[PIPS_DEPTH], t_w2[PIPS_DEPTH], t_head, t_conv[22], total_t;

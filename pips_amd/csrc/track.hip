@@ -4,7 +4,6 @@
 // for coalesced 512-byte channel-last reads and 64-lane waves.
 // State tensors are particle-major: row m = (b*N + n)*8 + s.
 #include "common.h"
-#include "token_mix_mfma.h"
 
 namespace pips {
 
@@ -443,6 +442,41 @@ __device__ __forceinline__ void ln_stats(const float (&x0)[S], const float (&x1)
 // channels per thread in packed float2 arithmetic (v_pk_fma_f32), the eight per-token wave sums of
 // every LayerNorm pass in one transpose-reduce, cross-wave combination through 32 floats of LDS.
 
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, BANK_MASK, false));
+}
+// Eight wave sums at once by transpose-reduce: three exchange steps (lane^1, ^2, ^4) in which a lane
+// keeps the half of its values that matches its lane bit and adds the partner's copy of it -- 8 -> 4
+// -> 2 -> 1 value per lane -- then three plain steps (^8, ^16, ^32).  Lane l returns the sum over the
+// wave of v[l & 7]: 26 instructions against ~200 for eight separate wave reductions.  DPP quad_perm /
+// row_shl / row_shr / row_ror within rows, ds_swizzle across rows, one bpermute across the halves.
+// (Neutral at B=1, where one block per CU leaves the kernel latency-bound; -20 % at 2048+ particles,
+// where it is VALU-issue bound.)
+__device__ __forceinline__ float wave_sum8(const float (&v)[S]) {
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float w[4], x[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
+        w[i] = keep + dpp_mov<0xB1, 0xf>(0.f, send);                   // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = b1 ? w[2 * j + 1] : w[2 * j], send = b1 ? w[2 * j] : w[2 * j + 1];
+        x[j] = keep + dpp_mov<0x4E, 0xf>(0.f, send);                   // quad_perm [2,3,0,1]
+    }
+    const float keep = b2 ? x[1] : x[0], send = b2 ? x[0] : x[1];
+    float recv = dpp_mov<0x104, 0x5>(0.f, send);                       // row_shl:4 into lanes 0-3, 8-11
+    recv = dpp_mov<0x114, 0xa>(recv, send);                            // row_shr:4 into lanes 4-7, 12-15
+    float y = keep + recv;
+    y += dpp_mov<0x128, 0xf>(0.f, y);                                  // row_ror:8  (lane ^ 8)
+    y += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(y), 0x401F));   // lane ^ 16
+    y += __shfl_xor(y, 32);
+    return y;
+}
+
 // sums of 8 per-token values over the 256 threads of the block; red is [S][4 waves].  Lane l returns the block total of
 // token l & 7 (one 16-byte LDS read per lane instead of eight; the callers finish the statistic in that lane and hand
 // it to the wave with v_readlane, which also leaves means and scales in scalar registers)
@@ -455,6 +489,17 @@ __device__ __forceinline__ float block_sum8_dpp(const float (&v)[S], float (*red
     const float4 r = *reinterpret_cast<const float4*>(red[lane & 7]);
     return (r.x + r.y) + (r.z + r.w);
 }
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// 1/sqrt(v) for v >= eps: v_rsq_f32 (1 ulp) + one Newton step -- 5 instructions where the IEEE 1.0f / sqrtf(v) of the
+// compiler is ~30 (denormal scaling, div_scale / div_fmas / div_fixup); every thread needs it 16 times per launch
+__device__ __forceinline__ float rsqrt_nr(float v) {
+    const float r = __builtin_amdgcn_rsqf(v);
+    return r * fmaf(-0.5f * v * r, r, 1.5f);
+}
+
 // two-pass LayerNorm statistics (mean, then centred squares) of 8 tokens x 512 channels, 2 channels per thread
 __device__ __forceinline__ void ln_stats2(const f2 (&x)[S], float (&mean)[S], float (&rstd)[S], float (*red)[4]) {
     float a[S];
@@ -538,130 +583,152 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// token_mix_kernel with the token MLP's 512 fp32 FMAs per channel on the matrix cores, EXACT fp32: v_mfma_f32_4x4x1_16B_f32
-// is sixteen independent 4 x 4 outer products per instruction -- D_b[i][j] += A_b[i] * B_b[j], one fused multiply-add per
-// element, lane 4b + j holding column j of block b in four registers (rows i).  With B = the lane's own channel value and A =
-// four weights that depend on (lane & 3) only,
-//     H[4 hg + i][ch(lane)] += W0[4 hg + i][t] * xn[t][ch(lane)]            (8 tokens x 8 hidden groups  = 64 instructions)
-//     Y[4 tg + i][ch(lane)] += W3[4 tg + i][j] * gelu(H)[j][ch(lane)]       (32 hidden x 2 token groups = 64 instructions)
-// every lane ends up with the 32 hidden units / 8 tokens of ITS channel in registers: lane = channel exactly as in the VALU
-// form, no padding (a 32x32x2 tile would spend 3/4 of the second product on zero rows), the same summation order (tokens /
-// hidden units ascending onto the bias), so the result is what the fmaf loop of token_mix_kernel gives.  The matrix pipe has
-// the same fp32 peak as the packed vector FMAs (157 TF); what this buys is the VECTOR pipe: 512 of the kernel's ~2 000
-// vector instructions per wave (the half-rate packed FMAs) leave it, and the GELU / LayerNorm work of one channel set runs
-// beside the MFMAs of the other.  Thread = channels 2 tid, 2 tid + 1 = channel sets 0 / 1 of its lane.
-typedef float f32x4_tm __attribute__((ext_vector_type(4)));
+// The same layer step for the bf16-operand mixer (BASELINE configs[2]) with the token MLP on the matrix cores.  Under
+// torch.autocast the token-mixing Conv1d layers (nets/pips.py:102-109,117) take bf16 operands like every other Linear, so
+// the 8 -> 32 -> 8 MLP per channel runs as three v_mfma_f32_32x32x16_bf16 per 32 channels instead of 512 fp32 FMAs per
+// channel (1 456 packed VALU instructions per thread in token_mix_kernel, which is VALU-bound at 2048 particles: 35 us):
+//   H[32 hidden][32 ch] = W0[32][8 tok -> K = 16, zero padded] * Xn[tok][ch]        (1 MFMA; N = channels)
+//   Y[8 tok -> M = 32][32 ch] = W3[tok][32 hidden] * gelu(H + b0)                    (2 MFMAs of K = 16)
+// A lane owns 4 tokens (lanes 0-31: tokens 0-3, lanes 32-63: tokens 4-7) x 4 channels (c0 = 128*wave + 4*(lane & 31)):
+// the fp32 loads are float4s, the MFMA for channel slot q takes the lane's four tokens of channel c0+q as its K values, H
+// comes back with this lane's channel in all 16 registers (hidden units m(r) = (r&3) + 8(r>>2) + 4*half) -- exactly the K
+// values the second product wants from this lane once W3's columns are permuted the same way -- and Y's rows 0-7 are the
+// lane's own four tokens again: no cross-lane traffic between the three products.  LayerNorm statistics in one pass
+// (sum, sum of squares; the operands are rounded to bf16 anyway), fp32 residual stream.
+typedef __bf16 bf16x8_tm __attribute__((ext_vector_type(8)));
 
-template <bool XN_BF16>
-__global__ __launch_bounds__(256, 2) void token_mix_f32mfma_kernel(const float* __restrict__ arena, MixLayerW L,
-                                                                   float* __restrict__ x, float* __restrict__ xn) {
-    __shared__ __attribute__((aligned(16))) float red[S][4];
-    __shared__ __attribute__((aligned(16))) float wsm[32 * 8 + 32 + 8 * 32 + 8];
-    const int tid = threadIdx.x;
-    float* xp = x + (size_t)blockIdx.x * S * PIPS_DMIX + 2 * tid;
-    float* xnp = xn + (size_t)blockIdx.x * S * PIPS_DMIX + 2 * tid;
-    f2 xv[S];
-    float mean[S], rstd[S];
-#pragma unroll
-    for (int t = 0; t < S; ++t) xv[t] = *reinterpret_cast<const f2*>(xp + t * PIPS_DMIX);
-    const f2 g1 = *reinterpret_cast<const f2*>(arena + L.ln1g + 2 * tid), be1 = *reinterpret_cast<const f2*>(arena + L.ln1b + 2 * tid);
-    const f2 g2 = *reinterpret_cast<const f2*>(arena + L.ln2g + 2 * tid), be2 = *reinterpret_cast<const f2*>(arena + L.ln2b + 2 * tid);
-    {   // w0[32][8], b0[32], w3[8][32], b3[8] -> LDS (all four values requested before the first is stored)
-        const float w0v = arena[L.tw0 + tid], w3v = arena[L.tw3 + tid];
-        const float b0v = arena[L.tb0 + (tid & 31)], b3v = arena[L.tb3 + (tid & 7)];
-        wsm[tid] = w0v;
-        wsm[288 + tid] = w3v;
-        if (tid < 32) wsm[256 + tid] = b0v;
-        if (tid >= 64 && tid < 72) wsm[544 + (tid - 64)] = b3v;
-    }
-    ln_stats2(xv, mean, rstd, red);          // (its barriers also publish wsm)
-
-    // A operands: the lane's row (lane & 3) of every 4-row weight block
-    const int l3 = tid & 3;
-    float wa0[8][S], wa3[2][32];
-#pragma unroll
-    for (int hg = 0; hg < 8; ++hg) {
-        const float4 p = *reinterpret_cast<const float4*>(&wsm[(4 * hg + l3) * 8]), q = *reinterpret_cast<const float4*>(&wsm[(4 * hg + l3) * 8 + 4]);
-        wa0[hg][0] = p.x; wa0[hg][1] = p.y; wa0[hg][2] = p.z; wa0[hg][3] = p.w;
-        wa0[hg][4] = q.x; wa0[hg][5] = q.y; wa0[hg][6] = q.z; wa0[hg][7] = q.w;
-    }
-#pragma unroll
-    for (int tg = 0; tg < 2; ++tg)
-#pragma unroll
-        for (int j = 0; j < 32; j += 4) {
-            const float4 p = *reinterpret_cast<const float4*>(&wsm[288 + (4 * tg + l3) * 32 + j]);
-            wa3[tg][j] = p.x; wa3[tg][j + 1] = p.y; wa3[tg][j + 2] = p.z; wa3[tg][j + 3] = p.w;
-        }
-    f2 h[S], y[S];
-#pragma unroll
-    for (int t = 0; t < S; ++t) h[t] = (xv[t] - (f2){mean[t], mean[t]}) * (g1 * (f2){rstd[t], rstd[t]}) + be1;
-
-    f32x4_tm H[2][8];
-#pragma unroll
-    for (int hg = 0; hg < 8; ++hg) {
-        const float4 b = *reinterpret_cast<const float4*>(&wsm[256 + 4 * hg]);
-        H[0][hg] = H[1][hg] = (f32x4_tm){b.x, b.y, b.z, b.w};
-    }
-#pragma unroll
-    for (int cs = 0; cs < 2; ++cs)
-#pragma unroll
-        for (int t = 0; t < S; ++t)
-#pragma unroll
-            for (int hg = 0; hg < 8; ++hg)
-                H[cs][hg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa0[hg][t], cs ? h[t].y : h[t].x, H[cs][hg], 0, 0, 0);
-    f32x4_tm Y[2][2];
-    {
-        const float4 b3a = *reinterpret_cast<const float4*>(&wsm[544]), b3b = *reinterpret_cast<const float4*>(&wsm[548]);
-        Y[0][0] = Y[1][0] = (f32x4_tm){b3a.x, b3a.y, b3a.z, b3a.w};
-        Y[0][1] = Y[1][1] = (f32x4_tm){b3b.x, b3b.y, b3b.z, b3b.w};
-    }
-#pragma unroll
-    for (int cs = 0; cs < 2; ++cs)
-#pragma unroll
-        for (int hg = 0; hg < 8; ++hg) {
-            const f2 ga = gelu_exact2((f2){H[cs][hg][0], H[cs][hg][1]}), gb = gelu_exact2((f2){H[cs][hg][2], H[cs][hg][3]});
-            const float gl[4] = {ga.x, ga.y, gb.x, gb.y};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int tg = 0; tg < 2; ++tg)
-                    Y[cs][tg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa3[tg][4 * hg + i], gl[i], Y[cs][tg], 0, 0, 0);
-        }
-#pragma unroll
-    for (int t = 0; t < S; ++t) y[t] = (f2){Y[0][t >> 2][t & 3], Y[1][t >> 2][t & 3]} + xv[t];
-
-    ln_stats2(y, mean, rstd, red);
-#pragma unroll
-    for (int t = 0; t < S; ++t) {
-        *reinterpret_cast<f2*>(xp + t * PIPS_DMIX) = y[t];
-        const f2 o = (y[t] - (f2){mean[t], mean[t]}) * (g2 * (f2){rstd[t], rstd[t]}) + be2;
-        if (XN_BF16) {
-            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-            const bf16x2_t ob = __builtin_convertvector(o, bf16x2_t);
-            reinterpret_cast<unsigned*>(xn)[((size_t)blockIdx.x * S + t) * (PIPS_DMIX / 2) + tid] = *reinterpret_cast<const unsigned*>(&ob);
-        } else {
-            *reinterpret_cast<f2*>(xnp + t * PIPS_DMIX) = o;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same layer step for the bf16-operand mixer (BASELINE configs[2]) with the token MLP on the matrix cores: one WAVE per
-// particle, three v_mfma_f32_32x32x16_bf16 per 32 channels instead of 512 fp32 FMAs per channel (token_mix_mfma.h has the
-// layout; round 3, second cut: a 256-thread block per particle spent its time in four block-wide reductions and the memory
-// round trips between them -- 30.5 us at 2048 particles against 35 for the VALU kernel).  From M = 16384 rows the bf16 mixer
-// runs the whole layer in one launch instead (mixer_layer_kernel, ffn_fused.hip), with the same code as its prologue.
+// One WAVE per particle (round 3, second cut: a 256-thread block per particle spent its time in four block-wide
+// reductions and the memory round trips between them -- 30.5 us at 2048 particles against 35 for the VALU kernel): the
+// lane holds 4 tokens x 16 channels (c = 128*g + 4*(lane & 31) + q), the LayerNorm sums stay inside the wave (one DPP
+// transpose-reduce, no LDS, no barrier), 16 channel slots x 3 MFMAs.
 __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __restrict__ arena, MixLayerW L, float* __restrict__ x,
                                                                 unsigned* __restrict__ xn, int particles) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int p = blockIdx.x * 4 + wave;                                      // (wave-uniform)
     if (p >= particles) return;
-    float* const xp[1] = {x + ((size_t)p * S + 4 * half) * PIPS_DMIX + 4 * l31};
+    // ---- the particle's tile first: its 16 loads are the long ones (HBM / Infinity Cache), the weights below hit L2
+    float* xp = x + ((size_t)p * S + 4 * half) * PIPS_DMIX + 4 * l31;         // + r * 512 + g * 128
+    float xv[4][16];                                                          // [token r][g * 4 + q]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + r * PIPS_DMIX + g * 128);
+            xv[r][4 * g] = v.x; xv[r][4 * g + 1] = v.y; xv[r][4 * g + 2] = v.z; xv[r][4 * g + 3] = v.w;
+        }
+    // ---- weights as MFMA A fragments
+    uint4 a1, a2[2];
+    {
+        const float* w0 = arena + L.tw0 + l31 * 8 + 4 * half;                 // w0[hidden = l31][token 4*half + i]
+        a1 = make_uint4(pack2_bf16(w0[0], w0[1]), pack2_bf16(w0[2], w0[3]), 0u, 0u);
+        // w3[token = l31 (< 8)][hidden]: register r of the lane = hidden unit (r & 3) + 8 (r >> 2) + 4 half, i.e. four runs of four
+        // consecutive floats.  Four UNCONDITIONAL 16-byte loads, masked afterwards: written as `l31 < 8 ? pack(w3[..]) : 0` hipcc
+        // sank every load into its own predicated block -- eight load -> s_waitcnt vmcnt(0) round trips in a row at the head of
+        // every wave, before the particle's own tile was even requested
+        const float4* w3 = reinterpret_cast<const float4*>(arena + L.tw3 + (l31 & 7) * 32 + 4 * half);
+        const float4 wq[4] = {w3[0], w3[2], w3[4], w3[6]};
+        const unsigned keep = l31 < 8 ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const float4 p0 = wq[2 * kc], p1 = wq[2 * kc + 1];
+            a2[kc] = make_uint4(pack2_bf16(p0.x, p0.y) & keep, pack2_bf16(p0.z, p0.w) & keep, pack2_bf16(p1.x, p1.y) & keep,
+                                pack2_bf16(p1.z, p1.w) & keep);
+        }
+    }
+    float b0r[16], b3r[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b0r[r] = arena[L.tb0 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b3r[r] = arena[L.tb3 + 4 * half + r];
+
+    // per-token mean / rstd of the lane's four tokens: one pass of sums, reduced over the wave
+    auto ln_stats = [&](const float (&v)[4][16], float (&mean)[4], float (&rstd)[4]) __attribute__((always_inline)) {
+        float s1[4], s2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                a += v[r][k]; b += v[r][k + 1];
+                c = fmaf(v[r][k], v[r][k], c); d = fmaf(v[r][k + 1], v[r][k + 1], d);
+            }
+            s1[r] = a + b; s2[r] = c + d;
+        }
+        float sa[S], sb[S];
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const bool mine = (t >> 2) == half;
+            sa[t] = mine ? s1[t & 3] : 0.f;
+            sb[t] = mine ? s2[t & 3] : 0.f;
+        }
+        const float ta = wave_sum8(sa), tb = wave_sum8(sb);                   // lane l: totals of token l & 7
+        const float m = ta * (1.0f / PIPS_DMIX);
+        const float var = fmaxf(tb * (1.0f / PIPS_DMIX) - m * m, 0.f);
+        const float rs = rsqrt_nr(var + 1e-5f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m_lo = lane_bcast(m, r), m_hi = lane_bcast(m, 4 + r);
+            const float r_lo = lane_bcast(rs, r), r_hi = lane_bcast(rs, 4 + r);
+            mean[r] = half ? m_hi : m_lo;
+            rstd[r] = half ? r_hi : r_lo;
+        }
+    };
+    float mean[4], rstd[4];
+    ln_stats(xv, mean, rstd);
+
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 g1 = *reinterpret_cast<const float4*>(arena + L.ln1g + g * 128 + 4 * l31);
+        const float4 be1 = *reinterpret_cast<const float4*>(arena + L.ln1b + g * 128 + 4 * l31);
+        const float g1a[4] = {g1.x, g1.y, g1.z, g1.w}, be1a[4] = {be1.x, be1.y, be1.z, be1.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 4 * g + q;
+            float n[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) n[r] = (xv[r][c] - mean[r]) * (rstd[r] * g1a[q]) + be1a[q];
+            const uint4 bx = make_uint4(pack2_bf16(n[0], n[1]), pack2_bf16(n[2], n[3]), 0u, 0u);
+            f32x16 h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[r] = b0r[r];                       // the MFMA accumulates onto the bias
+            h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_tm*>(&a1), *reinterpret_cast<const bf16x8_tm*>(&bx), h, 0, 0, 0);
+            unsigned hb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f2 gq = gelu_exact2((f2){h[2 * i], h[2 * i + 1]});
+                hb[i] = pack2_bf16(gq.x, gq.y);
+            }
+            const uint4 k0 = make_uint4(hb[0], hb[1], hb[2], hb[3]), k1 = make_uint4(hb[4], hb[5], hb[6], hb[7]);
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = r < 4 ? b3r[r] : 0.f;
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_tm*>(&a2[0]), *reinterpret_cast<const bf16x8_tm*>(&k0), o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_tm*>(&a2[1]), *reinterpret_cast<const bf16x8_tm*>(&k1), o, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xv[r][c] += o[r];                     // residual stream, in place
+        }
+        // the new residual stream of these 128 channels goes out while the next group is computed (all waves of the
+        // launch run in one round, in lock-step: stores held back to the end would queue behind one another)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4*>(xp + r * PIPS_DMIX + g * 128) = make_float4(xv[r][4 * g], xv[r][4 * g + 1], xv[r][4 * g + 2], xv[r][4 * g + 3]);
+    }
+    ln_stats(xv, mean, rstd);
     unsigned* xnp = xn + ((size_t)p * S + 4 * half) * (PIPS_DMIX / 2) + 2 * l31;
-    token_mix_mfma_particles<1>(arena, L, xp, [&](int, int r, int g, uint2 v) __attribute__((always_inline)) {
-        *reinterpret_cast<uint2*>(xnp + r * (PIPS_DMIX / 2) + g * 64) = v;
-    }, l31, half);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 g2 = *reinterpret_cast<const float4*>(arena + L.ln2g + g * 128 + 4 * l31);
+        const float4 be2 = *reinterpret_cast<const float4*>(arena + L.ln2b + g * 128 + 4 * l31);
+        const float g2a[4] = {g2.x, g2.y, g2.z, g2.w}, be2a[4] = {be2.x, be2.y, be2.z, be2.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float n[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) n[q] = (xv[r][4 * g + q] - mean[r]) * (rstd[r] * g2a[q]) + be2a[q];
+            *reinterpret_cast<uint2*>(xnp + r * (PIPS_DMIX / 2) + g * 64) = make_uint2(pack2_bf16(n[0], n[1]), pack2_bf16(n[2], n[3]));
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -784,15 +851,6 @@ int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn
         // bf16-operand mixer: token MLP on the matrix cores, one wave per particle
         hipLaunchKernelGGL(token_mix_mfma_kernel, dim3(cdiv(particles, 4)), dim3(256), 0, st, arena, L, x, reinterpret_cast<unsigned*>(xn), particles);
         PIPS_CHECK_LAUNCH("token_mix_mfma_kernel");
-        return PIPS_OK;
-    }
-    if (PIPS_TUNE("PIPS_TOKEN_F32_MFMA", 1)) {
-        // exact fp32: the token MLP's FMAs on v_mfma_f32_4x4x1_16B_f32 (same sums, vector pipe left to GELU / LayerNorm)
-        if (xn_bf16)
-            hipLaunchKernelGGL(token_mix_f32mfma_kernel<true>, dim3(particles), dim3(256), 0, st, arena, L, x, xn);
-        else
-            hipLaunchKernelGGL(token_mix_f32mfma_kernel<false>, dim3(particles), dim3(256), 0, st, arena, L, x, xn);
-        PIPS_CHECK_LAUNCH("token_mix_f32mfma_kernel");
         return PIPS_OK;
     }
     if (xn_bf16)

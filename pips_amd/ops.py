@@ -28,7 +28,7 @@ def _f32(t):
     return t.contiguous().to(torch.float32)
 
 
-PACK_FP32, PACK_BF16, PACK_SPLIT, PACK_FFN = 1, 2, 4, 8
+PACK_FP32, PACK_BF16, PACK_SPLIT = 1, 2, 4
 
 
 def pack_more(arena, sections, S=8):
@@ -40,7 +40,7 @@ def pack_more(arena, sections, S=8):
     return arena
 
 
-def pack_weights(state_dict, device, sections=PACK_FP32 | PACK_BF16 | PACK_SPLIT | PACK_FFN, S=8) -> torch.Tensor:
+def pack_weights(state_dict, device, sections=PACK_FP32 | PACK_BF16 | PACK_SPLIT, S=8) -> torch.Tensor:
     """state dict (reference key names/layouts, of a ``Pips(S=S)``) -> packed device arena (pips_repack_weights_s);
     ``sections``: which of the fp32 / bf16-copy / split-plane sections to build now (pack_more adds the others later)."""
     lib = _lib.load()
@@ -211,11 +211,9 @@ def score_map_terms(pyr, B, H8, W8, ffeats, tgt):
     return out
 
 
-def mixer_fwd(arena, X, bf16=False, split=False, fused=False, S=8):
+def mixer_fwd(arena, X, bf16=False, split=False, S=8):
     """X (M,544) -> delta (M/S, S*130).  bf16: bf16 MFMA operands in the channel-mix/head GEMMs;
-    split: every GEMM on the fp32-grade split-bf16 path; fused (with bf16, M % 64 == 0): True / "ffn" = each channel-mix
-    FeedForward as one launch behind the token-mix launch (pips_mixer_fwd_bf16_fused), "layer" = each mixer layer as ONE launch
-    (pips_mixer_fwd_bf16_layer: what the bf16 mixer takes by itself from M = 16384 on); the arena needs its PACK_FFN section.  S != 8 (arena packed for that S):
+    split: every GEMM on the fp32-grade split-bf16 path.  S != 8 (arena packed for that S):
     pips_mixer_fwd_s, whose rows are pips_delta_stride(S) apart (cut back to S*130 here)."""
     lib = _lib.load()
     X = _f32(X)
@@ -233,8 +231,7 @@ def mixer_fwd(arena, X, bf16=False, split=False, fused=False, S=8):
     nb = lib.pips_mixer_workspace_bytes(M)
     ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
-        fb = lib.pips_mixer_fwd_bf16_layer if fused == "layer" else (lib.pips_mixer_fwd_bf16_fused if fused else lib.pips_mixer_fwd_bf16)
-        fn = lib.pips_mixer_fwd_x3 if split else (fb if bf16 else lib.pips_mixer_fwd)
+        fn = lib.pips_mixer_fwd_x3 if split else (lib.pips_mixer_fwd_bf16 if bf16 else lib.pips_mixer_fwd)
         _lib.check(fn(_lib.ptr(arena), _lib.ptr(X), M, _lib.ptr(delta), _lib.ptr(ws), nb, _stream()), "pips_mixer_fwd")
     return delta
 

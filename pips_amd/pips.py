@@ -116,9 +116,7 @@ class Pips(nn.Module):
         of split planes.  ``need`` = ops.PACK_* mask (default: what self._flags() implies)."""
         if need is None:
             fl = self._flags()
-            # (the bf16 mixer runs whole layers per launch from M = 16384 rows on: its weights in fragment order, PACK_FFN)
-            need = ops.PACK_FP32 | (ops.PACK_BF16 if fl & 6 else 0) | (ops.PACK_FFN if fl & 2 else 0) | \
-                (ops.PACK_SPLIT if fl & 16 else 0)
+            need = ops.PACK_FP32 | (ops.PACK_BF16 if fl & 6 else 0) | (ops.PACK_SPLIT if fl & 16 else 0)
         if self._plist is None:
             # (owning module, leaf name) of every parameter: the LIVE object is looked up on every forward, so a
             # parameter that was replaced (load_state_dict(assign=True), ``node.weight = nn.Parameter(...)``) is seen

@@ -569,43 +569,6 @@ def test_mixer_any_window_length(S, P):
     assert 1e-6 < float((lo - ref).abs().max()) / scale < 3e-2
 
 
-@pytest.mark.parametrize("form", ["ffn", "layer"])
-@pytest.mark.parametrize("P", [8, 256, 2048])
-def test_mixer_bf16_fused_feedforward_route(P, form, weights_raw, arenas):
-    """The fused forms of the bf16 mixer (ffn_fused.hip) against the token-mix + two-GEMM route: "layer" = one launch per mixer
-    layer (token mixing + LayerNorm-2 as the prologue of the fused FeedForward; what pips_mixer_fwd_bf16 takes by itself from
-    M = 16384 rows on -- P = 2048 is that size), "ffn" = the FeedForward alone behind the separate token-mix launch.  The same
-    operand roundings (bf16 weights, bf16 LayerNorm output, bf16 hidden activation), a different summation order."""
-    from pips_amd import ops
-    O = _oracle()
-    g = torch.Generator().manual_seed(P + 7)
-    x = torch.randn(min(P, 256), 8, 519, generator=g)
-    if P > 256:
-        x = x.repeat(P // 256, 1, 1) + 0.01 * torch.randn(P, 8, 519, generator=g)
-    X = torch.zeros(P * 8, 544)
-    X[:, :519] = x.reshape(P * 8, 519)
-    two = ops.mixer_fwd(arenas["raw"], X.to(DEV), bf16=True).cpu()
-    one = ops.mixer_fwd(arenas["raw"], X.to(DEV), bf16=True, fused=form).cpu()
-    again = ops.mixer_fwd(arenas["raw"], X.to(DEV), bf16=True, fused=form).cpu()
-    assert torch.equal(one, again)                          # run-to-run bitwise (the block re-reads rows other waves wrote)
-    if form == "layer" and P == 2048:                       # the default route at this size IS the one-launch-per-layer form
-        from pips_amd import _lib
-        assert _lib.load().pips_mixer_layer_route(P * 8) == 2 and _lib.load().pips_mixer_layer_route(256 * 8) == 0
-        assert torch.equal(one, two)
-        two = ops.mixer_fwd(arenas["raw"], X.to(DEV), bf16=True, fused="ffn").cpu()
-    ref = O.mixer(weights_raw, x)
-    scale = max(1.0, float(ref.abs().max()))
-    d = float((one - two).abs().max()) / scale
-    e = float((one - ref).abs().max()) / scale
-    print(f"P={P} {form}: fused vs other route {d:.2e}, fused vs fp32 oracle {e:.2e}")
-    assert torch.isfinite(one).all()
-    assert d < 1e-2 and e < 3e-2
-    from pips_amd._lib import PipsHipError
-    with pytest.raises(PipsHipError):                       # M must be whole 64-row blocks
-        ops.mixer_fwd(arenas["raw"], X[:40].to(DEV), bf16=True, fused=form)
-
-
-
 def test_state_update(weights_raw, arenas):
     from pips_amd import ops
     O = _oracle()
