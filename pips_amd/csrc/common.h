@@ -153,6 +153,28 @@ int tune_env(const char* name, int dflt);
 #define PIPS_TUNE(name, dflt) (dflt)
 #endif
 
+// XCD-aware tile order over the WHOLE grid (x = m tiles fastest, then y = n tiles, then z = frames).  Workgroups are
+// dispatched round-robin over the 8 XCDs in linear id order and every XCD has its own L2: with the identity order the tiles
+// that run on one XCD at a time are eight apart -- every XCD ends up pulling (nearly) the whole operand / the whole map of
+// every frame through its L2.  Re-dealt, XCD k owns ONE contiguous run of the linear tile sequence: tiles that are neighbours
+// in a frame (shared conv halo rows, shared W rows) run side by side on one L2, and a frame is touched by one or two XCDs.
+// Bijective for any grid; returns (bx, by, bz).
+struct Tile3 { int x, y, z; };
+__device__ __forceinline__ Tile3 xcd_tile_order(bool on) {
+    Tile3 t = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    if (on) {
+        const int gx = gridDim.x, gxy = gx * gridDim.y, T = gxy * gridDim.z;
+        const int id = t.x + gx * t.y + gxy * t.z;
+        const int xcd = id & 7, local = id >> 3, q = T >> 3, r = T & 7;
+        const int nid = xcd * q + (xcd < r ? xcd : r) + local;
+        t.z = nid / gxy;
+        const int rem = nid - t.z * gxy;
+        t.y = rem / gx;
+        t.x = rem - t.y * gx;
+    }
+    return t;
+}
+
 // Compute units of the current device, queried once per device (persistent kernels size their grid by it).
 int device_cus();
 

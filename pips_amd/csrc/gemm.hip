@@ -49,22 +49,10 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
     const int wmn = wave - ks * (WGM * WGN);
     const int wm = wmn / WGN, wn = wmn % WGN;
     const int l31 = lane & 31, half = lane >> 5;
-    // XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs in linear
-    // id order, each XCD with a private 4 MiB L2.  Re-deal the (m,n) tiles of a frame so that
-    // every XCD owns one contiguous run of tiles (m fastest): a run shares W rows / conv halo
-    // rows inside one L2 instead of spreading every operand over all eight.
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (p.swz) {
-        const int T = gridDim.x * gridDim.y;
-        const int id = blockIdx.x + gridDim.x * blockIdx.y;
-        const int xcd = id & 7, local = id >> 3;
-        const int q = T >> 3, r = T & 7;
-        const int nid = xcd * q + (xcd < r ? xcd : r) + local;      // bijective for any T
-        by = nid / gridDim.x;
-        bx = nid - by * gridDim.x;
-    }
+    const Tile3 tile_ = xcd_tile_order(p.swz != 0);            // (common.h: XCD-aware order over the whole grid)
+    const int bx = tile_.x, by = tile_.y;
     const int m0 = bx * BM, n0 = by * BN;
-    const int frame = blockIdx.z;
+    const int frame = tile_.z;
 #ifdef PIPS_GEMM_TRACE
     // tools/gemm_trace.py: per-block phase timestamps (100 MHz constant clock) for plain GEMMs
     unsigned long long* tr_ = p.trace + 8 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
@@ -410,7 +398,16 @@ extern "C" int pips_trace_read(void* host, size_t bytes) {
 }
 #endif
 
-static int swizzle_on() { return PIPS_TUNE("PIPS_GEMM_SWZ", 0) != 0; }     // measured neutral at the mixer/encoder sizes: off
+// XCD-aware tile order (common.h).  [measured, profiles/r4_probe_f32_gemm_xcd_order.txt] plain GEMMs: neutral (-0.5 % .. +0.6 %)
+// up to M = 65536 rows, +3.4 % .. +5.3 % on the mixer pass at M = 131072 (BASELINE configs[3]), where the 2048-wide operand
+// (1 GiB) no longer fits the 256 MiB Infinity Cache and every XCD otherwise pulls all of W and an eighth-interleaved share of
+// the rows; convolutions: no effect at 8 x 368x496, 32 x 720x1280 (fp32) or 64 x 368x496 (bf16 maps).  So: plain GEMMs whose
+// wide operand exceeds the Infinity Cache.  PIPS_GEMM_SWZ (tuning builds): 0 off, 1 on wherever there are >= 64 tiles.
+static int swizzle_on(bool conv, long tiles, const GemmArgs& a) {
+    const int force = PIPS_TUNE("PIPS_GEMM_SWZ", -1);
+    if (force >= 0) return force != 0 && tiles >= 64;
+    return !conv && (long long)a.M * (a.N > a.K ? a.N : a.K) * 4 > (256ll << 20);
+}
 
 template <int BM, int BN, int WGM, int WGN, int KS, bool CONV>
 static int launch_tile(const GemmArgs& a_in, int frames, hipStream_t st) {
@@ -418,7 +415,7 @@ static int launch_tile(const GemmArgs& a_in, int frames, hipStream_t st) {
     GemmArgs a = a_in;
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), frames);
     dim3 block(WGM * WGN * KS * 64);
-    a.swz = swizzle_on() && (grid.x * grid.y >= 16);
+    a.swz = swizzle_on(CONV, (long)grid.x * grid.y * grid.z, a);
     size_t lds = (size_t)2 * (BM + BN) * (32 * KS + 4) * sizeof(float);
     auto kern = igemm_f32_kernel<BM, BN, WGM, WGN, KS, CONV>;
     if (lds > 64 * 1024) {

@@ -55,9 +55,11 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
     const int wmn = wave - ks * (WGM * WGN);
     const int wm = wmn / WGN, wn = wmn % WGN;
     const int l31 = lane & 31, half = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const Tile3 tile_ = xcd_tile_order(p.swz != 0);            // (common.h: XCD-aware order over the whole grid)
+    const int bx = tile_.x;
+    const int m0 = bx * BM, n0 = tile_.y * BN;
     const int lrow = tid / TPR, cg = tid % TPR;
-    const int frame = blockIdx.z;
+    const int frame = tile_.z;
 
     const float* __restrict__ Af = p.A;                                          // A_BF16 == false
     if (CONV) Af += (size_t)frame * p.H * p.Win * p.Cin;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
             const int left = p.M - (m0 + wm * WTM), nvalid = left < 0 ? 0 : (left > WTM ? WTM : left);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                store_conv_partial(p.stats, frame, (int)gridDim.x * WGM, (int)blockIdx.x * WGM + wm, p.N, n0 + wn * WTN + j * 32 + l31,
+                store_conv_partial(p.stats, frame, (int)gridDim.x * WGM, bx * WGM + wm, p.N, n0 + wn * WTN + j * 32 + l31,
                                    half, csum[j], csq[j], piv[j], nvalid);
         }
         return;
@@ -324,9 +326,18 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
     }
 }
 
+// XCD-aware tile order (common.h).  PIPS_BF16_SWZ (tuning builds): 0 off, 1 on from 64 tiles; default -1 = by kind and size.
+static int bf16_swizzle_on(bool conv, long tiles) {
+    const int force = PIPS_TUNE("PIPS_BF16_SWZ", -1);
+    if (force >= 0) return force != 0 && tiles >= 64;
+    return 0;
+}
+
 template <int BM, int BN, int WGM, int WGN, int KS, bool A_BF16, bool OUT_BF16, int BKE = 64>
-static int launch_bf16_tile(const GemmArgs& a, hipStream_t st) {
+static int launch_bf16_tile(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), 1);
+    a.swz = bf16_swizzle_on(false, (long)grid.x * grid.y);
     dim3 block(WGM * WGN * KS * 64);
     const size_t lds = (size_t)2 * (BM + BN) * (BKE * KS * 2 + 16);
     auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, KS, A_BF16, OUT_BF16, BKE>;
@@ -364,8 +375,10 @@ static int pick_tile(const GemmArgs& a, hipStream_t st) {
 }
 
 template <int BM, int BN, int BKE, bool A_BF16, bool OUT_BF16>
-static int launch_conv_tile_t(const GemmArgs& a, int frames, hipStream_t st) {
+static int launch_conv_tile_t(const GemmArgs& a_in, int frames, hipStream_t st) {
+    GemmArgs a = a_in;
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), frames);
+    a.swz = bf16_swizzle_on(true, (long)grid.x * grid.y * grid.z);
     const size_t lds = (size_t)2 * (BM + BN) * (BKE * 2 + 16);
     auto kern = gemm_bf16_kernel<BM, BN, 2, 2, 1, A_BF16, OUT_BF16, BKE, true>;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);

@@ -109,9 +109,10 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_x3_kernel(GemmArgs p
     const int wmn = wave - ks * (WGM * WGN);
     const int wm = wmn / WGN, wn = wmn % WGN;
     const int l31 = lane & 31, half = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const Tile3 tile_ = xcd_tile_order(p.swz != 0);            // (common.h: XCD-aware order over the whole grid)
+    const int m0 = tile_.x * BM, n0 = tile_.y * BN;
     const int lrow = tid / TPR, cg = tid % TPR;
-    const int frame = blockIdx.z;
+    const int frame = tile_.z;
     // swizzle of a row: (r / rows-per-256-bytes) mod CH.  ds_read_b128 is served in 16-lane groups
     // {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) over 64 banks: within a group the rows of equal
     // (r mod rows-per-256-B) must land on distinct chunks -- (r>>2)&3 / (r>>1)&7 does that; the
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_x3_kernel(GemmArgs p
 
     if (CONV) {
         conv_epilogue<BM, BN, WGM, WTM, WTN, NT, TM, TN>(acc, p, p.C + (size_t)frame * p.M * p.ldc,
-                                                        reinterpret_cast<float*>(smem), frame, blockIdx.x, m0, n0,
+                                                        reinterpret_cast<float*>(smem), frame, tile_.x, m0, n0,
                                                         wm, wn, l31, half, tid);
     } else {
         gemm_epilogue<TM, TN>(acc, p, m0 + BM <= p.M && n0 + BN <= p.N, m0 + wm * WTM + l31,
@@ -332,8 +333,14 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_x3_kernel(GemmArgs p
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS, bool CONV, int BKE = 32>
-static int launch_x3_tile(const GemmArgs& a, int frames, hipStream_t st) {
+static int launch_x3_tile(const GemmArgs& a_in, int frames, hipStream_t st) {
+    GemmArgs a = a_in;
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), frames);
+    {   // XCD-aware tile order (common.h).  PIPS_X3_SWZ (tuning builds): 0 off, 1 on from 64 tiles; default -1 = by kind and size
+        const int force = PIPS_TUNE("PIPS_X3_SWZ", -1);
+        const long tiles = (long)grid.x * grid.y * grid.z;
+        a.swz = force >= 0 ? (force != 0 && tiles >= 64) : 0;
+    }
     dim3 block(WGM * WGN * KS * 64);
     const size_t lds = (size_t)2 * 3 * (BM + BN) * (BKE * KS * 2);
     auto kern = gemm_x3_kernel<BM, BN, WGM, WGN, KS, CONV, BKE>;
