@@ -346,6 +346,8 @@ def config4_leg(device):
                      "achieved_GBs": comp / tg / 1e6, "frac_of_8TBs": comp / tg / 1e6 / PEAK_HBM_GBS}
     dom = out["iter0_grid"]
     traffic, traffic_src = pmc_traffic("gather_tiled_kernel")
+    valu_floor_ms = b * S * n * 4 * 64 * 128 / (105.0 * 256 * 2.4e9) * 1e3
+    lds_floor_ms = 0.78 * b * S * n * 4 * 64 * 128 * 4 / (256.0 * 256 * 2.4e9) * 1e3
     return {"workload": "BASELINE configs[3]: B=4 S=8 720x1280 N=4096 (64x64 grid) I=6 fp32 stride 8, encoder included",
             "value": b * S * n * ITERS / t_fwd * 1e3, "unit": "particle-updates/s", "ms_per_step": t_fwd, "dtype": "f32",
             "gather_roofline": {"bound": "hbm", "kernel": "gather_tiled_kernel", "achieved": dom["achieved_GBs"],
@@ -354,8 +356,10 @@ def config4_leg(device):
                                 "algorithmic_bytes_per_launch": comp,
                                 # the kernel's own on-chip floors (exact fp32 on the vector ALUs): the 0.80 HBM target
                                 # (76 us) lies below both
-                                "valu_floor_ms": b * S * n * 4 * 64 * 128 / (105.0 * 256 * 2.4e9) * 1e3,
-                                "lds_floor_ms": 0.78 * b * S * n * 4 * 64 * 128 * 4 / (256.0 * 256 * 2.4e9) * 1e3,
+                                "valu_floor_ms": valu_floor_ms, "lds_floor_ms": lds_floor_ms,
+                                # how close the launch is to what bounds THIS formulation: LDS -> VGPR fragment bandwidth
+                                "frac_of_lds_floor": lds_floor_ms / dom["gather_tiled_kernel_ms"],
+                                "frac_of_valu_floor": valu_floor_ms / dom["gather_tiled_kernel_ms"],
                                 "floors_note": "valu: 4.29 G lane-FMAs at the measured 105 lane-FMA/clk/CU (tools/valu_peak.hip) x 256 CUs x "
                                                "2.4 GHz; lds: 17.2 GB of window fragments x 0.78 (anchor sharing) at 256 B/clk/CU",
                                 "timing": "HIP event pair around the kernel launch (pips_mixer_input_build_tiled_timed), "

@@ -277,7 +277,7 @@ int    pips_gemm_bf16(const void* A, int a_bf16, int lda, const void* W, const f
 /* Which kernel pips_gemm_bf16 (and the bf16 mixer of pips_forward) takes for a problem with bias and, for
  * epi = residual, an fp32 residual of ldr = N: 0 = register-staged gemm_bf16_kernel, 1 = gemm_bf16_res_asm_kernel,
  * 2 = gemm_bf16_gelu_asm_kernel (generated assembly; rounds the Linear output to bf16 ahead of a table GELU, see
- * DESIGN.md 4b).  Pure host function: the mixer's bf16 numerics depend on M = B*N*8 through this choice. */
+ * DESIGN.md 4b), 3 = gemm_bf16_t4_res_kernel (the residual form on 128 x 256 tiles, N % 256 == 0).  Pure host function: the mixer's bf16 numerics depend on M = B*N*8 through this choice. */
 int    pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16);
 
 /* pips_conv_nhwc_f32 with bf16 MFMA operands: the fp32 map is rounded to bf16 while it is staged, wgt_bf16 is the

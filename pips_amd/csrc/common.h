@@ -268,6 +268,9 @@ bool conv3x3_c64_takes(int H, int W, int frames);      // whether that kernel ta
 // the config-3 up-projection as persistent blocks with a generated-assembly tile body (gemm_bf16_asm.hip); 1 = not taken
 int launch_gemm_bf16_asm(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
 int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16);   // 0 register-staged, 1 / 2 the assembly kernels
+// the large-M bf16 down-projection (+ bias + fp32 residual) on 128x256 tiles, four waves, 16x16x32 MFMAs (gemm_bf16_t4.hip)
+bool gemm_bf16_t4_takes(const GemmArgs& a, int a_bf16, int out_bf16);
+int launch_gemm_bf16_t4(const GemmArgs& a, hipStream_t st);
 // split-bf16 (bf16x3) fp32-grade GEMM / conv (gemm_x3.hip): A fp32, W = three bf16 planes [3][N][K]
 int launch_split_bf16x3(const float* src, size_t n, void* dst, hipStream_t st);
 int launch_gemm_x3(const GemmArgs& a, hipStream_t st);

@@ -431,6 +431,7 @@ int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st
     PIPS_CHECK_ARG((unsigned long long)a.M * (unsigned long long)a.lda < (1ull << 32) &&
                        (unsigned long long)a.N * (unsigned long long)a.K < (1ull << 32),
                    "gemm_bf16: operand exceeds 2^32 elements");
+    if (gemm_bf16_t4_takes(a, a_bf16, out_bf16)) return launch_gemm_bf16_t4(a, st);      // the config-3 down-projection
     {
         const int rc = launch_gemm_bf16_asm(a, a_bf16, out_bf16, st);      // the config-3 up-projection
         if (rc != 1) return rc;

@@ -455,6 +455,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_res4_asm_kernel(GemmArgs p, int
 // (down-projection + residual), 2 = gemm_bf16_gelu_asm_kernel (up-projection + GELU).  Pure function of the problem --
 // also behind pips_gemm_bf16_route(), which lets a test assert that a forward's geometry reaches the assembly kernels.
 int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16) {
+    if (gemm_bf16_t4_takes(a, a_bf16, out_bf16)) return 3;           // (launch_gemm_bf16 asks that kernel first)
     const int mode = PIPS_TUNE("PIPS_BF16_ASM", 1);        // tuning hook: 0 = off, 1 (default) = on, 2 = on for any tile count
     const int epi = a.epi & 0xff;
     if (!mode || !a_bf16 || a.lda % 8 != 0 || a.ldc % 8 != 0 || a.bias == nullptr || a.K % 64 != 0) return 0;

@@ -1,0 +1,102 @@
+// bf16 down-projection of the mixer at large M (BASELINE configs[2]: M = 16384, N = 512, K = 2048, + bias + fp32 residual):
+//
+//     C[m][n] = R[m][n] + sum_k A[m][k] * W[n][k] + bias[n]           (nets/pips.py:102-109 inside PreNormResidual :93-100)
+//
+// One 128 x 256 tile per block, FOUR waves (one per SIMD, 512 registers each), wave tile 64 x 128 on v_mfma_f32_16x16x32_bf16
+// (C^T: the W fragment is the MFMA's row operand, so a lane owns an output ROW and 4 consecutive columns per 16 x 16 tile).
+// What is different from gemm_bf16_res_asm_kernel (256 x 128 tile, eight waves of 64 x 64, LDS-DMA ring) and why
+// [measured, profiles/r4_probe_bf16_down_t4.txt]:
+//   * the 16-pass-shorter MFMA (16 clk instead of 32) lets ONE memory instruction sit between two MFMAs everywhere in the
+//     loop: per 64 K values a wave issues 64 MFMAs, 24 ds_read_b128 (12 fragments per 32-K step: 4 of A, 8 of W), 12
+//     ds_write_b128 and 12 buffer_load_dwordx4 -- 48 memory instructions in 64 slots;
+//   * operands go global -> registers -> LDS (two tiles ahead in registers), not by LDS-DMA: the DMA's LDS writes collided with
+//     the fragment reads (MFMA + reads 11.3, MFMA + DMA 10.3, all three 18.1 us per 1 024 K, DESIGN.md 4b iii), a ds_write
+//     is placed where the schedule wants it;
+//   * ONE LDS buffer (48 KiB) and two barriers per 64 K: [MFMAs of K step 0 | reads of K step 1] barrier [MFMAs | writes of
+//     the next tile + loads of the one after] barrier [MFMAs of K step 1 | reads of the next tile's K step 0];
+//   * the residual tile seeds the accumulators (its 32 loads per lane fly during the prologue), the bias is added at the end.
+// LDS image: rows of 64 K values (128 B), the 16-byte chunk index XORed with (row >> 1) & 7: conflict-free for the fragment
+// ds_read_b128 (lane = row & 15, K group = lane >> 4) and for the staging ds_write_b128 (8 lanes = one row).
+// The whole body is ONE generated assembly statement (gemm_bf16_t4_asm.inc <- tools/gen_gemm_bf16_t4.py: static schedule, counted
+// waits): as C++ with builtins + sched_barrier pins hipcc kept a third of the accumulators in ArchVGPRs and moved ~200 registers
+// per iteration between the two register files (88 v_accvgpr_read + 88 _write + 32 _mov per 64 MFMAs).
+#include "common.h"
+#include "gemm_bf16_t4_asm.inc"
+
+namespace pips {
+
+constexpr int T4_BM = 128, T4_BN = 256, T4_BK = 64;
+constexpr int T4_LDS = (T4_BM + T4_BN) * T4_BK * 2;          // 49 152 bytes: one buffer, [A rows 0..127 | W rows 0..255] x 128 B
+
+__device__ __forceinline__ unsigned t4_sgpr(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+#define T4_LO(ptr) t4_sgpr((unsigned)(unsigned long long)reinterpret_cast<uintptr_t>(ptr))
+#define T4_HI(ptr) t4_sgpr((unsigned)((unsigned long long)reinterpret_cast<uintptr_t>(ptr) >> 32))
+
+__global__ __launch_bounds__(256) void gemm_bf16_t4_res_kernel(GemmArgs p, int tiles_n, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, g = lane >> 4;
+
+    // XCD-aware tile order: XCD (block & 7) owns one contiguous run of the (row tile, column tile) sequence, column tile
+    // fastest -- the column tiles of a row block read the same 128 rows of A out of one L2
+    int tile;
+    {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, q = ntiles >> 3, r = ntiles & 7;
+        tile = xcd * q + (xcd < r ? xcd : r) + local;
+    }
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * T4_BM, n0 = tn * T4_BN;
+
+    // ---- staging: thread = (row lr of a 32-row pass, 16-byte chunk lc of the row's 128 bytes); LDS chunk = lc ^ ((row >> 1) & 7)
+    const int lr = tid >> 3, lc = tid & 7;
+    const unsigned short* Ab = reinterpret_cast<const unsigned short*>(p.A) + (size_t)m0 * p.lda;
+    const unsigned short* Wb = reinterpret_cast<const unsigned short*>(p.W) + (size_t)n0 * p.K;
+    const unsigned voA = (unsigned)(lr * p.lda * 2 + lc * 16), voW = (unsigned)(lr * p.K * 2 + lc * 16);
+    const unsigned passA = (unsigned)(32 * p.lda * 2), passW = (unsigned)(32 * p.K * 2);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned wA = lds0 + lr * 128 + ((lc ^ ((lr >> 1) & 7)) * 16);                         // + piece * 4096
+    const unsigned wW = wA + T4_BM * 128;
+    // ---- fragments: lane = row r16 of a 16-row block, K group g (8 K values = one 16-byte chunk); K step 1 = chunk ^ 4
+    const int sw = (r16 >> 1) & 7;
+    const unsigned rA0 = lds0 + (64 * wm + r16) * 128 + ((g ^ sw) * 16);                          // + i * 2048
+    const unsigned rW0 = lds0 + T4_BM * 128 + (128 * wn + r16) * 128 + ((g ^ sw) * 16);          // + j * 2048
+    const unsigned rA1 = rA0 ^ 64, rW1 = rW0 ^ 64;
+    // ---- residual / output / bias: acc tile (i, j) = R[m0 + 64 wm + 16 i + r16][n0 + 128 wn + 16 j + 4 g .. + 3]
+    const float* Rb = p.R + (size_t)(m0 + 64 * wm) * p.ldr + n0 + 128 * wn;
+    const float* Cb = p.C + (size_t)(m0 + 64 * wm) * p.ldc + n0 + 128 * wn;
+    const float* Bb = p.bias + n0 + 128 * wn;
+    const unsigned voR = (unsigned)((r16 * p.ldr + 4 * g) * 4), voC = (unsigned)((r16 * p.ldc + 4 * g) * 4), voB = (unsigned)(16 * g);
+    const unsigned rstep = (unsigned)(16 * p.ldr * 4), cstep = (unsigned)(16 * p.ldc * 4);
+    const unsigned kt = (unsigned)(p.K / T4_BK);
+    asm volatile(PIPS_T4_TEXT
+                 :
+                 : [rA0] "v"(rA0), [rW0] "v"(rW0), [rA1] "v"(rA1), [rW1] "v"(rW1), [wA] "v"(wA), [wW] "v"(wW), [voA] "v"(voA),
+                   [voW] "v"(voW), [voR] "v"(voR), [voC] "v"(voC), [voB] "v"(voB), [alo] "s"(T4_LO(Ab)), [ahi] "s"(T4_HI(Ab)),
+                   [wlo] "s"(T4_LO(Wb)), [whi] "s"(T4_HI(Wb)), [rlo] "s"(T4_LO(Rb)), [rhi] "s"(T4_HI(Rb)), [clo] "s"(T4_LO(Cb)),
+                   [chi] "s"(T4_HI(Cb)), [blo] "s"(T4_LO(Bb)), [bhi] "s"(T4_HI(Bb)), [passA] "s"(t4_sgpr(passA)),
+                   [passW] "s"(t4_sgpr(passW)), [rstep] "s"(t4_sgpr(rstep)), [cstep] "s"(t4_sgpr(cstep)), [kt] "s"(t4_sgpr(kt))
+                 : PIPS_T4_CLOBBER);
+}
+
+// Whether the down-projection form (bf16 A, fp32 C, + bias + fp32 residual) of a bf16-operand GEMM goes to this kernel.
+bool gemm_bf16_t4_takes(const GemmArgs& a, int a_bf16, int out_bf16) {
+    const int mode = PIPS_TUNE("PIPS_BF16_T4", 1);          // tuning hook: 0 = off, 2 = any tile count
+    if (!mode || !a_bf16 || out_bf16 || (a.epi & 0xff) != EPI_RESIDUAL || a.R == nullptr || a.bias == nullptr) return false;
+    if (a.M % T4_BM != 0 || a.N % T4_BN != 0 || a.K % T4_BK != 0 || a.K < 2 * T4_BK) return false;
+    if (a.lda % 8 != 0 || a.ldc % 4 != 0 || a.ldr % 4 != 0) return false;
+    if ((unsigned long long)80 * a.ldr * 4ull >= (1ull << 31) || (unsigned long long)80 * a.ldc * 4ull >= (1ull << 31)) return false;   // (buffer offsets inside a wave tile)
+    if ((unsigned long long)(T4_BM + 32) * a.lda * 2ull >= (1ull << 31) || (unsigned long long)(T4_BN + 32) * a.K * 2ull >= (1ull << 31)) return false;
+    const int cus = device_cus();
+    return mode == 2 || (cus > 0 && (long)(a.M / T4_BM) * (a.N / T4_BN) >= cus);
+}
+
+int launch_gemm_bf16_t4(const GemmArgs& a, hipStream_t st) {
+    const int tiles_n = a.N / T4_BN, ntiles = (a.M / T4_BM) * tiles_n;
+    hipLaunchKernelGGL(gemm_bf16_t4_res_kernel, dim3(ntiles), dim3(256), T4_LDS, st, a, tiles_n, ntiles);
+    PIPS_CHECK_LAUNCH("gemm_bf16_t4_res_kernel");
+    return PIPS_OK;
+}
+
+}  // namespace pips

@@ -31,7 +31,8 @@ def test_config3_routes_reach_the_assembly_gemms():
     lib = _lib.load()
     M = B * N * S
     assert lib.pips_gemm_bf16_route(M, 2048, 512, 1, 1, 1) == 2          # up-projection + GELU, bf16 out
-    assert lib.pips_gemm_bf16_route(M, 512, 2048, 2, 1, 0) == 1          # down-projection + residual, fp32 out
+    assert lib.pips_gemm_bf16_route(M, 512, 2048, 2, 1, 0) == 3          # down-projection + residual, fp32 out: gemm_bf16_t4_res_kernel
+    assert lib.pips_gemm_bf16_route(2 * M, 384, 2048, 2, 1, 0) == 1      # N % 256 != 0: the 256 x 128 assembly kernel
     assert lib.pips_gemm_bf16_route(1024, 2048, 512, 1, 1, 1) == 0       # tests/test_forward_gpu.py geometry
     assert lib.pips_gemm_bf16_route(2048, 2048, 512, 1, 1, 1) == 0       # B=1, N=256
 

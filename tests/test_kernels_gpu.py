@@ -493,7 +493,10 @@ def test_mixer(P, split, weights_raw, arenas):
     (32768, 1024, 512, 1, True),       # 512 tiles on 256 blocks, four column blocks
     (16384, 1920, 512, 1, True),       # N % 256 != 0: the 256 x 128 kernel (gemm_bf16_gelu_asm_kernel), 4 tiles per block
     (1280, 2048, 512, 1, True),        # below either threshold -> register-staged kernel, same contract
-    (16384, 512, 2048, 2, False),      # config-3 down-projection
+    (16384, 512, 2048, 2, False),      # config-3 down-projection: 128 x 256 tiles, four waves (gemm_bf16_t4_res_kernel)
+    (32896, 256, 128, 2, False),       # the same kernel: 257 tiles (not a multiple of the 8 XCDs), two K iterations (the minimum)
+    (16384, 768, 192, 2, False),       # three column tiles per row block, three K iterations
+    (32768, 384, 1024, 2, False),      # N % 256 != 0: the 256 x 128 assembly kernel (gemm_bf16_res_asm_kernel)
     (4096, 512, 544, 0, False),        # input projection: fp32 A, 32-element K blocks
 ])
 def test_gemm_bf16(M, N, K, epi, out_bf16):
