@@ -21,7 +21,10 @@
 // waits): as C++ with builtins + sched_barrier pins hipcc kept a third of the accumulators in ArchVGPRs and moved ~200 registers
 // per iteration between the two register files (88 v_accvgpr_read + 88 _write + 32 _mov per 64 MFMAs).
 #include "common.h"
-#include "gemm_bf16_t4_asm.inc"
+#ifndef PIPS_T4_INC
+#define PIPS_T4_INC "gemm_bf16_t4_asm.inc"      // tuning builds point this at another schedule of the generator
+#endif
+#include PIPS_T4_INC
 
 namespace pips {
 
@@ -70,14 +73,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_res_kernel(GemmArgs p, int t
     const unsigned voR = (unsigned)((r16 * p.ldr + 4 * g) * 4), voC = (unsigned)((r16 * p.ldc + 4 * g) * 4), voB = (unsigned)(16 * g);
     const unsigned rstep = (unsigned)(16 * p.ldr * 4), cstep = (unsigned)(16 * p.ldc * 4);
     const unsigned kt = (unsigned)(p.K / T4_BK);
-    asm volatile(PIPS_T4_TEXT
-                 :
-                 : [rA0] "v"(rA0), [rW0] "v"(rW0), [rA1] "v"(rA1), [rW1] "v"(rW1), [wA] "v"(wA), [wW] "v"(wW), [voA] "v"(voA),
-                   [voW] "v"(voW), [voR] "v"(voR), [voC] "v"(voC), [voB] "v"(voB), [alo] "s"(T4_LO(Ab)), [ahi] "s"(T4_HI(Ab)),
-                   [wlo] "s"(T4_LO(Wb)), [whi] "s"(T4_HI(Wb)), [rlo] "s"(T4_LO(Rb)), [rhi] "s"(T4_HI(Rb)), [clo] "s"(T4_LO(Cb)),
-                   [chi] "s"(T4_HI(Cb)), [blo] "s"(T4_LO(Bb)), [bhi] "s"(T4_HI(Bb)), [passA] "s"(t4_sgpr(passA)),
+#define T4_OPERANDS \
+                 : [rA0] "v"(rA0), [rW0] "v"(rW0), [rA1] "v"(rA1), [rW1] "v"(rW1), [wA] "v"(wA), [wW] "v"(wW), [voA] "v"(voA), \
+                   [voW] "v"(voW), [voR] "v"(voR), [voC] "v"(voC), [voB] "v"(voB), [alo] "s"(T4_LO(Ab)), [ahi] "s"(T4_HI(Ab)), \
+                   [wlo] "s"(T4_LO(Wb)), [whi] "s"(T4_HI(Wb)), [rlo] "s"(T4_LO(Rb)), [rhi] "s"(T4_HI(Rb)), [clo] "s"(T4_LO(Cb)), \
+                   [chi] "s"(T4_HI(Cb)), [blo] "s"(T4_LO(Bb)), [bhi] "s"(T4_HI(Bb)), [passA] "s"(t4_sgpr(passA)), \
                    [passW] "s"(t4_sgpr(passW)), [rstep] "s"(t4_sgpr(rstep)), [cstep] "s"(t4_sgpr(cstep)), [kt] "s"(t4_sgpr(kt))
-                 : PIPS_T4_CLOBBER);
+    asm volatile(PIPS_T4_TEXT : T4_OPERANDS : PIPS_T4_CLOBBER);
+#undef T4_OPERANDS
 }
 
 // Whether the down-projection form (bf16 A, fp32 C, + bias + fp32 residual) of a bf16-operand GEMM goes to this kernel.

@@ -104,10 +104,11 @@ def mfma(e, ks, n):
 def store_piece(e, s):
     e.need_vm({("st", s)})
     reg = ST + 4 * s
+    wa, ww = "%[wA]", "%[wW]"
     if s < 4:
-        e.lds("ds_write_b128 %%[wA], v[%d:%d] offset:%d" % (reg, reg + 3, s * 4096), ("wr", s))
+        e.lds("ds_write_b128 %s, v[%d:%d] offset:%d" % (wa, reg, reg + 3, s * 4096), ("wr", s))
     else:
-        e.lds("ds_write_b128 %%[wW], v[%d:%d] offset:%d" % (reg, reg + 3, (s - 4) * 4096), ("wr", s))
+        e.lds("ds_write_b128 %s, v[%d:%d] offset:%d" % (ww, reg, reg + 3, (s - 4) * 4096), ("wr", s))
 
 
 def load_piece(e, s, soff):
@@ -121,6 +122,41 @@ def descriptor(e, base, lo, hi):
     e.raw("s_and_b32 s%d, %s, 0xffff" % (base + 1, hi))
     e.raw("s_mov_b32 s%d, 0x7fffffff" % (base + 2))
     e.raw("s_mov_b32 s%d, 0x00020000" % (base + 3))
+
+
+def staging_slots():
+    slots = []
+    for s in range(12):
+        slots += [("st", s), ("ld", s)]
+    return slots
+
+
+def iteration_single(e):
+    """64 K values out of the ONE LDS buffer: two barriers.  (A two-buffer form with one barrier per iteration was built and
+    measured: the same 1.03 us per iteration -- the loop is bound by what the wave issues, not by its barriers.)"""
+    e.raw("s_add_u32 s%d, s%d, 128" % (S_SO, S_SO))
+    e.raw("s_min_u32 s%d, s%d, s%d" % (S_SO, S_SO, S_LAST))
+    # K step 0, first half: the fragments of K step 1 go out in between
+    for n in range(16):
+        mfma(e, 0, n)
+        if n < 12:
+            frag_read(e, 1, *FRAG_ORDER[n])
+    e.barrier()                                              # every wave has read tile kt: the buffer may be overwritten
+    # rest of K step 0 + first half of K step 1: next tile registers -> LDS, the one after global -> registers
+    slots = staging_slots()
+    k = 0
+    for n in range(16, 48):
+        mfma(e, n >> 5, n & 31)
+        if k < len(slots):
+            (store_piece(e, slots[k][1]) if slots[k][0] == "st" else load_piece(e, slots[k][1], "s%d" % S_SO))
+            k += 1
+    assert k == len(slots)
+    e.barrier()                                              # tile kt + 1 is in LDS
+    for n in range(16, 32):
+        mfma(e, 1, n)
+        f = n - 16
+        if f < 12:
+            frag_read(e, 0, *FRAG_ORDER[f])
 
 
 def body():
@@ -168,36 +204,7 @@ def body():
     # ends in the same state, which the asserts below check
     head_lgkm, head_vm = list(e.lgkm), list(e.vm)
     e.raw("1:")
-    e.raw("s_add_u32 s%d, s%d, 128" % (S_SO, S_SO))
-    e.raw("s_min_u32 s%d, s%d, s%d" % (S_SO, S_SO, S_LAST))
-    # K step 0, first half: the fragments of K step 1 go out in between
-    for n in range(16):
-        mfma(e, 0, n)
-        if n < 12:
-            frag_read(e, 1, *FRAG_ORDER[n])
-    e.barrier()                                              # every wave has read tile kt: the buffer may be overwritten
-    # rest of K step 0 + first half of K step 1: next tile registers -> LDS, the one after global -> registers
-    slots = []
-    for s in range(12):
-        slots += [("st", s), ("ld", s)]
-    k = 0
-    for n in range(16, 32):
-        mfma(e, 0, n)
-        if k < len(slots):
-            (store_piece(e, slots[k][1]) if slots[k][0] == "st" else load_piece(e, slots[k][1], "s%d" % S_SO))
-            k += 1
-    for n in range(16):
-        mfma(e, 1, n)
-        if k < len(slots):
-            (store_piece(e, slots[k][1]) if slots[k][0] == "st" else load_piece(e, slots[k][1], "s%d" % S_SO))
-            k += 1
-    assert k == len(slots)
-    e.barrier()                                              # tile kt + 1 is in LDS
-    for n in range(16, 32):
-        mfma(e, 1, n)
-        f = n - 16
-        if f < 12:
-            frag_read(e, 0, *FRAG_ORDER[f])
+    iteration_single(e)
     assert e.lgkm == head_lgkm and e.vm == head_vm, (e.lgkm, head_lgkm, e.vm, head_vm)
     e.raw("s_sub_u32 s%d, s%d, 1" % (S_KT, S_KT))
     e.raw("s_cmp_lg_u32 s%d, 0" % S_KT)
@@ -227,18 +234,19 @@ def body():
 
 
 def main():
-    lines = body()
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"a%d"' % i for i in range(128)] + ['"v%d"' % i for i in range(160)] + \
            ['"s%d"' % i for i in range(40, 76)]
     with open(OUT, "w") as f:
         f.write("// generated by tools/gen_gemm_bf16_t4.py -- do not edit\n")
-        f.write("#define PIPS_T4_TEXT \\\n")
-        for ln in lines:
-            f.write('    "%s\\n\\t" \\\n' % ln)
-        f.write('    ""\n\n')
+        for name in ("PIPS_T4_TEXT",):
+            lines = body()
+            f.write("#define %s \\\n" % name)
+            for ln in lines:
+                f.write('    "%s\\n\\t" \\\n' % ln)
+            f.write('    ""\n\n')
+            print("%s: %d instructions, %d MFMAs" % (name, len(lines), sum("v_mfma" in ln for ln in lines)))
         f.write("#define PIPS_T4_CLOBBER " + ", ".join(clob) + "\n")
-    n_mfma = sum("v_mfma" in ln for ln in lines)
-    print("wrote %s: %d instructions, %d MFMAs in the loop body" % (OUT, len(lines), n_mfma))
+    print("wrote", OUT)
 
 
 if __name__ == "__main__":
