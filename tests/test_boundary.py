@@ -174,3 +174,7 @@ def test_build_script_dependencies_exist_and_asm_is_current(tmp_path):
     env["PIPS_GEN_OUT"] = str(out2)
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_gemm_bf16_asm.py")], env=env, stdout=subprocess.DEVNULL)
     assert out2.read_text() == open(os.path.join(root, "pips_amd", "csrc", "gemm_bf16_tile_asm.inc")).read()
+    out3 = tmp_path / "gemm_bf16_t4_asm.inc"
+    env["PIPS_GEN_OUT"] = str(out3)
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_gemm_bf16_t4.py")], env=env, stdout=subprocess.DEVNULL)
+    assert out3.read_text() == open(os.path.join(root, "pips_amd", "csrc", "gemm_bf16_t4_asm.inc")).read()
