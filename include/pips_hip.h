@@ -274,10 +274,12 @@ int    pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin,
  * K % 32 == 0 (K % 64 unless A and C are fp32). */
 int    pips_gemm_bf16(const void* A, int a_bf16, int lda, const void* W, const float* bias, void* C, int out_bf16, int ldc,
                       int M, int N, int K, int epi, const float* R, int ldr, void* stream);
-/* Which kernel pips_gemm_bf16 (and the bf16 mixer of pips_forward) takes for a problem with bias and, for
- * epi = residual, an fp32 residual of ldr = N: 0 = register-staged gemm_bf16_kernel, 1 = gemm_bf16_res_asm_kernel,
- * 2 = gemm_bf16_gelu_asm_kernel (generated assembly; rounds the Linear output to bf16 ahead of a table GELU, see
- * DESIGN.md 4b), 3 = gemm_bf16_t4_res_kernel (the residual form on 128 x 256 tiles, N % 256 == 0).  Pure host function: the mixer's bf16 numerics depend on M = B*N*8 through this choice. */
+/* Which kernel pips_gemm_bf16 (and the bf16 mixer of pips_forward) takes for a problem with bias and, for epi = residual, an
+ * fp32 residual of ldr = N: 0 = register-staged gemm_bf16_kernel, 2 = gemm_bf16_gelu256_asm_kernel (up-projection: bf16 A and C,
+ * GELU, K = 512, M and N multiples of 256 and at least one 256 x 256 tile per compute unit; generated assembly; rounds the Linear
+ * output to bf16 ahead of a table GELU), 3 = gemm_bf16_t4_res_kernel (down-projection: bf16 A, fp32 C, bias +
+ * residual, M % 128 == 0, N % 256 == 0, K % 64 == 0, at least one 128 x 256 tile per compute unit).  (1 was a kernel of rounds
+ * 2-3.)  Host function; needs a current device.  The mixer's bf16 numerics depend on M = B*N*8 through this choice. */
 int    pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16);
 
 /* pips_conv_nhwc_f32 with bf16 MFMA operands: the fp32 map is rounded to bf16 while it is staged, wgt_bf16 is the

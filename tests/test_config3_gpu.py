@@ -3,7 +3,7 @@ in the encoder convolutions and every mixer Linear -- end to end against the ora
 would be run in bf16 (``torch.autocast(bfloat16)`` around nets/pips.py:428-611).
 
 This is the only shape at which the forward reaches the generated-assembly channel-mix GEMMs (M = B*N*8 = 16384 rows:
-``gemm_bf16_gelu_asm_kernel`` / ``gemm_bf16_res_asm_kernel``) and the LDS-resident layer-1 convolution at full
+``gemm_bf16_gelu256_asm_kernel`` / ``gemm_bf16_t4_res_kernel``) and the LDS-resident layer-1 convolution at full
 occupancy; the smaller bf16 tests (tests/test_forward_gpu.py) run M = 1024 and never select them.
 
 Tolerance: 2e-2 px on the tamed weights against the bf16-autocast oracle; the two bf16 runs round at
@@ -32,7 +32,8 @@ def test_config3_routes_reach_the_assembly_gemms():
     M = B * N * S
     assert lib.pips_gemm_bf16_route(M, 2048, 512, 1, 1, 1) == 2          # up-projection + GELU, bf16 out
     assert lib.pips_gemm_bf16_route(M, 512, 2048, 2, 1, 0) == 3          # down-projection + residual, fp32 out: gemm_bf16_t4_res_kernel
-    assert lib.pips_gemm_bf16_route(2 * M, 384, 2048, 2, 1, 0) == 1      # N % 256 != 0: the 256 x 128 assembly kernel
+    assert lib.pips_gemm_bf16_route(2 * M, 384, 2048, 2, 1, 0) == 0      # N % 256 != 0: register-staged
+    assert lib.pips_gemm_bf16_route(M, 1920, 512, 1, 1, 1) == 0          # likewise for the up-projection form
     assert lib.pips_gemm_bf16_route(1024, 2048, 512, 1, 1, 1) == 0       # tests/test_forward_gpu.py geometry
     assert lib.pips_gemm_bf16_route(2048, 2048, 512, 1, 1, 1) == 0       # B=1, N=256
 

@@ -491,12 +491,12 @@ def test_mixer(P, split, weights_raw, arenas):
     (8192, 2048, 512, 1, True),        # 256 such tiles: one per block (no run-on)
     (16640, 2048, 512, 1, True),       # 65 row blocks: a block's tile pair straddles two column blocks (run-on across W panels)
     (32768, 1024, 512, 1, True),       # 512 tiles on 256 blocks, four column blocks
-    (16384, 1920, 512, 1, True),       # N % 256 != 0: the 256 x 128 kernel (gemm_bf16_gelu_asm_kernel), 4 tiles per block
+    (16384, 1920, 512, 1, True),       # N % 256 != 0: the register-staged kernel (the 256 x 128 assembly form of rounds 2-3 is gone)
     (1280, 2048, 512, 1, True),        # below either threshold -> register-staged kernel, same contract
     (16384, 512, 2048, 2, False),      # config-3 down-projection: 128 x 256 tiles, four waves (gemm_bf16_t4_res_kernel)
     (32896, 256, 128, 2, False),       # the same kernel: 257 tiles (not a multiple of the 8 XCDs), two K iterations (the minimum)
     (16384, 768, 192, 2, False),       # three column tiles per row block, three K iterations
-    (32768, 384, 1024, 2, False),      # N % 256 != 0: the 256 x 128 assembly kernel (gemm_bf16_res_asm_kernel)
+    (32768, 384, 1024, 2, False),      # N % 256 != 0: the register-staged kernel
     (4096, 512, 544, 0, False),        # input projection: fp32 A, 32-element K blocks
 ])
 def test_gemm_bf16(M, N, K, epi, out_bf16):
@@ -637,7 +637,7 @@ def test_fixed_window_entry_points_equal_the_general_ones(weights_raw):
     a1 = torch.zeros(n, device=dev)
     a2 = torch.zeros(n, device=dev)
     _lib.check(lib.pips_repack_weights(arr, len(srcs), _lib.ptr(a1), st()), "pips_repack_weights")
-    _lib.check(lib.pips_repack_weights_ex(arr, len(srcs), _lib.ptr(a2), 15, st()), "pips_repack_weights_ex")
+    _lib.check(lib.pips_repack_weights_ex(arr, len(srcs), _lib.ptr(a2), 7, st()), "pips_repack_weights_ex")
     torch.cuda.synchronize()
     used = a1 != 0                                                           # (alignment gaps are never written)
     assert torch.equal(a1[used], a0[used]) and torch.equal(a2, a1)
