@@ -33,7 +33,7 @@ def _stale(target: str, deps) -> bool:
 
 def headers():
     """Files every translation unit depends on (beyond its own source)."""
-    return [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tail.h"), os.path.join(CSRC, "gather_item_asm.inc"), os.path.join(CSRC, "gemm_bf16_tile_asm.inc"), os.path.join(CSRC, "gemm_bf16_t4_asm.inc"),
+    return [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tail.h"), os.path.join(CSRC, "gather_item_asm.inc"), os.path.join(CSRC, "gemm_bf16_tile_asm.inc"), os.path.join(CSRC, "gemm_bf16_t4_asm.inc"), os.path.join(CSRC, "gemm_bf16_t4up_asm.inc"),
             os.path.join(HERE, "..", "include", "pips_hip.h")]
 
 

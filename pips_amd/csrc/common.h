@@ -271,6 +271,8 @@ int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16);   // 0 reg
 // the large-M bf16 down-projection (+ bias + fp32 residual) on 128x256 tiles, four waves, 16x16x32 MFMAs (gemm_bf16_t4.hip)
 bool gemm_bf16_t4_takes(const GemmArgs& a, int a_bf16, int out_bf16);
 int launch_gemm_bf16_t4(const GemmArgs& a, hipStream_t st);
+bool gemm_bf16_t4up_takes(const GemmArgs& a, int a_bf16, int out_bf16, int* tpb);      // the up-projection form (GELU, K = 512)
+int launch_gemm_bf16_t4up(const GemmArgs& a, int tpb, hipStream_t st);
 // split-bf16 (bf16x3) fp32-grade GEMM / conv (gemm_x3.hip): A fp32, W = three bf16 planes [3][N][K]
 int launch_split_bf16x3(const float* src, size_t n, void* dst, hipStream_t st);
 int launch_gemm_x3(const GemmArgs& a, hipStream_t st);

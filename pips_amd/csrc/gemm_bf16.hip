@@ -433,6 +433,10 @@ int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st
                    "gemm_bf16: operand exceeds 2^32 elements");
     if (gemm_bf16_t4_takes(a, a_bf16, out_bf16)) return launch_gemm_bf16_t4(a, st);      // the config-3 down-projection
     {
+        int tpb = 1;
+        if (gemm_bf16_t4up_takes(a, a_bf16, out_bf16, &tpb)) return launch_gemm_bf16_t4up(a, tpb, st);   // ... and up-projection
+    }
+    {
         const int rc = launch_gemm_bf16_asm(a, a_bf16, out_bf16, st);      // the config-3 up-projection
         if (rc != 1) return rc;
     }

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_gelu256_asm_kernel(GemmArgs p, 
 // function of the problem and the device's CU count -- also behind pips_gemm_bf16_route(), which lets a test assert that a
 // forward's geometry reaches the assembly kernels.  (1 was the 256 x 128 down-projection kernel of rounds 2-3.)
 int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16) {
-    if (gemm_bf16_t4_takes(a, a_bf16, out_bf16)) return 3;           // (launch_gemm_bf16 asks that kernel first)
+    if (gemm_bf16_t4_takes(a, a_bf16, out_bf16)) return 3;           // (launch_gemm_bf16 asks these kernels first)
+    if (gemm_bf16_t4up_takes(a, a_bf16, out_bf16, nullptr)) return 4;
     if (!PIPS_TUNE("PIPS_BF16_ASM", 1)) return 0;                    // tuning hook: 0 = register-staged kernels only
     if (!a_bf16 || !out_bf16 || (a.epi & 0xff) != EPI_GELU || a.bias == nullptr || a.K != 512) return 0;
     if (a.lda % 8 != 0 || a.ldc % 8 != 0 || a.M % 256 != 0 || a.N % 256 != 0) return 0;

@@ -25,6 +25,10 @@
 #define PIPS_T4_INC "gemm_bf16_t4_asm.inc"      // tuning builds point this at another schedule of the generator
 #endif
 #include PIPS_T4_INC
+#ifndef PIPS_T4UP_INC
+#define PIPS_T4UP_INC "gemm_bf16_t4up_asm.inc"
+#endif
+#include PIPS_T4UP_INC
 
 namespace pips {
 
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_res_kernel(GemmArgs p, int t
     const int sw = (r16 >> 1) & 7;
     const unsigned rA0 = lds0 + (64 * wm + r16) * 128 + ((g ^ sw) * 16);                          // + i * 2048
     const unsigned rW0 = lds0 + T4_BM * 128 + (128 * wn + r16) * 128 + ((g ^ sw) * 16);          // + j * 2048
-    const unsigned rA1 = rA0 ^ 64, rW1 = rW0 ^ 64;
+    const unsigned rA1 = lds0 + ((rA0 - lds0) ^ 64), rW1 = lds0 + ((rW0 - lds0) ^ 64);
     // ---- residual / output / bias: acc tile (i, j) = R[m0 + 64 wm + 16 i + r16][n0 + 128 wn + 16 j + 4 g .. + 3]
     const float* Rb = p.R + (size_t)(m0 + 64 * wm) * p.ldr + n0 + 128 * wn;
     const float* Cb = p.C + (size_t)(m0 + 64 * wm) * p.ldc + n0 + 128 * wn;
@@ -81,6 +85,79 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_res_kernel(GemmArgs p, int t
                    [passW] "s"(t4_sgpr(passW)), [rstep] "s"(t4_sgpr(rstep)), [cstep] "s"(t4_sgpr(cstep)), [kt] "s"(t4_sgpr(kt))
     asm volatile(PIPS_T4_TEXT : T4_OPERANDS : PIPS_T4_CLOBBER);
 #undef T4_OPERANDS
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The up-projection C = bf16(gelu(bf16(A W^T + b))), K = 512, in the same style (round 4): 256 x 256 tile, four waves with 128 x 128
+// wave tiles and all 256 AccVGPRs as accumulators (0.25 fragment reads per MFMA against 0.375 above), a block walking `tpb`
+// consecutive row tiles of one column tile with the K pipeline running on across the tile boundary, exact polynomial GELU
+// (gelu_exact2's arithmetic: 4.8e-7, where the LDS table of gemm_bf16_gelu256_asm_kernel carried 2.4e-5) on the Linear's
+// bf16-rounded output.  The W rows of a tile are staged in a permuted order (w_perm) so that the 16 x 16 tiles 2 j', 2 j' + 1
+// together give a lane 8 consecutive output columns: one 16-byte store.  Body: gemm_bf16_t4up_asm.inc <- tools/gen_gemm_bf16_t4up.py.
+constexpr int T4U_B = 256, T4U_K = 512;
+constexpr int T4U_LDS = 2 * T4U_B * T4_BK * 2;              // 65 536 bytes
+
+__global__ __launch_bounds__(256) void gemm_bf16_t4_gelu_kernel(GemmArgs p, int tiles_m, int tpb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int runs = tiles_m / tpb;                            // blocks per column tile
+    const int tn = blockIdx.x / runs, tm0 = (blockIdx.x - tn * runs) * tpb;
+    const int m0 = tm0 * T4U_B, n0 = tn * T4U_B;
+
+    const int lr = tid >> 3, lc = tid & 7;
+    const unsigned short* Ab = reinterpret_cast<const unsigned short*>(p.A) + (size_t)m0 * p.lda;
+    const unsigned short* Wb = reinterpret_cast<const unsigned short*>(p.W) + (size_t)n0 * p.K;
+    // LDS row lr + 32 s of the W tile holds global row 32 s + w_perm(lr): rows are in MFMA order (column block j, row rho of it)
+    const int w_perm = 8 * ((lr & 15) >> 2) + 4 * (lr >> 4) + (lr & 3);
+    const unsigned voA = (unsigned)(lr * p.lda * 2 + lc * 16), voW = (unsigned)(w_perm * p.K * 2 + lc * 16);
+    const unsigned passA = (unsigned)(32 * p.lda * 2), passW = (unsigned)(32 * p.K * 2);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned wA = lds0 + lr * 128 + ((lc ^ ((lr >> 1) & 7)) * 16), wW = wA + T4U_B * 128;
+    const int sw = (r16 >> 1) & 7;
+    const unsigned oA = (128 * wm + r16) * 128 + ((g ^ sw) * 16), oW = T4U_B * 128 + (128 * wn + r16) * 128 + ((g ^ sw) * 16);
+    const unsigned rA0 = lds0 + oA, rW0 = lds0 + oW, rA1 = lds0 + (oA ^ 64), rW1 = lds0 + (oW ^ 64);
+    // output: lane = row r16 of a 16-row block, 8 consecutive bf16 columns 32 j' + 8 g .. + 7 of the wave's 128
+    unsigned short* Cb = reinterpret_cast<unsigned short*>(p.C) + (size_t)(m0 + 128 * wm) * p.ldc + n0 + 128 * wn;
+    const float* Bb = p.bias + n0 + 128 * wn;
+    const unsigned voC = (unsigned)((r16 * p.ldc + 8 * g) * 2), voB = (unsigned)(32 * g);
+    const unsigned cstep = (unsigned)(16 * p.ldc * 2), tstepC = (unsigned)(T4U_B * p.ldc * 2);
+    const unsigned tstepA = (unsigned)(T4U_B * p.lda * 2 - 128 * (T4U_K / T4_BK));
+    asm volatile(PIPS_T4UP_TEXT
+                 :
+                 : [rA0] "v"(rA0), [rW0] "v"(rW0), [rA1] "v"(rA1), [rW1] "v"(rW1), [wA] "v"(wA), [wW] "v"(wW), [voA] "v"(voA),
+                   [voW] "v"(voW), [voC] "v"(voC), [voB] "v"(voB), [alo] "s"(T4_LO(Ab)), [ahi] "s"(T4_HI(Ab)), [wlo] "s"(T4_LO(Wb)),
+                   [whi] "s"(T4_HI(Wb)), [clo] "s"(T4_LO(Cb)), [chi] "s"(T4_HI(Cb)), [blo] "s"(T4_LO(Bb)), [bhi] "s"(T4_HI(Bb)),
+                   [passA] "s"(t4_sgpr(passA)), [passW] "s"(t4_sgpr(passW)), [cstep] "s"(t4_sgpr(cstep)), [tstepC] "s"(t4_sgpr(tstepC)),
+                   [tstepA] "s"(t4_sgpr(tstepA)), [ntile] "s"(t4_sgpr((unsigned)tpb))
+                 : PIPS_T4UP_CLOBBER);
+}
+
+// Whether the up-projection form (bf16 A and C, GELU, K = 512) goes to gemm_bf16_t4_gelu_kernel; *tpb = row tiles per block.
+bool gemm_bf16_t4up_takes(const GemmArgs& a, int a_bf16, int out_bf16, int* tpb) {
+    if (!PIPS_TUNE("PIPS_BF16_T4UP", 1)) return false;       // tuning hook: 0 = gemm_bf16_gelu256_asm_kernel
+    if (!a_bf16 || !out_bf16 || (a.epi & 0xff) != EPI_GELU || a.bias == nullptr || a.K != T4U_K) return false;
+    if (a.M % T4U_B != 0 || a.N % T4U_B != 0 || a.lda % 8 != 0 || a.ldc % 8 != 0) return false;
+    if ((unsigned long long)a.M * a.lda * 2ull >= (1ull << 31) || (unsigned long long)288 * a.ldc * 2ull >= (1ull << 31)) return false;
+    const int cus = device_cus();
+    const long tiles = (long)(a.M / T4U_B) * (a.N / T4U_B);
+    if (cus <= 0 || tiles < cus) return false;
+    int t = PIPS_TUNE("PIPS_BF16_T4UP_TPB", 2);
+    while (t > 1 && ((a.M / T4U_B) % t != 0 || tiles / t < cus)) --t;
+    if (tpb) *tpb = t;
+    return true;
+}
+
+int launch_gemm_bf16_t4up(const GemmArgs& a, int tpb, hipStream_t st) {
+    const int tiles_m = a.M / T4U_B, blocks = tiles_m / tpb * (a.N / T4U_B);
+    static std::atomic<unsigned long long> raised{0};
+    const int rc = ensure_dynamic_lds(raised, (const void*)gemm_bf16_t4_gelu_kernel, T4U_LDS);
+    if (rc != PIPS_OK) return rc;
+    hipLaunchKernelGGL(gemm_bf16_t4_gelu_kernel, dim3(blocks), dim3(256), T4U_LDS, st, a, tiles_m, tpb);
+    PIPS_CHECK_LAUNCH("gemm_bf16_t4_gelu_kernel");
+    return PIPS_OK;
 }
 
 // Whether the down-projection form (bf16 A, fp32 C, + bias + fp32 residual) of a bf16-operand GEMM goes to this kernel.

@@ -178,3 +178,7 @@ def test_build_script_dependencies_exist_and_asm_is_current(tmp_path):
     env["PIPS_GEN_OUT"] = str(out3)
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_gemm_bf16_t4.py")], env=env, stdout=subprocess.DEVNULL)
     assert out3.read_text() == open(os.path.join(root, "pips_amd", "csrc", "gemm_bf16_t4_asm.inc")).read()
+    out4 = tmp_path / "gemm_bf16_t4up_asm.inc"
+    env["PIPS_GEN_OUT"] = str(out4)
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_gemm_bf16_t4up.py")], env=env, stdout=subprocess.DEVNULL)
+    assert out4.read_text() == open(os.path.join(root, "pips_amd", "csrc", "gemm_bf16_t4up_asm.inc")).read()

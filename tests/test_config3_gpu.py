@@ -30,7 +30,7 @@ def test_config3_routes_reach_the_assembly_gemms():
     from pips_amd import _lib
     lib = _lib.load()
     M = B * N * S
-    assert lib.pips_gemm_bf16_route(M, 2048, 512, 1, 1, 1) == 2          # up-projection + GELU, bf16 out
+    assert lib.pips_gemm_bf16_route(M, 2048, 512, 1, 1, 1) == 4          # up-projection + GELU, bf16 out: gemm_bf16_t4_gelu_kernel
     assert lib.pips_gemm_bf16_route(M, 512, 2048, 2, 1, 0) == 3          # down-projection + residual, fp32 out: gemm_bf16_t4_res_kernel
     assert lib.pips_gemm_bf16_route(2 * M, 384, 2048, 2, 1, 0) == 0      # N % 256 != 0: register-staged
     assert lib.pips_gemm_bf16_route(M, 1920, 512, 1, 1, 1) == 0          # likewise for the up-projection form

@@ -215,7 +215,8 @@ def body():
     e.lgkm, e.vm = [], []
     for j in range(8):
         e.vmem("buffer_load_dwordx4 v[%d:%d], %%[voB], s[%d:%d], 0 offen offset:%d" % (4 * j, 4 * j + 3, RS_B, RS_B + 3, 64 * j), ("bias", j))
-    e.raw("s_nop 7")                                         # MFMA results -> v_accvgpr_read
+    e.raw("s_nop 15")
+    e.raw("s_nop 15")                                         # MFMA results -> v_accvgpr_read
     for j in range(8):
         e.need_vm({("bias", j)})
         for i in range(4):
