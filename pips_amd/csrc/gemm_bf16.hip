@@ -436,10 +436,6 @@ int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st
         int tpb = 1;
         if (gemm_bf16_t4up_takes(a, a_bf16, out_bf16, &tpb)) return launch_gemm_bf16_t4up(a, tpb, st);   // ... and up-projection
     }
-    {
-        const int rc = launch_gemm_bf16_asm(a, a_bf16, out_bf16, st);      // the config-3 up-projection
-        if (rc != 1) return rc;
-    }
     if (a_bf16) return out_bf16 ? pick_tile<true, true>(a, st) : pick_tile<true, false>(a, st);
     return out_bf16 ? pick_tile<false, true>(a, st) : pick_tile<false, false>(a, st);
 }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_res_kernel(GemmArgs p, int t
 // The up-projection C = bf16(gelu(bf16(A W^T + b))), K = 512, in the same style (round 4): 256 x 256 tile, four waves with 128 x 128
 // wave tiles and all 256 AccVGPRs as accumulators (0.25 fragment reads per MFMA against 0.375 above), a block walking `tpb`
 // consecutive row tiles of one column tile with the K pipeline running on across the tile boundary, exact polynomial GELU
-// (gelu_exact2's arithmetic: 4.8e-7, where the LDS table of gemm_bf16_gelu256_asm_kernel carried 2.4e-5) on the Linear's
+// (gelu_exact2's arithmetic: 4.8e-7, where the LDS table of round 3's gemm_bf16_gelu256_asm_kernel carried 2.4e-5 -- profiles/r4_probe_bf16_up_t4.txt has the A/B against that kernel) on the Linear's
 // bf16-rounded output.  The W rows of a tile are staged in a permuted order (w_perm) so that the 16 x 16 tiles 2 j', 2 j' + 1
 // together give a lane 8 consecutive output columns: one 16-byte store.  Body: gemm_bf16_t4up_asm.inc <- tools/gen_gemm_bf16_t4up.py.
 constexpr int T4U_B = 256, T4U_K = 512;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_gelu_kernel(GemmArgs p, int 
 
 // Whether the up-projection form (bf16 A and C, GELU, K = 512) goes to gemm_bf16_t4_gelu_kernel; *tpb = row tiles per block.
 bool gemm_bf16_t4up_takes(const GemmArgs& a, int a_bf16, int out_bf16, int* tpb) {
-    if (!PIPS_TUNE("PIPS_BF16_T4UP", 1)) return false;       // tuning hook: 0 = gemm_bf16_gelu256_asm_kernel
+    if (!PIPS_TUNE("PIPS_BF16_T4UP", 1)) return false;       // tuning hook: 0 = the register-staged kernel
     if (!a_bf16 || !out_bf16 || (a.epi & 0xff) != EPI_GELU || a.bias == nullptr || a.K != T4U_K) return false;
     if (a.M % T4U_B != 0 || a.N % T4U_B != 0 || a.lda % 8 != 0 || a.ldc % 8 != 0) return false;
     if ((unsigned long long)a.M * a.lda * 2ull >= (1ull << 31) || (unsigned long long)288 * a.ldc * 2ull >= (1ull << 31)) return false;
@@ -177,6 +177,16 @@ int launch_gemm_bf16_t4(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gemm_bf16_t4_res_kernel, dim3(ntiles), dim3(256), T4_LDS, st, a, tiles_n, ntiles);
     PIPS_CHECK_LAUNCH("gemm_bf16_t4_res_kernel");
     return PIPS_OK;
+}
+
+// Which kernel a bf16-operand GEMM goes to: 0 = the register-staged gemm_bf16_kernel (gemm_bf16.hip), 3 = gemm_bf16_t4_res_kernel
+// (down-projection + residual), 4 = gemm_bf16_t4_gelu_kernel (up-projection + GELU).  Pure function of the problem and the
+// device's CU count -- behind pips_gemm_bf16_route(), which lets a test assert that a forward's geometry reaches these kernels.
+// (1 and 2 were the LDS-DMA assembly kernels of rounds 2-3, gemm_bf16_asm.hip: removed in round 4.)
+int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16) {
+    if (gemm_bf16_t4_takes(a, a_bf16, out_bf16)) return 3;
+    if (gemm_bf16_t4up_takes(a, a_bf16, out_bf16, nullptr)) return 4;
+    return 0;
 }
 
 }  // namespace pips

@@ -158,7 +158,7 @@ def test_packed_weights_follow_parameter_changes():
 
 def test_build_script_dependencies_exist_and_asm_is_current(tmp_path):
     """The build script's dependency list names real files (a stale name makes every rebuild fail), and the committed
-    generated assembly is what tools/gen_gather_asm.py / tools/gen_gemm_bf16_asm.py emit today."""
+    generated assembly is what tools/gen_gather_asm.py / tools/gen_gemm_bf16_t4.py / tools/gen_gemm_bf16_t4up.py emit today."""
     import subprocess, sys
     from pips_amd import _build
     for h in _build.headers():
@@ -170,10 +170,6 @@ def test_build_script_dependencies_exist_and_asm_is_current(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_gather_asm.py")], env=env, stdout=subprocess.DEVNULL)
     assert out.read_text() == open(os.path.join(root, "pips_amd", "csrc", "gather_item_asm.inc")).read()
-    out2 = tmp_path / "gemm_bf16_tile_asm.inc"
-    env["PIPS_GEN_OUT"] = str(out2)
-    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_gemm_bf16_asm.py")], env=env, stdout=subprocess.DEVNULL)
-    assert out2.read_text() == open(os.path.join(root, "pips_amd", "csrc", "gemm_bf16_tile_asm.inc")).read()
     out3 = tmp_path / "gemm_bf16_t4_asm.inc"
     env["PIPS_GEN_OUT"] = str(out3)
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_gemm_bf16_t4.py")], env=env, stdout=subprocess.DEVNULL)

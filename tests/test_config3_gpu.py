@@ -3,7 +3,7 @@ in the encoder convolutions and every mixer Linear -- end to end against the ora
 would be run in bf16 (``torch.autocast(bfloat16)`` around nets/pips.py:428-611).
 
 This is the only shape at which the forward reaches the generated-assembly channel-mix GEMMs (M = B*N*8 = 16384 rows:
-``gemm_bf16_gelu256_asm_kernel`` / ``gemm_bf16_t4_res_kernel``) and the LDS-resident layer-1 convolution at full
+``gemm_bf16_t4_gelu_kernel`` / ``gemm_bf16_t4_res_kernel``) and the LDS-resident layer-1 convolution at full
 occupancy; the smaller bf16 tests (tests/test_forward_gpu.py) run M = 1024 and never select them.
 
 Tolerance: 2e-2 px on the tamed weights against the bf16-autocast oracle; the two bf16 runs round at

@@ -487,9 +487,9 @@ def test_mixer(P, split, weights_raw, arenas):
 
 
 @pytest.mark.parametrize("M,N,K,epi,out_bf16", [
-    (16384, 2048, 512, 1, True),       # config-3 up-projection: 256 x 256 tiles, two per block (gemm_bf16_gelu256_asm_kernel)
+    (16384, 2048, 512, 1, True),       # config-3 up-projection: 256 x 256 tiles, two per block (gemm_bf16_t4_gelu_kernel)
     (8192, 2048, 512, 1, True),        # 256 such tiles: one per block (no run-on)
-    (16640, 2048, 512, 1, True),       # 65 row blocks: a block's tile pair straddles two column blocks (run-on across W panels)
+    (16640, 2048, 512, 1, True),       # 65 row tiles (odd): one tile per block
     (32768, 1024, 512, 1, True),       # 512 tiles on 256 blocks, four column blocks
     (16384, 1920, 512, 1, True),       # N % 256 != 0: the register-staged kernel (the 256 x 128 assembly form of rounds 2-3 is gone)
     (1280, 2048, 512, 1, True),        # below either threshold -> register-staged kernel, same contract
@@ -501,7 +501,7 @@ def test_mixer(P, split, weights_raw, arenas):
 ])
 def test_gemm_bf16(M, N, K, epi, out_bf16):
     """pips_gemm_bf16 against torch: bf16 operands, fp32 accumulation, exact GELU, result rounded to the output type.  (The
-    generated-assembly kernel rounds the Linear's output to bf16 before the GELU, as autocast does; the register-staged one
+    four-wave 256 x 256 kernel rounds the Linear's output to bf16 before the GELU, as autocast does; the register-staged one
     feeds the fp32 accumulator to it: one or two bf16 roundings, |gelu'| <= 1.13 -> both within 1.2e-2 of the fp32 GELU of the
     fp32 pre-activation, relative to max(|gelu|, 0.25).)"""
     from pips_amd import ops
