@@ -601,35 +601,24 @@ typedef __bf16 bf16x8_tm __attribute__((ext_vector_type(8)));
 // reductions and the memory round trips between them -- 30.5 us at 2048 particles against 35 for the VALU kernel): the
 // lane holds 4 tokens x 16 channels (c = 128*g + 4*(lane & 31) + q), the LayerNorm sums stay inside the wave (one DPP
 // transpose-reduce, no LDS, no barrier), 16 channel slots x 3 MFMAs.
-// Round 4, WPP = 2: TWO waves per particle, 256 channels (two groups of 128) each.  The kernel is a chain per wave -- tile in,
-// LayerNorm, 16 x (MFMA -> 16 GELUs -> 2 MFMAs), LayerNorm, tile out -- at two waves per SIMD (196 registers); with half the
-// tile per wave a wave needs ~120 registers, four fit a SIMD, and the chains of four waves fill each other's waits.  The two
-// halves of a LayerNorm sum meet in 128 bytes of LDS (one barrier per LayerNorm; both waves add them in the same order).
-// GELU5: the GELU of the hidden units (rounded to bf16 right behind it) with the degree-5 exponent polynomial (common.h).
-template <int WPP, bool GELU5>
-#ifndef PIPS_TOKEN_OCC
-#define PIPS_TOKEN_OCC 4      // waves per SIMD the two-waves-per-particle form is held to (tuning builds: 3 = no spill at all)
-#endif
-__global__ __launch_bounds__(256, WPP == 2 ? PIPS_TOKEN_OCC : 2) void token_mix_mfma_kernel(const float* __restrict__ arena, MixLayerW L, float* __restrict__ x,
-                                                                                unsigned* __restrict__ xn, int particles) {
-    constexpr int NG = 4 / WPP;                                               // channel groups of 128 per wave
-    __shared__ float red[WPP == 2 ? 2 * 2 * 2 * 8 : 1];                       // [LayerNorm pass parity][particle of the block][wave half][sum, sum of squares][token]... see ln_stats
+// Round 4: the hidden units' GELU with the degree-5 exponent polynomial (gelu_bf16out2: the result is rounded to bf16 at once):
+// -2.4 % on the bf16 mixer pass.  TWO waves per particle (half the tile and ~120 registers per wave, four waves per SIMD, the
+// LayerNorm halves meeting in LDS) was built and measured: +2 % with the 12-register spill of a 128-register budget, the same as
+// one wave per particle when held to three waves per SIMD (profiles/r4_probe_token_mix_bf16_variants.txt) -- not kept.
+__global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __restrict__ arena, MixLayerW L, float* __restrict__ x,
+                                                                unsigned* __restrict__ xn, int particles) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int sub = WPP == 2 ? (wave & 1) : 0, pl = WPP == 2 ? (wave >> 1) : wave;
-    const int p_raw = blockIdx.x * (4 / WPP) + pl;                            // (wave-uniform)
-    const bool live = p_raw < particles;
-    if (WPP == 1 && !live) return;
-    const int p = live ? p_raw : particles - 1;                               // WPP = 2: a dead pair still meets its barriers
-    const int g0 = sub * NG;
-    // ---- the particle's tile first: its loads are the long ones (HBM / Infinity Cache), the weights below hit L2
+    const int p = blockIdx.x * 4 + wave;                                      // (wave-uniform)
+    if (p >= particles) return;
+    // ---- the particle's tile first: its 16 loads are the long ones (HBM / Infinity Cache), the weights below hit L2
     float* xp = x + ((size_t)p * S + 4 * half) * PIPS_DMIX + 4 * l31;         // + r * 512 + g * 128
-    float xv[4][4 * NG];                                                      // [token r][(g - g0) * 4 + q]
+    float xv[4][16];                                                          // [token r][g * 4 + q]
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const float4 v = *reinterpret_cast<const float4*>(xp + r * PIPS_DMIX + (g0 + g) * 128);
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + r * PIPS_DMIX + g * 128);
             xv[r][4 * g] = v.x; xv[r][4 * g + 1] = v.y; xv[r][4 * g + 2] = v.z; xv[r][4 * g + 3] = v.w;
         }
     // ---- weights as MFMA A fragments
@@ -657,14 +646,14 @@ __global__ __launch_bounds__(256, WPP == 2 ? PIPS_TOKEN_OCC : 2) void token_mix_
 #pragma unroll
     for (int r = 0; r < 4; ++r) b3r[r] = arena[L.tb3 + 4 * half + r];
 
-    // per-token mean / rstd of the lane's four tokens: one pass of sums, reduced over the wave (and, WPP = 2, over the pair)
-    auto ln_stats = [&](const float (&v)[4][4 * NG], float (&mean)[4], float (&rstd)[4], int pass) __attribute__((always_inline)) {
+    // per-token mean / rstd of the lane's four tokens: one pass of sums, reduced over the wave
+    auto ln_stats = [&](const float (&v)[4][16], float (&mean)[4], float (&rstd)[4]) __attribute__((always_inline)) {
         float s1[4], s2[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4 * NG; k += 2) {
+            for (int k = 0; k < 16; k += 2) {
                 a += v[r][k]; b += v[r][k + 1];
                 c = fmaf(v[r][k], v[r][k], c); d = fmaf(v[r][k + 1], v[r][k + 1], d);
             }
@@ -677,16 +666,7 @@ __global__ __launch_bounds__(256, WPP == 2 ? PIPS_TOKEN_OCC : 2) void token_mix_
             sa[t] = mine ? s1[t & 3] : 0.f;
             sb[t] = mine ? s2[t & 3] : 0.f;
         }
-        float ta = wave_sum8(sa), tb = wave_sum8(sb);                         // lane l: totals of token l & 7 (this wave's channels)
-        if (WPP == 2) {
-            // red[pass][pl][sub][0 / 1][token]: the two passes use different halves of the array, so ONE barrier per pass is enough
-            float* mine = red + ((pass * 2 + pl) * 2 + sub) * 16;
-            if (lane < 8) { mine[lane] = ta; mine[8 + lane] = tb; }
-            lds_barrier();
-            const float* r0 = red + ((pass * 2 + pl) * 2) * 16;
-            ta = r0[lane & 7] + r0[16 + (lane & 7)];
-            tb = r0[8 + (lane & 7)] + r0[24 + (lane & 7)];
-        }
+        const float ta = wave_sum8(sa), tb = wave_sum8(sb);                   // lane l: totals of token l & 7
         const float m = ta * (1.0f / PIPS_DMIX);
         const float var = fmaxf(tb * (1.0f / PIPS_DMIX) - m * m, 0.f);
         const float rs = rsqrt_nr(var + 1e-5f);
@@ -699,12 +679,12 @@ __global__ __launch_bounds__(256, WPP == 2 ? PIPS_TOKEN_OCC : 2) void token_mix_
         }
     };
     float mean[4], rstd[4];
-    ln_stats(xv, mean, rstd, 0);
+    ln_stats(xv, mean, rstd);
 
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const float4 g1 = *reinterpret_cast<const float4*>(arena + L.ln1g + (g0 + g) * 128 + 4 * l31);
-        const float4 be1 = *reinterpret_cast<const float4*>(arena + L.ln1b + (g0 + g) * 128 + 4 * l31);
+    for (int g = 0; g < 4; ++g) {
+        const float4 g1 = *reinterpret_cast<const float4*>(arena + L.ln1g + g * 128 + 4 * l31);
+        const float4 be1 = *reinterpret_cast<const float4*>(arena + L.ln1b + g * 128 + 4 * l31);
         const float g1a[4] = {g1.x, g1.y, g1.z, g1.w}, be1a[4] = {be1.x, be1.y, be1.z, be1.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -720,7 +700,7 @@ __global__ __launch_bounds__(256, WPP == 2 ? PIPS_TOKEN_OCC : 2) void token_mix_
             unsigned hb[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const f2 gq = GELU5 ? gelu_bf16out2((f2){h[2 * i], h[2 * i + 1]}) : gelu_exact2((f2){h[2 * i], h[2 * i + 1]});
+                const f2 gq = gelu_bf16out2((f2){h[2 * i], h[2 * i + 1]});      // (rounded to bf16 in the next line)
                 hb[i] = pack2_bf16(gq.x, gq.y);
             }
             const uint4 k0 = make_uint4(hb[0], hb[1], hb[2], hb[3]), k1 = make_uint4(hb[4], hb[5], hb[6], hb[7]);
@@ -734,25 +714,23 @@ __global__ __launch_bounds__(256, WPP == 2 ? PIPS_TOKEN_OCC : 2) void token_mix_
         }
         // the new residual stream of these 128 channels goes out while the next group is computed (all waves of the
         // launch run in one round, in lock-step: stores held back to the end would queue behind one another)
-        if (live) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<float4*>(xp + r * PIPS_DMIX + (g0 + g) * 128) = make_float4(xv[r][4 * g], xv[r][4 * g + 1], xv[r][4 * g + 2], xv[r][4 * g + 3]);
-        }
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4*>(xp + r * PIPS_DMIX + g * 128) = make_float4(xv[r][4 * g], xv[r][4 * g + 1], xv[r][4 * g + 2], xv[r][4 * g + 3]);
     }
-    ln_stats(xv, mean, rstd, 1);
+    ln_stats(xv, mean, rstd);
     unsigned* xnp = xn + ((size_t)p * S + 4 * half) * (PIPS_DMIX / 2) + 2 * l31;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const float4 g2 = *reinterpret_cast<const float4*>(arena + L.ln2g + (g0 + g) * 128 + 4 * l31);
-        const float4 be2 = *reinterpret_cast<const float4*>(arena + L.ln2b + (g0 + g) * 128 + 4 * l31);
+    for (int g = 0; g < 4; ++g) {
+        const float4 g2 = *reinterpret_cast<const float4*>(arena + L.ln2g + g * 128 + 4 * l31);
+        const float4 be2 = *reinterpret_cast<const float4*>(arena + L.ln2b + g * 128 + 4 * l31);
         const float g2a[4] = {g2.x, g2.y, g2.z, g2.w}, be2a[4] = {be2.x, be2.y, be2.z, be2.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float n[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) n[q] = (xv[r][4 * g + q] - mean[r]) * (rstd[r] * g2a[q]) + be2a[q];
-            if (live) *reinterpret_cast<uint2*>(xnp + r * (PIPS_DMIX / 2) + (g0 + g) * 64) = make_uint2(pack2_bf16(n[0], n[1]), pack2_bf16(n[2], n[3]));
+            *reinterpret_cast<uint2*>(xnp + r * (PIPS_DMIX / 2) + g * 64) = make_uint2(pack2_bf16(n[0], n[1]), pack2_bf16(n[2], n[3]));
         }
     }
 }
@@ -875,12 +853,7 @@ int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn
         return launch_token_mix_any<PIPS_S_MAX>(arena, L, x, xn, particles, st, xn_bf16, Sw);
     if (xn_bf16 && PIPS_TUNE("PIPS_TOKEN_MFMA", 1)) {
         // bf16-operand mixer: token MLP on the matrix cores, one wave per particle
-        unsigned* xnu = reinterpret_cast<unsigned*>(xn);
-        const int wpp = PIPS_TUNE("PIPS_TOKEN_WPP", 2), g5 = PIPS_TUNE("PIPS_TOKEN_GELU5", 1);      // tuning hooks: 1 / 0 = round 3's form
-        if (wpp == 2 && g5) hipLaunchKernelGGL((token_mix_mfma_kernel<2, true>), dim3(cdiv(particles, 2)), dim3(256), 0, st, arena, L, x, xnu, particles);
-        else if (wpp == 2) hipLaunchKernelGGL((token_mix_mfma_kernel<2, false>), dim3(cdiv(particles, 2)), dim3(256), 0, st, arena, L, x, xnu, particles);
-        else if (g5) hipLaunchKernelGGL((token_mix_mfma_kernel<1, true>), dim3(cdiv(particles, 4)), dim3(256), 0, st, arena, L, x, xnu, particles);
-        else hipLaunchKernelGGL((token_mix_mfma_kernel<1, false>), dim3(cdiv(particles, 4)), dim3(256), 0, st, arena, L, x, xnu, particles);
+        hipLaunchKernelGGL(token_mix_mfma_kernel, dim3(cdiv(particles, 4)), dim3(256), 0, st, arena, L, x, reinterpret_cast<unsigned*>(xn), particles);
         PIPS_CHECK_LAUNCH("token_mix_mfma_kernel");
         return PIPS_OK;
     }
