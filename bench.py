@@ -323,6 +323,11 @@ def config4_leg(device):
     fwd = lambda: model(xys, rgbs, iters=ITERS)
     preds = fwd()[0]
     t_fwd = ev_time_ms(fwd, 2)
+    # the same forward in the fp32-grade split-bf16 matrix mode (config 4 is 77 % fp32 GEMM at 0.85 of a roof that mode may exceed)
+    model.matmul = "split"
+    fwd()
+    t_split = ev_time_ms(fwd, 2)
+    model.matmul = "exact"
     # gather in isolation on the real maps: iteration-0 state (the dense grid) and the state after 6 updates
     arena = model._packed(device)
     H8, W8, F, M = h // STRIDE, w // STRIDE, b * S, b * n * S
@@ -350,6 +355,8 @@ def config4_leg(device):
     lds_floor_ms = 0.78 * b * S * n * 4 * 64 * 128 * 4 / (256.0 * 256 * 2.4e9) * 1e3
     return {"workload": "BASELINE configs[3]: B=4 S=8 720x1280 N=4096 (64x64 grid) I=6 fp32 stride 8, encoder included",
             "value": b * S * n * ITERS / t_fwd * 1e3, "unit": "particle-updates/s", "ms_per_step": t_fwd, "dtype": "f32",
+            "split_bf16": {"ms_per_step": t_split, "value": b * S * n * ITERS / t_split * 1e3,
+                           "note": "Pips.matmul='split' at the same size; same 1e-3 px gate (tests/test_config45_gpu.py)"},
             "gather_roofline": {"bound": "hbm", "kernel": "gather_tiled_kernel", "achieved": dom["achieved_GBs"],
                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": traffic,
                                 "traffic_source": traffic_src,
