@@ -3,7 +3,7 @@
 # of the config-3 / config-4 legs, and FETCH_SIZE / WRITE_SIZE counter passes of the same two commands (separate runs: counters and
 # --stats traces are never combined).  Outputs under gpurun_out/prof_<tag>_*; copy what is to be judged into profiles/.
 # usage: sh tools/profile_round.sh r2
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 cd /tmp
