@@ -3,7 +3,7 @@
 # --stats traces are never combined) for the headline command, the config-3 leg and the split-bf16 mode, plus the stock
 # library yardsticks (rocBLAS / MIOpen / hipBLASLt through torch) that DESIGN.md quotes.  Run on the GPU box:
 #   sh tools/profile_mfma.sh r3      -> gpurun_out/<tag>_pmc_mfma_util_{exact,config3,split}.txt, <tag>_probe_*.txt
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 cd /tmp
