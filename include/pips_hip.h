@@ -276,9 +276,9 @@ int    pips_gemm_bf16(const void* A, int a_bf16, int lda, const void* W, const f
                       int M, int N, int K, int epi, const float* R, int ldr, void* stream);
 /* Which kernel pips_gemm_bf16 (and the bf16 mixer of pips_forward) takes for a problem with bias and, for epi = residual, an
  * fp32 residual of ldr = N: 0 = register-staged gemm_bf16_kernel; 3 = gemm_bf16_t4_res_kernel (down-projection: bf16 A, fp32 C,
- * bias + residual, M % 128 == 0, N % 256 == 0, K % 64 == 0, at least one 128 x 256 tile per compute unit); 4 =
- * gemm_bf16_t4_gelu_kernel (up-projection: bf16 A and C, GELU, K = 512, M and N multiples of 256, at least one 256 x 256 tile per
- * compute unit; rounds the Linear output to bf16 ahead of the GELU as autocast does).  Both are four-wave kernels on
+ * bias + residual, M % 128 == 0, N % 256 == 0, K % 64 == 0, at least half a 128 x 256 tile per compute unit); 4 =
+ * gemm_bf16_t4_gelu_kernel (up-projection: bf16 A and C, GELU, K = 512, M and N multiples of 256, at least three quarters of a 256 x 256
+ * tile per compute unit; rounds the Linear output to bf16 ahead of the GELU as autocast does).  Both are four-wave kernels on
  * v_mfma_f32_16x16x32_bf16 with a generated static schedule (1 and 2 were kernels of rounds 2-3).  Host function;
  * needs a current device.  The mixer's bf16 numerics depend on M = B*N*8 through this choice. */
 int    pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16);

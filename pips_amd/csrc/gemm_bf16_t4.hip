@@ -143,7 +143,7 @@ bool gemm_bf16_t4up_takes(const GemmArgs& a, int a_bf16, int out_bf16, int* tpb)
     if ((unsigned long long)a.M * a.lda * 2ull >= (1ull << 31) || (unsigned long long)288 * a.ldc * 2ull >= (1ull << 31)) return false;
     const int cus = device_cus();
     const long tiles = (long)(a.M / T4U_B) * (a.N / T4U_B);
-    if (cus <= 0 || tiles * 100 < (long)cus * PIPS_TUNE("PIPS_BF16_T4UP_MINPCT", 100)) return false;
+    if (cus <= 0 || tiles * 100 < (long)cus * PIPS_TUNE("PIPS_BF16_T4UP_MINPCT", 75)       /* M = 6144: -7.5 %; at 50 %, M = 4096: +3.4 % */) return false;
     int t = PIPS_TUNE("PIPS_BF16_T4UP_TPB", 2);
     while (t > 1 && ((a.M / T4U_B) % t != 0 || tiles / t < cus)) --t;
     if (tpb) *tpb = t;
@@ -169,8 +169,9 @@ bool gemm_bf16_t4_takes(const GemmArgs& a, int a_bf16, int out_bf16) {
     if ((unsigned long long)80 * a.ldr * 4ull >= (1ull << 31) || (unsigned long long)80 * a.ldc * 4ull >= (1ull << 31)) return false;   // (buffer offsets inside a wave tile)
     if ((unsigned long long)(T4_BM + 32) * a.lda * 2ull >= (1ull << 31) || (unsigned long long)(T4_BN + 32) * a.K * 2ull >= (1ull << 31)) return false;
     const int cus = device_cus();
-    // (tuning hook PIPS_BF16_T4_MINPCT: tiles needed, in percent of the CU count)
-    return mode == 2 || (cus > 0 && (long)(a.M / T4_BM) * (a.N / T4_BN) * 100 >= (long)cus * PIPS_TUNE("PIPS_BF16_T4_MINPCT", 100));
+    // tiles needed, in percent of the CU count: from HALF a tile per CU on this kernel is ahead of the register-staged one (bf16 mixer pass
+    // at M = 8192 / 12288: -9.4 % / -13.7 %; at a quarter, M = 4096: +14 %; profiles/r4_probe_bf16_t4_min_tiles.txt)
+    return mode == 2 || (cus > 0 && (long)(a.M / T4_BM) * (a.N / T4_BN) * 100 >= (long)cus * PIPS_TUNE("PIPS_BF16_T4_MINPCT", 50));
 }
 
 int launch_gemm_bf16_t4(const GemmArgs& a, hipStream_t st) {

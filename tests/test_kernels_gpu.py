@@ -489,11 +489,13 @@ def test_mixer(P, split, weights_raw, arenas):
 @pytest.mark.parametrize("M,N,K,epi,out_bf16", [
     (16384, 2048, 512, 1, True),       # config-3 up-projection: 256 x 256 tiles, two per block (gemm_bf16_t4_gelu_kernel)
     (8192, 2048, 512, 1, True),        # 256 such tiles: one per block (no run-on)
+    (6144, 2048, 512, 1, True),        # 192 tiles: three quarters of a tile per compute unit
     (16640, 2048, 512, 1, True),       # 65 row tiles (odd): one tile per block
     (32768, 1024, 512, 1, True),       # 512 tiles on 256 blocks, four column blocks
     (16384, 1920, 512, 1, True),       # N % 256 != 0: the register-staged kernel (the 256 x 128 assembly form of rounds 2-3 is gone)
     (1280, 2048, 512, 1, True),        # below either threshold -> register-staged kernel, same contract
     (16384, 512, 2048, 2, False),      # config-3 down-projection: 128 x 256 tiles, four waves (gemm_bf16_t4_res_kernel)
+    (8192, 512, 2048, 2, False),       # the same kernel at half a tile per compute unit (128 tiles)
     (32896, 256, 128, 2, False),       # the same kernel: 257 tiles (not a multiple of the 8 XCDs), two K iterations (the minimum)
     (16384, 768, 192, 2, False),       # three column tiles per row block, three K iterations
     (32768, 384, 1024, 2, False),      # N % 256 != 0: the register-staged kernel
