@@ -400,6 +400,7 @@ int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st
     PIPS_CHECK_ARG(a.Cin % 32 == 0 && a.K == a.KH * a.KW * a.Cin, "conv_bf16: Cin %% 32, K = kh*kw*Cin");
     PIPS_CHECK_ARG(in_bf16 || !out_bf16, "conv_bf16: fp32 map in, bf16 map out is not built");
     PIPS_CHECK_ARG(a.N % 2 == 0, "conv_bf16: Cout must be even");
+    if (conv_c96_t4_takes(a, frames, in_bf16, out_bf16)) return launch_conv_c96_t4(a, frames, tiles_m, st);    // 96 -> 96, 3x3 (conv_bf16_t4c.hip)
     if (in_bf16 == out_bf16) {
         const int rc = launch_conv3x3_c64_bf16(a, frames, tiles_m, st, in_bf16, out_bf16);     // 64 -> 64, 3x3: weights + halo patch in LDS
         if (rc != 1) return rc;

@@ -178,3 +178,7 @@ def test_build_script_dependencies_exist_and_asm_is_current(tmp_path):
     env["PIPS_GEN_OUT"] = str(out4)
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_gemm_bf16_t4up.py")], env=env, stdout=subprocess.DEVNULL)
     assert out4.read_text() == open(os.path.join(root, "pips_amd", "csrc", "gemm_bf16_t4up_asm.inc")).read()
+    out5 = tmp_path / "conv_bf16_t4c_asm.inc"
+    env["PIPS_GEN_OUT"] = str(out5)
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_conv_bf16_t4c.py")], env=env, stdout=subprocess.DEVNULL)
+    assert out5.read_text() == open(os.path.join(root, "pips_amd", "csrc", "conv_bf16_t4c_asm.inc")).read()

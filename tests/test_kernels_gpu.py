@@ -198,6 +198,9 @@ def test_conv_nhwc_bf16(F_, H, W, Cin, Cout):
     (16, 92, 124, 64, 64, 3, 1, False, True),    # the same kernel on a finished activation
     (2, 46, 62, 64, 64, 3, 1, False, True),      # too few tiles: implicit GEMM on bf16 maps
     (8, 92, 124, 96, 96, 3, 1, False, True),     # Cout = 96 on a 128-wide tile
+    (24, 92, 124, 96, 96, 3, 1, False, True),    # >= 4 tiles of 256 pixels per compute unit: the four-wave kernel of conv_bf16_t4c.hip
+    (24, 93, 125, 96, 96, 3, 1, False, True),    # the same, odd size: ragged last tile, column flags at every phase of a piece
+    (64, 20, 13, 96, 96, 3, 1, False, True),     # the same on tiny frames (two tiles each, image rows shorter than a piece run)
     (8, 93, 125, 64, 96, 3, 2, False, True),     # stride 2, odd size
     (8, 92, 124, 64, 96, 1, 2, False, True),     # the 1x1 stride-2 shortcut
     (8, 46, 62, 256, 128, 1, 1, False, False),   # conv3: bf16 map in, fp32 pyramid out
@@ -232,9 +235,16 @@ def test_conv_nhwc_bf16_maps(F_, H, W, Cin, Cout, k, s, norm, out_bf16):
         assert bool((err <= ref.abs() * 2.0 ** -8 + (3e-3 if norm else 1e-5)).all()), float((err / (ref.abs() + 1e-3)).max())
     else:
         assert _rel_err(out.double(), ref) < 2e-6
-    s1, s2 = ops.partial_sums(stats.cpu())                     # statistics come from the fp32 accumulators
-    assert _rel_err(s1, ref.sum(dim=(1, 2))) < 1e-5
-    assert _rel_err(s2, (ref * ref).sum(dim=(1, 2))) < 1e-5
+    s1, s2 = ops.partial_sums(stats.cpu())
+    t4c = out_bf16 and Cin == 96 and Cout == 96 and k == 3 and s == 1 and F_ * ((H * W + 255) // 256) >= 1024
+    if t4c:
+        # conv_bf16_t4c.hip: the statistics are those of the STORED bf16 map (what autocast's instance_norm sees)
+        assert _rel_err(s1, out.double().sum(dim=(1, 2))) < 1e-5
+        assert _rel_err(s2, (out.double() ** 2).sum(dim=(1, 2))) < 1e-5
+        assert _rel_err(s1, ref.sum(dim=(1, 2))) < 5e-3 and _rel_err(s2, (ref * ref).sum(dim=(1, 2))) < 5e-3
+    else:
+        assert _rel_err(s1, ref.sum(dim=(1, 2))) < 1e-5            # statistics come from the fp32 accumulators
+        assert _rel_err(s2, (ref * ref).sum(dim=(1, 2))) < 1e-5
 
 
 # ----------------------------------------------------------------------------- encoder
