@@ -283,6 +283,14 @@ int    pips_gemm_bf16(const void* A, int a_bf16, int lda, const void* W, const f
  * needs a current device.  The mixer's bf16 numerics depend on M = B*N*8 through this choice. */
 int    pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16);
 
+/* Which kernel pips_gemm_f32 (and the fp32 mixer of pips_forward) takes for a problem with bias and, for epi = residual, a residual of
+ * ldr = N: 0 = igemm_f32_kernel (gemm.hip); 1 = gemm_f32_t4u_kernel (128 x 128 tiles: epi GELU or residual, M and N multiples of
+ * 128, K % 64 == 0, at least three quarters of a tile per compute unit); 2 = gemm_f32_t4d_kernel (64 x 64 tiles, the K range split
+ * over the four waves and summed in a fixed order: epi residual, K % 256 == 0, between 0.75 and 2 tiles per compute unit -- the
+ * down-projection at M = 2048).  Same exact-fp32 MFMA arithmetic everywhere; 1 is bitwise igemm_f32_kernel's unsplit form, 2
+ * differs from it by the order of the four partial sums.  Host function; needs a current device. */
+int    pips_gemm_f32_route(int M, int N, int K, int epi);
+
 /* pips_conv_nhwc_f32 with bf16 MFMA operands: the fp32 map is rounded to bf16 while it is staged, wgt_bf16 is the
  * round-to-nearest-even bf16 copy of the [Cout][kh][kw][Cin] weights; fp32 accumulation and output, same stats. */
 int    pips_conv_nhwc_bf16(const float* in, int F, int H, int W, int Cin,

@@ -75,6 +75,7 @@ SIGNATURES = {
     "pips_gemm_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, fp, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, fp, c_int,
                        c_void_p]),
     "pips_gemm_bf16_route": (c_int, [c_int] * 6),
+    "pips_gemm_f32_route": (c_int, [c_int] * 4),
     "pips_conv_nhwc_bf16": (c_int, [fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp,
                                     C.POINTER(c_int), c_void_p]),
     "pips_conv_nhwc_bf16_maps": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int,

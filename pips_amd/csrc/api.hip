@@ -791,6 +791,16 @@ int pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16)
     return gemm_bf16_asm_route(g, a_bf16, out_bf16);
 }
 
+int pips_gemm_f32_route(int M, int N, int K, int epi) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    static const float dummy = 0.f;                     // only null-ness of bias / R is inspected
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.bias = &dummy; g.R = &dummy;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N; g.epi = epi;
+    return gemm_f32_t4_route(g, nullptr);
+}
+
 // bf16 == 1: bf16 MFMA operands for every Linear of the mixer (weights pre-converted; the LayerNorm-2 output and the
 // 2048-wide hidden activation stored as bf16, everything else fp32); the 544-wide input projection rides
 // 32-element K blocks (544 = 17 x 32).

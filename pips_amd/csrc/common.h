@@ -275,6 +275,10 @@ __device__ __forceinline__ void epilogue_full_tile(const f32x16 (&acc)[TM][TN], 
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t st);          // plain GEMM, picks a tile
+// the mixer's exact-fp32 Linears (bias + GELU / bias + residual) on four waves with a generated static schedule (gemm_f32_t4.hip):
+// 0 = not taken (igemm_f32_kernel), 1 = 128 x 128 tiles, 2 = 64 x 64 tiles with the K range split over the waves
+int gemm_f32_t4_route(const GemmArgs& a, int* tpb);
+int launch_gemm_f32_t4(const GemmArgs& a, int route, int tpb, hipStream_t st);
 int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
 // bf16-operand GEMM (gemm_bf16.hip): A fp32 or bf16, W bf16, C fp32 or bf16; pointers passed as float*
 int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);

@@ -452,6 +452,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
                        (unsigned long long)a.N * (unsigned long long)a.K < (1ull << 32),
                    "gemm: operand exceeds 2^32 elements");
     const bool k64 = a.K % 64 == 0;
+    if (forced_tile(a) < 0) {                              // the four-wave assembly kernels of gemm_f32_t4.hip (up- / down-projection forms)
+        int tpb = 1;
+        const int route = gemm_f32_t4_route(a, &tpb);
+        if (route) return launch_gemm_f32_t4(a, route, tpb, st);
+    }
     switch (forced_tile(a)) {
         case 0: return launch_tile<128, 128, 2, 2, 1, false>(a, 1, st);
         case 1: return launch_tile<128, 64, 2, 2, 1, false>(a, 1, st);

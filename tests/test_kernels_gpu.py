@@ -32,6 +32,11 @@ def _rel_err(a, b):
     (77, 130, 64, 0),          # ragged M and N
     (8, 32, 32, 1),            # tiny
     (16384, 2048, 512, 1),     # config-3 per-GPU rows
+    (4096, 2048, 512, 1),      # gemm_f32_t4u_kernel, two row tiles per block
+    (16384, 512, 2048, 2),     # the same with the residual epilogue
+    (2048, 2048, 128, 1),      # the same, four stages only (no pass through its K loop)
+    (3072, 512, 1024, 2),      # gemm_f32_t4d_kernel (64x64 tiles, K split over the waves), 8 stages
+    (2048, 384, 512, 2),       # the same at its shortest K, 192 tiles
 ])
 def test_gemm_f32(M, N, K, epi):
     from pips_amd import ops
@@ -48,6 +53,26 @@ def test_gemm_f32(M, N, K, epi):
     out = ops.gemm(A.to(DEV), W.to(DEV), b.to(DEV), epi, None if R is None else R.to(DEV)).cpu()
     # asymmetric operands: a transposed C write would fail this by O(1)
     assert _rel_err(out.double(), ref) < 2e-6
+
+
+def test_gemm_f32_assembly_routes_and_bitwise():
+    """The headline's channel-mix Linears reach the four-wave assembly kernels (gemm_f32_t4.hip); the 128 x 128 form keeps
+    igemm_f32_kernel's K order, so its result is BITWISE that kernel's (reached here through a null bias)."""
+    from pips_amd import ops, _lib
+    lib = _lib.load()
+    assert lib.pips_gemm_f32_route(2048, 2048, 512, 1) == 1
+    assert lib.pips_gemm_f32_route(2048, 512, 2048, 2) == 2
+    assert lib.pips_gemm_f32_route(16384, 512, 2048, 2) == 1
+    assert lib.pips_gemm_f32_route(2048, 512, 544, 0) == 0        # plain bias epilogue, K % 64 != 0
+    assert lib.pips_gemm_f32_route(1024, 2048, 512, 1) == 0       # half a tile per compute unit
+    assert lib.pips_gemm_f32_route(256, 1040, 512, 0) == 0
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K) in ((2048, 2048, 512), (4096, 2048, 512)):
+        A = torch.randn(M, K, generator=g).to(DEV)
+        W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+        t4 = ops.gemm(A, W, torch.zeros(N, device=DEV), 1)
+        ref = ops.gemm(A, W, None, 1)
+        assert torch.equal(t4, ref)
 
 
 def test_gemm_identity_asymmetric():
