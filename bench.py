@@ -103,17 +103,29 @@ def gemm_roofline(model, device, b, flags=0):
             "down_proj(M=%d,N=512,K=2048)" % M: {"ms": t_down, "tflops": flops / t_down / 1e9}}
 
 
+def gemm_kernel_name(M, N, K, epi):
+    """The kernel a channel-mix Linear of this shape runs on (pips_gemm_f32_route: gemm_f32_t4.hip's assembly kernels or igemm_f32_kernel)."""
+    from pips_amd import _lib
+    route = _lib.load().pips_gemm_f32_route(M, N, K, epi)
+    if route == 1:
+        return "gemm_f32_t4u_kernel<%d>" % (0 if epi == 1 else 1)
+    if route == 2:
+        return "gemm_f32_t4d_kernel"
+    return "igemm_f32_kernel<64, 64, 2, 2, %d, false>" % (1 if epi == 1 else 2)
+
+
 def roofline_object(kern, fake=False):
     dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
     # HBM-side bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
     # command, committed per round under profiles/ (a live bench run cannot collect PMC counters itself)
-    traffic, traffic_src = pmc_traffic("igemm_f32_kernel<64, 64, 2, 2, 1, false>" if dom[0].startswith("up") else
-                                       "igemm_f32_kernel<64, 64, 2, 2, 2, false>")
-    # both GEMM shapes run the same kernel template; report the slower (dominant) launch
+    M = int(dom[0].split("M=")[1].split(",")[0])
+    name = gemm_kernel_name(M, 2048, 512, 1) if dom[0].startswith("up") else gemm_kernel_name(M, 512, 2048, 2)
+    traffic, traffic_src = pmc_traffic(name)
+    # report the slower (dominant) of the two GEMM shapes
     return {"bound": "mfma", "achieved": dom[1]["tflops"], "peak": PEAK_F32_MFMA_TF,
             "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_F32_MFMA_TF, "traffic": traffic,
             "traffic_source": traffic_src,
-            "kernel": "igemm_f32_kernel " + dom[0], "launch_ms": dom[1]["ms"],
+            "kernel": name + " " + dom[0], "launch_ms": dom[1]["ms"],
             "timing": "HIP event pair around each in-situ launch, empty-pair overhead subtracted",
             "all": kern}
 

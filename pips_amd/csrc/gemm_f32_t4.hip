@@ -13,16 +13,21 @@
 //
 // Block shapes (the generator's header has the details):
 //     U   128 x 128 tile, waves 2 x 2; a block walks `tpb` consecutive row tiles of one column tile
-//     D   64 x 64 tile, waves = four K quarters summed through LDS in a fixed order -- when there are too few 128 x 128 tiles
-//         for the chip (the down-projection at M = 2048: 64 of them)
+//     D   64 x 64 tile, every wave the whole tile on one of the four groups of 8 K values of each 32-wide stage, the four partial
+//         tiles summed through LDS in a fixed order -- when there are too few 128 x 128 tiles for the chip (the down-projection
+//         at M = 2048: 64 of them)
 #include "common.h"
-#include "gemm_f32_t4_asm.inc"
+#ifndef PIPS_F32T4_INC
+#define PIPS_F32T4_INC "gemm_f32_t4_asm.inc"      // tuning builds point this at another schedule of the generator
+#endif
+#include PIPS_F32T4_INC
 
 namespace pips {
 
 constexpr int F4_ROW = 144;                                  // LDS row: 32 K values + 16 bytes
 constexpr int F4_LDS_U = 2 * 256 * F4_ROW;                   // 73 728 bytes: two stages of [A rows 0..127 | W rows 0..127]
-constexpr int F4_LDS_D = 2 * 512 * F4_ROW;                   // 147 456 bytes: two stages of [A 4 x 64 rows | W 4 x 64 rows]
+constexpr int F4_STAGE_D = 128 * F4_ROW;                     // a stage of shape D: [A rows 0..63 | W rows 0..63]
+constexpr int F4_LDS_D = 4 * F4_STAGE_D;                     // 73 728 bytes: four stages; the four partial tiles at the end use 64 KiB of it
 
 __device__ __forceinline__ unsigned f4_sgpr(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 #define F4_LO(ptr) f4_sgpr((unsigned)(unsigned long long)reinterpret_cast<uintptr_t>(ptr))
@@ -36,17 +41,43 @@ __device__ __forceinline__ unsigned f4_sgpr(unsigned v) { return (unsigned)__bui
       [cstep] "s"(f4_sgpr(cstep)), [kt] "s"(f4_sgpr(kt)), [tstepA] "s"(f4_sgpr(tstepA)), [tstepC] "s"(f4_sgpr(tstepC)),         \
       [tstepR] "s"(f4_sgpr(tstepR)), [ntile] "s"(f4_sgpr(ntile))
 
+// Block -> (row unit, column tile).  Blocks go to the XCDs round robin (block & 7), every XCD has its own L2, and the operands
+// come out of the Infinity Cache: in the linear order (column tile fastest) the eight column tiles of the M = 2048 down-projection
+// land on eight XCDs and EVERY XCD pulls all of A through its L2 -- 132 MB per launch for 20 MB of operands.  Instead the XCDs
+// split the tile grid gm x gn (host: the split with the smallest per-XCD footprint) and each works through its own sub-grid.
+struct F4Grid { int units_m, tiles_n, gm, gn; };
+__device__ __forceinline__ void f4_tile(const F4Grid& g, int* um, int* tn) {
+    const int b = blockIdx.x;
+    if (g.gm == 0) { *um = b / g.tiles_n; *tn = b - *um * g.tiles_n; return; }
+    const int xcd = b & 7, local = b >> 3, xm = xcd / g.gn, xn = xcd - xm * g.gn;
+    const int pm = g.units_m / g.gm, pn = g.tiles_n / g.gn, lm = local / pn, ln = local - lm * pn;
+    *um = xm * pm + lm; *tn = xn * pn + ln;
+    (void)pm;
+}
+static F4Grid f4_grid(int units_m, int tiles_n, long bytes_unit_m, long bytes_tile_n) {
+    F4Grid g = {units_m, tiles_n, 0, 1};
+    if (!PIPS_TUNE("PIPS_F32_T4_XCD", 1) || ((long)units_m * tiles_n) % 8 != 0) return g;
+    long best = -1;
+    for (int gm = 8; gm >= 1; gm >>= 1) {
+        const int gn = 8 / gm;
+        if (units_m % gm != 0 || tiles_n % gn != 0) continue;
+        const long foot = (units_m / gm) * bytes_unit_m + (tiles_n / gn) * bytes_tile_n;
+        if (best < 0 || foot < best) { best = foot; g.gm = gm; g.gn = gn; }
+    }
+    return g;
+}
+
 // EPI: 0 = + bias + GELU, 1 = + bias + residual
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_t4u_kernel(GemmArgs p, int tiles_m, int tpb) {
+__global__ __launch_bounds__(256) void gemm_f32_t4u_kernel(GemmArgs p, F4Grid grid, int tpb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
-    const int runs = tiles_m / tpb;                            // blocks per column tile
-    const int tn = blockIdx.x / runs, tm0 = (blockIdx.x - tn * runs) * tpb;
-    const int m0 = tm0 * 128, n0 = tn * 128;
+    int um, tn;                                                // row unit = `tpb` consecutive row tiles
+    f4_tile(grid, &um, &tn);
+    const int m0 = um * tpb * 128, n0 = tn * 128;
 
     // staging: thread = (row lr of a 32-row pass, 16-byte chunk lc of the row's 128 bytes)
     const int lr = tid >> 3, lc = tid & 7;
@@ -73,25 +104,27 @@ __global__ __launch_bounds__(256) void gemm_f32_t4u_kernel(GemmArgs p, int tiles
     else          asm volatile(PIPS_F32T4_U_RES_TEXT : F4_OPERANDS : PIPS_F32T4_CLOBBER);
 }
 
-__global__ __launch_bounds__(256) void gemm_f32_t4d_kernel(GemmArgs p, int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_f32_t4d_kernel(GemmArgs p, F4Grid grid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = the K quarter in the loop, = the MFMA block (i + 2 j) at the end
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = the K group of a stage in the loop, = the MFMA block (i + 2 j) at the end
     const int l31 = lane & 31, half = lane >> 5;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    int tm, tn;
+    f4_tile(grid, &tm, &tn);
     const int m0 = tm * 64, n0 = tn * 64;
 
-    // staging: piece s of a thread = rows 32 (s & 1) + lr of the tile, K quarter s >> 1 (128 bytes each) -> LDS row 32 s + lr
+    // staging: piece s of a thread = row 32 s + lr of the tile, 16-byte chunk lc of the stage's 128 bytes
     const int lr = tid >> 3, lc = tid & 7;
     const float* Ab = p.A + (size_t)m0 * p.lda;
     const float* Wb = p.W + (size_t)n0 * p.K;
     const unsigned voA = (unsigned)(lr * p.lda * 4 + lc * 16), voW = (unsigned)(lr * p.K * 4 + lc * 16);
     const unsigned passA = (unsigned)(32 * p.lda * 4), passW = (unsigned)(32 * p.K * 4);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned wA0 = lds0 + lr * F4_ROW + lc * 16, wW0 = wA0 + 256 * F4_ROW;
-    const unsigned wA1 = wA0 + F4_LDS_D / 2, wW1 = wW0 + F4_LDS_D / 2;
-    const unsigned rA0 = lds0 + (64 * wave + l31) * F4_ROW + half * 16, rW0 = lds0 + (256 + 64 * wave + l31) * F4_ROW + half * 16;
-    const unsigned rA1 = rA0 + F4_LDS_D / 2, rW1 = rW0 + F4_LDS_D / 2;
+    const unsigned wA0 = lds0 + lr * F4_ROW + lc * 16, wW0 = wA0 + 64 * F4_ROW;
+    const unsigned wA1 = wA0 + F4_STAGE_D, wW1 = wW0 + F4_STAGE_D;
+    // fragments: this wave's 8 K values of the stage = bytes 32 wave .. of a row
+    const unsigned rA0 = lds0 + l31 * F4_ROW + wave * 32 + half * 16, rW0 = lds0 + (64 + l31) * F4_ROW + wave * 32 + half * 16;
+    const unsigned rA1 = rA0 + F4_STAGE_D, rW1 = rW0 + F4_STAGE_D;
     // the sum over the K quarters: red[quarter][4 block + quad][lane] (16 bytes each, 64 KiB over the stage buffers)
     const unsigned redW = lds0 + wave * 16384 + lane * 16, redR = lds0 + wave * 4096 + lane * 16;
     const int bi = wave & 1, bj = wave >> 1;
@@ -100,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_f32_t4d_kernel(GemmArgs p, int tiles
     const float* Bb = p.bias + n0 + 32 * bj;
     const unsigned voC = (unsigned)((l31 * p.ldc + 4 * half) * 4), voR = (unsigned)((l31 * p.ldr + 4 * half) * 4), voB = (unsigned)(16 * half);
     const unsigned cstep = 0, rstep = 0, tstepC = 0, tstepR = 0;
-    const unsigned kt = (unsigned)(p.K / 128), tstepA = (unsigned)(64 * p.lda * 4) - 512u * kt, ntile = 1;
+    const unsigned kt = (unsigned)(p.K / 32), tstepA = (unsigned)(64 * p.lda * 4) - 128u * kt, ntile = 1;
     asm volatile(PIPS_F32T4_D_RES_TEXT : F4_OPERANDS : PIPS_F32T4_CLOBBER);
 }
 
@@ -123,7 +156,7 @@ int gemm_f32_t4_route(const GemmArgs& a, int* tpb) {
         return 1;
     }
     const long t64 = (long)(a.M / 64) * (a.N / 64);
-    if (epi == EPI_RESIDUAL && a.M % 64 == 0 && a.N % 64 == 0 && a.K % 256 == 0 && a.K >= 512 &&
+    if (epi == EPI_RESIDUAL && a.M % 64 == 0 && a.N % 64 == 0 && a.K % 128 == 0 && a.K >= 256 &&
         t64 * 100 >= (long)cus * PIPS_TUNE("PIPS_F32_T4D_MINPCT", 75) && t64 <= 2l * cus)
         return 2;
     return 0;
@@ -132,16 +165,17 @@ int gemm_f32_t4_route(const GemmArgs& a, int* tpb) {
 int launch_gemm_f32_t4(const GemmArgs& a, int route, int tpb, hipStream_t st) {
     const int epi = a.epi & 0xff;
     if (route == 1) {
-        const int tiles_m = a.M / 128, blocks = tiles_m / tpb * (a.N / 128);
+        const int units_m = a.M / 128 / tpb, blocks = units_m * (a.N / 128);
+        const F4Grid grid = f4_grid(units_m, a.N / 128, (long)tpb * 128 * a.K * 4, (long)128 * a.K * 4);
         static std::atomic<unsigned long long> raised0{0}, raised1{0};
         if (epi == EPI_GELU) {
             const int rc = ensure_dynamic_lds(raised0, (const void*)gemm_f32_t4u_kernel<0>, F4_LDS_U);
             if (rc != PIPS_OK) return rc;
-            hipLaunchKernelGGL(gemm_f32_t4u_kernel<0>, dim3(blocks), dim3(256), F4_LDS_U, st, a, tiles_m, tpb);
+            hipLaunchKernelGGL(gemm_f32_t4u_kernel<0>, dim3(blocks), dim3(256), F4_LDS_U, st, a, grid, tpb);
         } else {
             const int rc = ensure_dynamic_lds(raised1, (const void*)gemm_f32_t4u_kernel<1>, F4_LDS_U);
             if (rc != PIPS_OK) return rc;
-            hipLaunchKernelGGL(gemm_f32_t4u_kernel<1>, dim3(blocks), dim3(256), F4_LDS_U, st, a, tiles_m, tpb);
+            hipLaunchKernelGGL(gemm_f32_t4u_kernel<1>, dim3(blocks), dim3(256), F4_LDS_U, st, a, grid, tpb);
         }
         PIPS_CHECK_LAUNCH("gemm_f32_t4u_kernel");
         return PIPS_OK;
@@ -149,8 +183,8 @@ int launch_gemm_f32_t4(const GemmArgs& a, int route, int tpb, hipStream_t st) {
     static std::atomic<unsigned long long> raised2{0};
     const int rc = ensure_dynamic_lds(raised2, (const void*)gemm_f32_t4d_kernel, F4_LDS_D);
     if (rc != PIPS_OK) return rc;
-    const int tiles_n = a.N / 64;
-    hipLaunchKernelGGL(gemm_f32_t4d_kernel, dim3((a.M / 64) * tiles_n), dim3(256), F4_LDS_D, st, a, tiles_n);
+    const F4Grid grid = f4_grid(a.M / 64, a.N / 64, (long)64 * a.K * 4, (long)64 * a.K * 4);
+    hipLaunchKernelGGL(gemm_f32_t4d_kernel, dim3((a.M / 64) * (a.N / 64)), dim3(256), F4_LDS_D, st, a, grid);
     PIPS_CHECK_LAUNCH("gemm_f32_t4d_kernel");
     return PIPS_OK;
 }

@@ -8,9 +8,11 @@ LDS buffers, ONE barrier per stage, fragments of the next 8 K values read while 
 Two block shapes:
     U   128 x 128 tile, waves 2 x 2, a stage = 32 K values (rows 0..127 of the LDS image: A, 128..255: W); the block walks
         `ntile` consecutive row tiles of one column tile with the pipeline running on across the tile boundary
-    D   64 x 64 tile, every wave the whole tile on a quarter of each 128-wide K block (LDS rows 64 ks..: A, 256 + 64 ks..: W);
-        the four partial tiles are summed through LDS in a fixed order (((0 + 1) + 2) + 3) and every wave finishes ONE of the
-        four 32 x 32 blocks -- for the problems with too few 128 x 128 tiles to fill the chip (M = 2048, N = 512)
+    D   64 x 64 tile, every wave the whole tile on ONE of the four groups of 8 K values of each 32-wide stage (a stage = 16 MFMAs,
+        four stages in flight in registers); the four partial tiles are summed through LDS in a fixed order (((0 + 1) + 2) + 3)
+        and every wave finishes ONE of the four 32 x 32 blocks -- for the problems with too few 128 x 128 tiles to fill the
+        chip (M = 2048, N = 512).  (First built with every wave on a quarter of a 128-wide stage: 64 KiB per stage and CU had
+        to arrive before the first MFMA, 3 us of prologue.)
 and three epilogues: + bias + exact GELU (U), + bias + residual (U, D).
 
 LDS image of a stage: rows of 32 K values (128 B) at a stride of 144 B -- what makes the ds_read_b128 fragment reads
@@ -24,9 +26,9 @@ register quad q, the four consecutive columns 8 q + 4 (l >> 5) ..: 16-byte bias 
 Registers (all clobbered):
     a[0:63]      accumulators: MFMA block (i, j) = rows 32 i.., columns 32 j.. of the wave block -> a[16 (i + 2 j) : +15]
     v[0:15]      fragments, set 0: A0 A1 W0 W1 (4 registers each); v[16:31] set 1
-    v[32:..]     the stage in flight (U: 8 pieces of 16 B per thread, D: 16), then per-piece global byte offsets, bias quads,
-                 residual quads (GELU form: the polynomial's second coefficient), the epilogue's temporaries (class Shape);
-                 v[216:255] stay with the compiler
+    v[32:95]     the stages in flight (U: 2 x 8 pieces of 16 B per thread, D: 4 x 4), then per-piece global byte offsets, bias
+                 quads, residual quads (GELU form: the polynomial's second coefficient), the epilogue's temporaries (class
+                 Shape); v[216:255] stay with the compiler
     s[40:59] buffer descriptors A, W, C, bias, R;  s[60:61] / s[82:83] row-block offsets in C / R;  s[62:81] GELU constants;
     s[84:95] loop state
 """
@@ -104,16 +106,19 @@ class Emit:
 
 
 class Shape:
-    def __init__(self, name):
+    def __init__(self, name, epi):
         self.name = name
-        self.npa = 4 if name == "U" else 8          # staged pieces per thread and stage: A, W
+        self.npa = 4 if name == "U" else 2          # staged pieces per thread and stage: A, W
         self.np = 2 * self.npa
+        self.nsub = 4 if name == "U" else 1         # groups of 8 K values a wave multiplies per stage
+        self.ring = 2 if name == "U" else 4         # stages in flight in registers
+        self.unroll = 2 if name == "U" else 4       # lcm(2 LDS buffers, ring)
         self.blocks = [(i, j) for j in range(2) for i in range(2)]
-        # registers behind the staged pieces: per-piece offsets, bias quads, residual quads, the epilogue's temporaries
+        # registers behind the staged pieces (v[32:95]): per-piece offsets, bias quads, residual quads, the epilogue's temporaries
         if name == "U":
-            self.vo, self.bias, self.res, self.ep = 64, 72, 104, 168
+            self.vo, self.bias, self.res, self.ep = 96, 104, 136, (138 if epi == "gelu" else 200)
         else:
-            self.vo, self.bias, self.res, self.ep = 96, 112, 128, 144
+            self.vo, self.bias, self.res, self.ep = 96, 100, 116, 132
         self.vc = self.res                          # GELU form: the polynomial's second coefficient as a vector pair
 
 
@@ -121,10 +126,21 @@ def acc(i, j):
     return 16 * (i + 2 * j)
 
 
+D4 = os.environ.get("PIPS_GEN_D4", "1") == "1"      # shape D on four LDS buffers (0: two)
+DSTAGE = 128 * LDROW
+
+
 def frag_read(e, par, fset, kk, which, idx):
     """fragment `idx` (A: row block i, W: column block j) of the 8 K values kk of the stage in LDS buffer `par`, into set `fset`"""
     reg = (FA if which == "a" else FW)[fset] + 4 * idx
-    e.lds("ds_read_b128 v[%d:%d], %%[r%s%d] offset:%d" % (reg, reg + 3, "A" if which == "a" else "W", par, idx * 32 * LDROW + kk * 32),
+    off = idx * 32 * LDROW + kk * 32
+    e.lds("ds_read_b128 v[%d:%d], %%[r%s%d] offset:%d" % (reg, reg + 3, "A" if which == "a" else "W", par, off), ("f" + which, fset, idx))
+
+
+def frag_read_d(e, buf, fset, which, idx):
+    """shape D on four buffers: one base register, the buffer in the offset"""
+    reg = (FA if which == "a" else FW)[fset] + 4 * idx
+    e.lds("ds_read_b128 v[%d:%d], %%[r%s0] offset:%d" % (reg, reg + 3, "A" if which == "a" else "W", buf * DSTAGE + idx * 32 * LDROW),
           ("f" + which, fset, idx))
 
 
@@ -138,22 +154,29 @@ def mfma(e, fset, c, i, j, zero):
           (a, a + 15, FW[fset] + 4 * j + c, FA[fset] + 4 * i + c, "0" if zero else "a[%d:%d]" % (a, a + 15)))
 
 
-def store_piece(e, sh, par, s):
-    """staged piece s -> LDS buffer `par`"""
-    e.need_vm({("st", s)})
-    reg = ST + 4 * s
+def store_piece(e, sh, par, ring, s):
+    """staged piece s of register set `ring` -> LDS buffer `par`"""
+    e.need_vm({("st", ring, s)})
+    reg = ST + 4 * (ring * sh.np + s)
     if s < sh.npa:
         e.lds("ds_write_b128 %%[wA%d], v[%d:%d] offset:%d" % (par, reg, reg + 3, s * 32 * LDROW), ("wr", s))
     else:
         e.lds("ds_write_b128 %%[wW%d], v[%d:%d] offset:%d" % (par, reg, reg + 3, (s - sh.npa) * 32 * LDROW), ("wr", s))
 
 
-def load_piece(e, sh, s):
-    reg = ST + 4 * s
+def store_piece_d(e, sh, buf, ring, s):
+    e.need_vm({("st", ring, s)})
+    reg = ST + 4 * (ring * sh.np + s)
+    name, k = ("A", s) if s < sh.npa else ("W", s - sh.npa)
+    e.lds("ds_write_b128 %%[w%s0], v[%d:%d] offset:%d" % (name, reg, reg + 3, buf * DSTAGE + k * 32 * LDROW), ("wr", s))
+
+
+def load_piece(e, sh, ring, s):
+    reg = ST + 4 * (ring * sh.np + s)
     if s < sh.npa:
-        e.vmem("buffer_load_dwordx4 v[%d:%d], v%d, s[%d:%d], s%d offen" % (reg, reg + 3, sh.vo + s, RS_A, RS_A + 3, S_SOA), ("st", s))
+        e.vmem("buffer_load_dwordx4 v[%d:%d], v%d, s[%d:%d], s%d offen" % (reg, reg + 3, sh.vo + s, RS_A, RS_A + 3, S_SOA), ("st", ring, s))
     else:
-        e.vmem("buffer_load_dwordx4 v[%d:%d], v%d, s[%d:%d], s%d offen" % (reg, reg + 3, sh.vo + s, RS_W, RS_W + 3, S_SOW), ("st", s))
+        e.vmem("buffer_load_dwordx4 v[%d:%d], v%d, s[%d:%d], s%d offen" % (reg, reg + 3, sh.vo + s, RS_W, RS_W + 3, S_SOW), ("st", ring, s))
 
 
 def descriptor(e, base, lo, hi):
@@ -177,50 +200,97 @@ def advance_request(e):
     e.raw("s_min_u32 s%d, s%d, s%d" % (S_SOA, S_SOA, S_LASTA))
 
 
-def stage(e, sh, par, first, extra=()):
-    """One stage: 64 MFMAs on LDS buffer `par`; the stage after it goes registers -> buffer 1 - par, the one after that is
-    requested; `extra`: operations (callables) of the tile's last stage (residual prefetch) for the free slots."""
+def stage(e, sh, t, first, extra=()):
+    """Stage t of an unrolled group: 16 nsub MFMAs on LDS buffer t & 1; stage t + 1 goes from register set (t + 1) % ring to the
+    other buffer and stage t + 1 + ring is requested into that set; `extra`: operations (callables) of the tile's last stage
+    (residual prefetch) for the free slots."""
     advance_request(e)
+    par, ring, nsub = t & 1, (t + 1) % sh.ring, sh.nsub
+    g0 = t * nsub                                             # fragment set of the 8 K values kk of this stage: (g0 + kk) & 1
     slots = {}
 
     def put(n, op):
         slots.setdefault(n, []).append(op)
 
-    for kk in range(3):                                       # fragments of the 8 K values kk + 1, set (kk + 1) & 1
-        for r, (which, idx) in enumerate(FRAG_ORDER):
-            put(16 * kk + 1 + r, ("fr", par, (kk + 1) & 1, kk + 1, which, idx))
-    free = [n for n in range(5, 47) if n % 16 >= 5 or n % 16 == 0]
-    free = [n for n in free if n not in slots]
     ops = []
     for s in range(sh.np):
         ops += [("st", s), ("ld", s)]
-    assert len(ops) <= len(free)
-    step = len(free) / float(len(ops))
-    for k, op in enumerate(ops):
-        put(free[int(k * step)], op)
-    put(47, ("bar",))
-    for r, (which, idx) in enumerate(FRAG_ORDER):             # the next stage's first fragments, set 0, from the other buffer
-        put(49 + r, ("fr", 1 - par, 0, 0, which, idx))
-    rest = [n for n in range(53, 64)] + [n for n in range(5, 47) if n not in slots]
+    if nsub == 4:
+        for kk in range(3):
+            for r, (which, idx) in enumerate(FRAG_ORDER):
+                put(16 * kk + 1 + r, ("fr", par, (g0 + kk + 1) & 1, kk + 1, which, idx))
+        free = [n for n in range(5, 47) if n not in slots]
+        step = len(free) / float(len(ops))
+        for k, op in enumerate(ops):
+            put(free[int(k * step)], op)
+        bar, nxt = 47, 49
+        rest = [n for n in range(53, 64)] + [n for n in range(5, 47) if n not in slots]
+    else:
+        for k, op in enumerate(ops):
+            put(k, op)
+        bar, nxt = 8, 9
+        rest = [13, 14, 15, 12]
+    put(bar, ("bar",))
+    for r, (which, idx) in enumerate(FRAG_ORDER):             # the next stage's first fragments, from the other buffer
+        put(nxt + r, ("fr", 1 - par, (g0 + nsub) & 1, 0, which, idx))
     for k, op in enumerate(extra):
         put(rest[k], ("extra", op))
     n = 0
-    for kk in range(4):
+    for kk in range(nsub):
         for c in range(4):
             for (i, j) in sh.blocks:
-                mfma(e, kk & 1, c, i, j, first and kk == 0 and c == 0)
+                mfma(e, (g0 + kk) & 1, c, i, j, first and kk == 0 and c == 0)
                 for op in slots.get(n, []):
                     if op[0] == "fr":
                         frag_read(e, *op[1:])
                     elif op[0] == "st":
-                        store_piece(e, sh, 1 - par, op[1])
+                        store_piece(e, sh, 1 - par, ring, op[1])
                     elif op[0] == "ld":
-                        load_piece(e, sh, op[1])
+                        load_piece(e, sh, ring, op[1])
                     elif op[0] == "bar":
                         e.barrier()
                     else:
                         op[1](e)
                 n += 1
+
+
+def stage_d4(e, sh, t, first, extra=()):
+    """Shape D on FOUR LDS buffers, stage t of a group of four: 16 MFMAs on buffer t; the fragments of stage t + 1 are read at
+    once (its buffer was completed before the barrier of stage t - 1); stage t + 2 goes from register set (t + 2) % 4 to its
+    buffer and stage t + 6 is requested into that set; the barrier sits at the stage's end, well behind its writes -- with two
+    buffers the writes, the barrier and the next stage's reads had to follow each other inside 16 MFMAs and every wait was live."""
+    advance_request(e)
+    ring = (t + 2) % 4
+    slots = {}
+
+    def put(n, op):
+        slots.setdefault(n, []).append(op)
+
+    for r, (which, idx) in enumerate(FRAG_ORDER):
+        put(1 + r, ("fr", which, idx))
+    for s in range(sh.np):
+        put(5 + 2 * s, ("st", s))
+        put(6 + 2 * s, ("ld", s))
+    put(15, ("bar",))
+    rest = [13, 14, 12, 11]
+    for k, op in enumerate(extra):
+        put(rest[k], ("extra", op))
+    n = 0
+    for c in range(4):
+        for (i, j) in sh.blocks:
+            mfma(e, t & 1, c, i, j, first and c == 0)
+            for op in slots.get(n, []):
+                if op[0] == "fr":
+                    frag_read_d(e, (t + 1) % 4, (t + 1) & 1, op[1], op[2])
+                elif op[0] == "st":
+                    store_piece_d(e, sh, ring, ring, op[1])
+                elif op[0] == "ld":
+                    load_piece(e, sh, ring, op[1])
+                elif op[0] == "bar":
+                    e.barrier()
+                else:
+                    op[1](e)
+            n += 1
 
 
 def gelu4(e, X, T, Q, VC):
@@ -282,7 +352,7 @@ def epilogue_u(e, sh, epi):
     e.raw("s_nop 15")
     e.raw("s_nop 15")
     EP, BIAS = sh.ep, sh.bias
-    sets = [(EP, EP + 8, EP + 16), (EP + 24, EP + 32, EP + 40)]
+    sets = [(EP, EP + 8, EP + 16), (EP + 24, EP + 32, EP + 40)] if epi == "gelu" else [(EP, 0, 0), (EP + 8, 0, 0)]
     k = 0
     for i in range(2):
         for j in range(2):
@@ -356,7 +426,7 @@ def epilogue_d(e, sh):
 
 
 def body(shape, epi):
-    sh = Shape(shape)
+    sh = Shape(shape, epi)
     e = Emit()
     descriptor(e, RS_A, "%[alo]", "%[ahi]")
     descriptor(e, RS_W, "%[wlo]", "%[whi]")
@@ -364,19 +434,13 @@ def body(shape, epi):
     descriptor(e, RS_B, "%[blo]", "%[bhi]")
     if epi == "res":
         descriptor(e, RS_R, "%[rlo]", "%[rhi]")
-    # per-piece global offsets.  U: piece s = rows 32 s.. of the tile (A, then W).  D: piece s = rows 32 (s & 1).. of the tile,
-    # K slice s >> 1 (128 bytes each)
+    # per-piece global offsets: piece s = rows 32 s.. of the tile (A, then W)
     for base, v0 in (("%[voA]", sh.vo), ("%[voW]", sh.vo + sh.npa)):
         pas = "%[passA]" if v0 == sh.vo else "%[passW]"
         e.raw("v_mov_b32 v%d, %s" % (v0, base))
-        if shape == "U":
-            for s in range(1, sh.npa):
-                e.raw("v_add_u32 v%d, %s, v%d" % (v0 + s, pas, v0 + s - 1))
-        else:
-            e.raw("v_add_u32 v%d, %s, v%d" % (v0 + 1, pas, v0))
-            for s in range(2, sh.npa):
-                e.raw("v_add_u32 v%d, 128, v%d" % (v0 + s, v0 + s - 2))
-    e.raw("s_mov_b32 s%d, %d" % (S_KSTEP, 128 if shape == "U" else 512))
+        for s in range(1, sh.npa):
+            e.raw("v_add_u32 v%d, %s, v%d" % (v0 + s, pas, v0 + s - 1))
+    e.raw("s_mov_b32 s%d, 128" % S_KSTEP)
     if shape == "U":
         e.raw("s_mov_b32 s%d, 0" % S_CR)
         e.raw("s_mov_b32 s%d, %%[cstep]" % (S_CR + 1))
@@ -396,44 +460,61 @@ def body(shape, epi):
     e.raw("s_sub_u32 s%d, %%[ntile], 1" % S_TL)
     e.raw("s_mul_i32 s%d, s%d, s%d" % (S_T, S_T, S_TL))
     e.raw("s_add_u32 s%d, s%d, s%d" % (S_LASTA, S_LASTA, S_T))
-    # ---- stage 0 -> registers -> LDS buffer 0, stage 1 -> registers, bias, fragments of the first 8 K values
+    # ---- stages 0 .. ring - 1 -> register sets, bias, stage 0 -> LDS buffer 0, stage `ring` requested, fragments of the first 8 K values
     e.raw("s_mov_b32 s%d, 0" % S_SOA)
     e.raw("s_mov_b32 s%d, 0" % S_SOW)
     e.raw("s_mov_b32 s%d, 0" % S_RQK)
-    for s in range(sh.np):
-        load_piece(e, sh, s)
     nb = 8 if shape == "U" else 4
+    d4 = shape == "D" and D4
+    for r in range(sh.ring):
+        if r:
+            advance_request(e)
+        for s in range(sh.np):
+            load_piece(e, sh, r, s)
     for t in range(nb):                                      # bias quad t: columns 8 t + 4 (l >> 5) .. of the wave's (U) / the block's (D)
         e.vmem("buffer_load_dwordx4 v[%d:%d], %%[voB], s[%d:%d], 0 offen offset:%d" % (sh.bias + 4 * t, sh.bias + 4 * t + 3, RS_B, RS_B + 3, 32 * t),
                ("bias", t))
-    for s in range(sh.np):
-        store_piece(e, sh, 0, s)
-    advance_request(e)
-    for s in range(sh.np):
-        load_piece(e, sh, s)
-    e.barrier()
-    for which, idx in FRAG_ORDER:
-        frag_read(e, 0, 0, 0, which, idx)
+    if d4:                                                   # stages 0, 1 -> buffers 0, 1; stages 4, 5 requested
+        for r in range(2):
+            for s in range(sh.np):
+                store_piece_d(e, sh, r, r, s)
+            advance_request(e)
+            for s in range(sh.np):
+                load_piece(e, sh, r, s)
+        e.barrier()
+        for which, idx in FRAG_ORDER:
+            frag_read_d(e, 0, 0, which, idx)
+    else:
+        for s in range(sh.np):
+            store_piece(e, sh, 0, 0, s)
+        advance_request(e)
+        for s in range(sh.np):
+            load_piece(e, sh, 0, s)
+        e.barrier()
+        for which, idx in FRAG_ORDER:
+            frag_read(e, 0, 0, 0, which, idx)
     e.raw("s_mov_b32 s%d, %%[ntile]" % S_TL)
     extra = residual_loads(sh) if epi == "res" else ()
+    U = sh.unroll
+    stage_fn = stage_d4 if d4 else stage
     e.raw("2:")
-    stage(e, sh, 0, True)
-    stage(e, sh, 1, False)
-    e.raw("s_lshr_b32 s%d, %%[kt], 1" % S_KL)
+    for t in range(U):
+        stage_fn(e, sh, t, t == 0)
+    e.raw("s_lshr_b32 s%d, %%[kt], %d" % (S_KL, 1 if U == 2 else 2))
     e.raw("s_sub_u32 s%d, s%d, 2" % (S_KL, S_KL))
     e.raw("s_cmp_eq_u32 s%d, 0" % S_KL)
     e.raw("s_cbranch_scc1 3f")
     head = (list(e.lgkm), list(e.vm))
     e.raw("1:")
-    stage(e, sh, 0, False)
-    stage(e, sh, 1, False)
+    for t in range(U):
+        stage_fn(e, sh, t, False)
     assert (e.lgkm, e.vm) == head, "loop body does not reproduce its head state"
     e.raw("s_sub_u32 s%d, s%d, 1" % (S_KL, S_KL))
     e.raw("s_cmp_lg_u32 s%d, 0" % S_KL)
     e.raw("s_cbranch_scc1 1b")
     e.raw("3:")
-    stage(e, sh, 0, False)
-    stage(e, sh, 1, False, extra)
+    for t in range(U):
+        stage_fn(e, sh, t, False, extra if t == U - 1 else ())
     if shape == "U":
         epilogue_u(e, sh, epi)
         e.raw("s_sub_u32 s%d, s%d, 1" % (S_TL, S_TL))
