@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpips_hip.so")
-SOURCES = ["gemm.hip", "gemm_f32_t4.hip", "encoder.hip", "encoder_bf16.hip", "track.hip", "gather_tiled.hip", "scoremap.hip", "gemm_bf16.hip", "gemm_bf16_t4.hip", "conv_bf16_c64.hip", "conv_bf16_t4c.hip", "gemm_x3.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm_f32_t4.hip", "conv_f32_t4.hip", "encoder.hip", "encoder_bf16.hip", "track.hip", "gather_tiled.hip", "scoremap.hip", "gemm_bf16.hip", "gemm_bf16_t4.hip", "conv_bf16_c64.hip", "conv_bf16_t4c.hip", "gemm_x3.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Werror=inline-asm"]
 # per-file additions.  conv_bf16_c64.hip: its VALU work runs beside MFMAs of a co-resident wave, where packed fp32 ops are an
 # anti-lever -- keep hipcc's SLP vectoriser from re-packing the scalar ops (MI355X_MICROARCH.md)
@@ -33,7 +33,7 @@ def _stale(target: str, deps) -> bool:
 
 def headers():
     """Files every translation unit depends on (beyond its own source)."""
-    return [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tail.h"), os.path.join(CSRC, "gather_item_asm.inc"), os.path.join(CSRC, "gemm_bf16_t4_asm.inc"), os.path.join(CSRC, "gemm_bf16_t4up_asm.inc"), os.path.join(CSRC, "conv_bf16_t4c_asm.inc"), os.path.join(CSRC, "gemm_f32_t4_asm.inc"),
+    return [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tail.h"), os.path.join(CSRC, "gather_item_asm.inc"), os.path.join(CSRC, "gemm_bf16_t4_asm.inc"), os.path.join(CSRC, "gemm_bf16_t4up_asm.inc"), os.path.join(CSRC, "conv_bf16_t4c_asm.inc"), os.path.join(CSRC, "gemm_f32_t4_asm.inc"), os.path.join(CSRC, "conv_f32_t4_asm.inc"),
             os.path.join(HERE, "..", "include", "pips_hip.h")]
 
 

@@ -280,6 +280,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t st);          // plain GEMM, pick
 int gemm_f32_t4_route(const GemmArgs& a, int* tpb);
 int launch_gemm_f32_t4(const GemmArgs& a, int route, int tpb, hipStream_t st);
 int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st);
+// the big 3x3 / stride 1 layers of the fp32 encoder on four waves with a generated static schedule (conv_f32_t4.hip): the configuration
+// that takes a layer (-1: none); *parts_out = InstanceNorm partials per frame
+int conv_f32_t4_config(const GemmArgs& a, int frames);
+int launch_conv_f32_t4(const GemmArgs& a, int cfg, int frames, int* parts_out, hipStream_t st);
 // bf16-operand GEMM (gemm_bf16.hip): A fp32 or bf16, W bf16, C fp32 or bf16; pointers passed as float*
 int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st);
 // in_bf16 / out_bf16: the NHWC maps are bf16 instead of fp32 (the bf16 encoder keeps every activation in bf16)

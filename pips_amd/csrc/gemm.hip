@@ -499,6 +499,10 @@ int launch_conv(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st) {
     PIPS_CHECK_ARG(a.Cin % 32 == 0, "conv: Cin=%d must be a multiple of 32", a.Cin);
     PIPS_CHECK_ARG(a.N % 32 == 0 && (a.N % 64 == 0 || a.N % 96 == 0), "conv: unsupported Cout=%d", a.N);
     PIPS_CHECK_ARG(a.K == a.KH * a.KW * a.Cin, "conv: K mismatch");
+    {                                                        // the four-wave assembly kernels of conv_f32_t4.hip (the big 3x3 layers)
+        const int cfg = conv_f32_t4_config(a, frames);
+        if (cfg >= 0) return launch_conv_f32_t4(a, cfg, frames, tiles_m, st);
+    }
     int bm, bn;
     conv_tile(a.M, a.N, frames, &bm, &bn);
     // partials per frame: m tiles x wave rows (WGM = 4 for the 128x96 tile, 2 elsewhere)

@@ -13,6 +13,6 @@ cd "$ROOT/pips_amd/csrc"
 EXT=o
 case " $* " in *" -DPIPS_TUNING "*) EXT=tune.o ;; esac
 OBJS=""
-for f in gemm gemm_f32_t4 encoder encoder_bf16 track gather_tiled scoremap gemm_bf16 gemm_bf16_t4 conv_bf16_c64 conv_bf16_t4c gemm_x3 api; do [ $f = $UNIT ] || OBJS="$OBJS $f.$EXT"; done
+for f in gemm gemm_f32_t4 conv_f32_t4 encoder encoder_bf16 track gather_tiled scoremap gemm_bf16 gemm_bf16_t4 conv_bf16_c64 conv_bf16_t4c gemm_x3 api; do [ $f = $UNIT ] || OBJS="$OBJS $f.$EXT"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build/libpips_$NAME.so" $OBJS "$ROOT/build/${UNIT}_$NAME.o"
 echo "$ROOT/build/libpips_$NAME.so"
