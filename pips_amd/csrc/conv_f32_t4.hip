@@ -28,6 +28,7 @@ __device__ __forceinline__ unsigned cf4_sgpr(unsigned v) { return (unsigned)__bu
 struct ConvT4Args {
     const float* in; const float* wgt; const float* bias; float* out; float* stats;
     int M, Wimg, bpf, tiles, parts; unsigned invW;
+    int by_xcd;      // frames % 8 == 0: blocks are dealt so that all blocks of a frame run on ONE XCD (block & 7 = frame & 7)
 };
 
 // CFG 0: 64 -> 64 (tile 256 pixels x 64 channels), 1: 96 -> 96 (128 x 96), 2: 416 -> 256 (128 x 64, four column tiles)
@@ -45,7 +46,15 @@ __global__ __launch_bounds__(256) void conv3x3_f32_t4_kernel(ConvT4Args p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int f = blockIdx.x / (NCOL * p.bpf), rem = blockIdx.x - f * (NCOL * p.bpf);
+    // Neighbouring tiles share their halo rows (tap row kh = 0 / 2 of a tile is the pixel range of the tile before / behind it, an image
+    // row being about a tile long at 1/2 resolution): with the blocks of a frame on one XCD the halo comes out of that XCD's L2
+    int f, rem;
+    if (p.by_xcd) {
+        const int per = 8 * NCOL * p.bpf, grp = blockIdx.x / per, j = blockIdx.x - grp * per;
+        f = 8 * grp + (j & 7); rem = j >> 3;
+    } else {
+        f = blockIdx.x / (NCOL * p.bpf); rem = blockIdx.x - f * (NCOL * p.bpf);
+    }
     const int tn = rem / p.bpf, b = rem - tn * p.bpf;
     const int ntile = (p.tiles - b + p.bpf - 1) / p.bpf;                  // tiles of this block (>= 1: bpf <= tiles)
     const int col0 = tn * TN;
@@ -121,6 +130,7 @@ static int launch_conv_f32_t4_cfg(const GemmArgs& a, int frames, int* parts_out,
     ConvT4Args p;
     p.in = a.A; p.wgt = a.W; p.bias = a.bias; p.out = a.C; p.stats = a.stats;
     p.M = a.M; p.Wimg = a.Win; p.bpf = bpf; p.tiles = tiles; p.parts = cdiv(a.M, PX / 4);
+    p.by_xcd = (frames % 8 == 0) && PIPS_TUNE("PIPS_CONV_F32_T4_XCD", 1);
     p.invW = (unsigned)((0x100000000ull + (unsigned)a.Win - 1) / (unsigned)a.Win);      // ceil(2^32 / W): exact rows for p < 2^32 / W
     hipLaunchKernelGGL(conv3x3_f32_t4_kernel<CFG>, dim3(frames * NCOL * bpf), dim3(256), LDS, st, p);
     PIPS_CHECK_LAUNCH("conv3x3_f32_t4_kernel");
