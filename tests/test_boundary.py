@@ -182,3 +182,8 @@ def test_build_script_dependencies_exist_and_asm_is_current(tmp_path):
     env["PIPS_GEN_OUT"] = str(out5)
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_conv_bf16_t4c.py")], env=env, stdout=subprocess.DEVNULL)
     assert out5.read_text() == open(os.path.join(root, "pips_amd", "csrc", "conv_bf16_t4c_asm.inc")).read()
+    for gen, inc in (("gen_gemm_f32_t4.py", "gemm_f32_t4_asm.inc"), ("gen_conv_f32_t4.py", "conv_f32_t4_asm.inc")):
+        out6 = tmp_path / inc
+        env["PIPS_GEN_OUT"] = str(out6)
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", gen)], env=env, stdout=subprocess.DEVNULL)
+        assert out6.read_text() == open(os.path.join(root, "pips_amd", "csrc", inc)).read()

@@ -32,6 +32,7 @@ OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc"
 
 LDROW = 144
 NV = 216
+ABLATE = set(os.environ.get("PIPS_GEN_ABLATE", "").split(","))      # timing experiments only (wrong results): noflags, noepi, nostats
 RS_A, RS_W, RS_C, RS_B, RS_S = 40, 44, 48, 52, 56
 S_TAP = 60                          # s[60:68]: ((kh - 1) W + (kw - 1)) * 4 Cin of the nine taps, as wrapping unsigned numbers
 S_P, S_PNEXT, S_M0, S_NEXT, S_TL, S_T, S_WOFF, S_T2, S_T3, S_NVR, S_C0, S_S0 = 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80
@@ -148,7 +149,7 @@ def load_piece(e, c, ring, s, kw):
     if s < c.npa:
         off = c.tmp + 1 + (s & 1)                              # (alternating: the load before may not have read its address yet)
         e.raw("v_add_u32 v%d, s%d, v%d" % (off, S_T, c.voa + s))
-        if kw != 1:
+        if kw != 1 and "noflags" not in ABLATE:
             e.raw("v_and_b32 v%d, %d, v%d" % (c.tmp, 1 if kw == 0 else 2, c.flg + s))
             e.raw("v_cmp_ne_u32 vcc, 0, v%d" % c.tmp)
             e.raw("v_cndmask_b32 v%d, v%d, v%d, vcc" % (off, off, c.voob))
@@ -240,6 +241,9 @@ def stage(e, c, t):
 def epilogue(e, c):
     """the finished tile: + bias, 4-byte stores (dropped behind the frame's last pixel), InstanceNorm partials; left with its last
     stores in flight; then the tile state moves on"""
+    if "noepi" in ABLATE:
+        tile_advance(e, c)
+        return
     e.need_loads()
     e.raw("s_nop 15")
     e.raw("s_nop 15")
@@ -280,10 +284,11 @@ def epilogue(e, c):
                 e.raw("v_accvgpr_read_b32 v%d, a%d" % (X + j, c.acc(i, j) + r))
                 e.raw("v_add_f32 v%d, v%d, v%d" % (X + j, X + j, c.bias + j))
                 e.need_lds({("piv", j)})
-                e.raw("v_sub_f32 v%d, v%d, v%d" % (D, X + j, S + 2))
-                e.raw("v_cndmask_b32 v%d, 0, v%d, vcc" % (D, D))
-                e.raw("v_add_f32 v%d, v%d, v%d" % (S, S, D))
-                e.raw("v_fmac_f32 v%d, v%d, v%d" % (S + 1, D, D))
+                if "nostats" not in ABLATE:
+                    e.raw("v_sub_f32 v%d, v%d, v%d" % (D, X + j, S + 2))
+                    e.raw("v_cndmask_b32 v%d, 0, v%d, vcc" % (D, D))
+                    e.raw("v_add_f32 v%d, v%d, v%d" % (S, S, D))
+                    e.raw("v_fmac_f32 v%d, v%d, v%d" % (S + 1, D, D))
                 e.vmem("buffer_store_dword v%d, v%d, s[%d:%d], 0 offen offset:%d" % (X + j, OFF, RS_C, RS_C + 3, 128 * j), ("out", k))
             k += 1
     # the lane halves' sums and counts meet (ds_bpermute with lane ^ 32), the lower half stores {s1, s2, p, n}
@@ -304,7 +309,11 @@ def epilogue(e, c):
     for j in range(c.nj):
         S = c.stat + 4 * j
         e.vmem("buffer_store_dwordx4 v[%d:%d], v%d, s[%d:%d], 0 offen offset:%d" % (S, S + 3, T, RS_S, RS_S + 3, 512 * j), ("out", "s"))
-    # the next tile becomes this one; the one after it: + pstep pixels (clamped: the tile behind the block's last one is never used)
+    tile_advance(e, c)
+
+
+def tile_advance(e, c):
+    """the next tile becomes this one; the one after it: + pstep pixels (clamped: the tile behind the block's last one is never used)"""
     e.raw("s_mov_b32 s%d, s%d" % (S_P, S_PNEXT))
     e.raw("s_mov_b32 s%d, s%d" % (S_M0, S_NEXT))
     e.raw("s_add_u32 s%d, s%d, %%[pstep]" % (S_PNEXT, S_PNEXT))
