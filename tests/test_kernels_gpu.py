@@ -37,6 +37,9 @@ def _rel_err(a, b):
     (2048, 2048, 128, 1),      # the same, four stages only (no pass through its K loop)
     (3072, 512, 1024, 2),      # gemm_f32_t4d_kernel (64x64 tiles, K split over the waves), 8 stages
     (2048, 384, 512, 2),       # the same at its shortest K, 192 tiles
+    (2176, 2048, 576, 1),      # 17 x 16 tiles of 128 (more blocks than compute units, a 1 x 8 XCD split), 18 stages
+    (2112, 512, 768, 2),       # 33 x 8 tiles of 64, 24 stages
+    (2048, 2176, 512, 2),      # residual form on 128 x 128 tiles with ldc = ldr = 2176
 ])
 def test_gemm_f32(M, N, K, epi):
     from pips_amd import ops
@@ -188,6 +191,9 @@ def test_conv_split_bf16_256_row_tile(F_, H, W, Cin, Cout, k, s, p):
     (8, 93, 125, 96, 96, 3, 1, 1),
     (8, 46, 62, 416, 256, 3, 1, 1),    # conv2: four column tiles of 64 channels, 117 stages per tile
     (8, 45, 63, 416, 256, 3, 1, 1),
+    (640, 5, 7, 64, 64, 3, 1, 1),      # one ragged tile per frame, seven-pixel image rows: every piece straddles rows, most taps fall outside
+    (1300, 3, 3, 96, 96, 3, 1, 1),     # the smallest frame the kernels take
+    (3, 300, 401, 64, 64, 3, 1, 1),    # few large frames (frames % 8 != 0: the linear block order)
 ])
 def test_conv_nhwc(F_, H, W, Cin, Cout, k, s, p):
     from pips_amd import ops
