@@ -521,12 +521,24 @@ __device__ __forceinline__ void ln_stats2(const f2 (&x)[S], float (&mean)[S], fl
 // XN_BF16: the LayerNorm-2 output only feeds the up-projection; in the bf16-operand mode that GEMM rounds it to bf16
 // while staging it, so it is stored as bf16 here (same hardware round-to-nearest-even: identical operands, half the
 // bytes the 16 column tiles of the GEMM re-read)
+#ifdef PIPS_TOKEN_TRACE
+// tools/token_trace.py (variant build): shader-clock stamps of block 0 .. 255 at the kernel's phases
+__device__ unsigned long long g_token_trace[256 * 8];
+#define PIPS_TT(k) if (threadIdx.x == 0 && blockIdx.x < 256) g_token_trace[blockIdx.x * 8 + (k)] = clock64();
+extern "C" int pips_debug_token_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_token_trace), sizeof(unsigned long long) * 256 * 8);
+}
+#else
+#define PIPS_TT(k)
+#endif
+
 template <bool XN_BF16>
 __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict__ arena, MixLayerW L,
                                                         float* __restrict__ x, float* __restrict__ xn) {
     __shared__ __attribute__((aligned(16))) float red[S][4];
     __shared__ float wsm[32 * 8 + 32 + 8 * 32 + 8];
     const int tid = threadIdx.x;
+    PIPS_TT(0)
     // thread -> channels 2*tid, 2*tid+1 (one 8-byte access per token row).  The particle's tile is requested FIRST: hipcc turns
     // the four small weight copies below into load -> wait -> ds_write one after the other, and with them in front the tile's
     // loads (the long ones) left three L2 round trips late -- in a kernel that is all latency at 256 particles.
@@ -547,7 +559,9 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
         if (tid < 32) wsm[256 + tid] = b0v;
         if (tid >= 64 && tid < 72) wsm[544 + (tid - 64)] = b3v;
     }
+    PIPS_TT(1)
     ln_stats2(xv, mean, rstd, red);          // (its barriers also publish wsm)
+    PIPS_TT(2)
 
     f2 h[S], y[S];
 #pragma unroll
@@ -566,8 +580,10 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int t = 0; t < S; ++t) y[t] += xv[t];
+    PIPS_TT(3)
 
     ln_stats2(y, mean, rstd, red);
+    PIPS_TT(4)
 #pragma unroll
     for (int t = 0; t < S; ++t) {
         *reinterpret_cast<f2*>(xp + t * PIPS_DMIX) = y[t];
@@ -580,6 +596,7 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
             *reinterpret_cast<f2*>(xnp + t * PIPS_DMIX) = o;
         }
     }
+    PIPS_TT(5)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
