@@ -110,7 +110,7 @@ def gemm_kernel_name(M, N, K, epi):
     if route == 1:
         return "gemm_f32_t4u_kernel<%d>" % (0 if epi == 1 else 1)
     if route == 2:
-        return "gemm_f32_t4d_kernel"
+        return "gemm_f32_t4e_kernel"
     return "igemm_f32_kernel<64, 64, 2, 2, %d, false>" % (1 if epi == 1 else 2)
 
 

@@ -285,7 +285,7 @@ int    pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf
 
 /* Which kernel pips_gemm_f32 (and the fp32 mixer of pips_forward) takes for a problem with bias and, for epi = residual, a residual of
  * ldr = N: 0 = igemm_f32_kernel (gemm.hip); 1 = gemm_f32_t4u_kernel (128 x 128 tiles: epi GELU or residual, M and N multiples of
- * 128, K % 64 == 0, at least three quarters of a tile per compute unit); 2 = gemm_f32_t4d_kernel (64 x 64 tiles, the K range split
+ * 128, K % 64 == 0, at least three quarters of a tile per compute unit); 2 = gemm_f32_t4e_kernel (64 x 64 tiles, LDS-DMA staging; the K range split
  * over the four waves and summed in a fixed order: epi residual, K % 128 == 0, between 0.75 and 2 tiles per compute unit -- the
  * down-projection at M = 2048).  Same exact-fp32 MFMA arithmetic everywhere; 1 is bitwise igemm_f32_kernel's unsplit form, 2
  * differs from it by the order of the four partial sums.  Host function; needs a current device. */

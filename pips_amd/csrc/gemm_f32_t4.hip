@@ -137,6 +137,46 @@ __global__ __launch_bounds__(256) void gemm_f32_t4d_kernel(GemmArgs p, F4Grid gr
     asm volatile(PIPS_F32T4_D_RES_TEXT : F4_OPERANDS : PIPS_F32T4_CLOBBER);
 }
 
+// Shape E = shape D with the operands staged by LDS-DMA (no staging registers, no ds_write; tools/gen_gemm_f32_t4.py: body_e).  LDS: four
+// buffers of 128 dense 128-byte rows, chunk slot j of row r = global chunk j ^ ((r >> 1) & 7).
+constexpr int F4_LDS_E = 4 * 128 * 128;                      // 65 536 bytes (the four partial tiles at the end use the same 64 KiB)
+__global__ __launch_bounds__(256) void gemm_f32_t4e_kernel(GemmArgs p, F4Grid grid) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    int tm, tn;
+    f4_tile(grid, &tm, &tn);
+    const int m0 = tm * 64, n0 = tn * 64;
+    // staging: wave w fills LDS rows 32 w .. 32 w + 31 (waves 0, 1: the tile's A rows, waves 2, 3: its W rows); DMA instruction k:
+    // rows 8 k .. 8 k + 7 of them, lane = (row q = lane >> 3, chunk slot j = lane & 7) fetching chunk j ^ ((row >> 1) & 7)
+    const bool isA = wave < 2;
+    const int ld = isA ? p.lda : p.K, row0 = 32 * (wave & 1);
+    const float* Xb = isA ? p.A + (size_t)m0 * p.lda : p.W + (size_t)n0 * p.K;
+    const int q = lane >> 3, j = lane & 7;
+    const unsigned vo0 = (unsigned)((row0 + q) * ld * 4 + ((j ^ (q >> 1)) * 16));
+    const unsigned vo1 = (unsigned)((row0 + 8 + q) * ld * 4 + ((j ^ (4 + (q >> 1))) * 16));
+    const unsigned pass2 = (unsigned)(16 * ld * 4);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = lds0 + 32 * wave * 128;
+    // fragments: lane = row l31 of a 32-row block, this wave's 8 K values of the stage = chunks 2 wave, 2 wave + 1 (lane half)
+    const unsigned rA0 = lds0 + l31 * 128 + (((2 * wave + half) ^ ((l31 >> 1) & 7)) * 16), rW0 = rA0 + 64 * 128;
+    const unsigned redW = lds0 + wave * 16384 + lane * 16, redR = lds0 + wave * 4096 + lane * 16;
+    const int bi = wave & 1, bj = wave >> 1;
+    const float* Cb = p.C + (size_t)(m0 + 32 * bi) * p.ldc + n0 + 32 * bj;
+    const float* Rb = p.R + (size_t)(m0 + 32 * bi) * p.ldr + n0 + 32 * bj;
+    const float* Bb = p.bias + n0 + 32 * bj;
+    const unsigned voC = (unsigned)((l31 * p.ldc + 4 * half) * 4), voR = (unsigned)((l31 * p.ldr + 4 * half) * 4), voB = (unsigned)(16 * half);
+    const unsigned kt = (unsigned)(p.K / 32);
+    asm volatile(PIPS_F32T4_E_RES_TEXT
+                 :
+                 : [rA0] "v"(rA0), [rW0] "v"(rW0), [vo0] "v"(vo0), [vo1] "v"(vo1), [voR] "v"(voR), [voC] "v"(voC), [voB] "v"(voB),
+                   [redW] "v"(redW), [redR] "v"(redR), [xlo] "s"(F4_LO(Xb)), [xhi] "s"(F4_HI(Xb)), [rlo] "s"(F4_LO(Rb)), [rhi] "s"(F4_HI(Rb)),
+                   [clo] "s"(F4_LO(Cb)), [chi] "s"(F4_HI(Cb)), [blo] "s"(F4_LO(Bb)), [bhi] "s"(F4_HI(Bb)), [pass2] "s"(f4_sgpr(pass2)),
+                   [ldsw] "s"(f4_sgpr(ldsw)), [kt] "s"(f4_sgpr(kt))
+                 : PIPS_F32T4_CLOBBER);
+}
+
 // Which of the kernels above takes a plain fp32 GEMM: 0 none (igemm_f32_kernel), 1 shape U, 2 shape D; *tpb = row tiles per block (U).
 int gemm_f32_t4_route(const GemmArgs& a, int* tpb) {
     if (!PIPS_TUNE("PIPS_F32_T4", 1)) return 0;               // tuning hook: 0 = igemm_f32_kernel everywhere
@@ -178,6 +218,15 @@ int launch_gemm_f32_t4(const GemmArgs& a, int route, int tpb, hipStream_t st) {
             hipLaunchKernelGGL(gemm_f32_t4u_kernel<1>, dim3(blocks), dim3(256), F4_LDS_U, st, a, grid, tpb);
         }
         PIPS_CHECK_LAUNCH("gemm_f32_t4u_kernel");
+        return PIPS_OK;
+    }
+    if (PIPS_TUNE("PIPS_F32_T4_E", 1)) {                      // tuning hook: shape E (LDS-DMA staging) in place of shape D
+        static std::atomic<unsigned long long> raised3{0};
+        const int rc3 = ensure_dynamic_lds(raised3, (const void*)gemm_f32_t4e_kernel, F4_LDS_E);
+        if (rc3 != PIPS_OK) return rc3;
+        const F4Grid grid = f4_grid(a.M / 64, a.N / 64, (long)64 * a.K * 4, (long)64 * a.K * 4);
+        hipLaunchKernelGGL(gemm_f32_t4e_kernel, dim3((a.M / 64) * (a.N / 64)), dim3(256), F4_LDS_E, st, a, grid);
+        PIPS_CHECK_LAUNCH("gemm_f32_t4e_kernel");
         return PIPS_OK;
     }
     static std::atomic<unsigned long long> raised2{0};

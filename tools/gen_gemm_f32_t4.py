@@ -526,6 +526,103 @@ def body(shape, epi):
     return e.lines
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Shape E = shape D with the operands staged by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write).  Shape D's K loop
+# pays for its staging instructions (4 loads + 4 ds_writes per 16 MFMAs: 130 TF against 158 without them).  LDS image of a stage:
+# 128 dense rows of 128 bytes (A rows 0..63, W rows 64..127), chunk slot j of row r holding global chunk j ^ ((r >> 1) & 7) -- the
+# swizzle is applied on the GLOBAL side (a DMA instruction writes 1 KiB linearly: lane l -> 16 bytes at 16 l) and makes the fragment
+# reads conflict-free.  Wave w stages rows 32 w .. 32 w + 31 (four DMA instructions of 8 rows), FOUR buffers, a stage requested three
+# stages ahead, waited for (by its own wave) before the barrier at the end of the stage two before its use.
+EBUF = 128 * 128
+
+
+def body_e():
+    sh = Shape("D", "res")
+    sh.vo = 96
+    e = Emit()
+    descriptor(e, RS_A, "%[xlo]", "%[xhi]")                  # this wave's operand (A for waves 0, 1; W for waves 2, 3)
+    descriptor(e, RS_C, "%[clo]", "%[chi]")
+    descriptor(e, RS_B, "%[blo]", "%[bhi]")
+    descriptor(e, RS_R, "%[rlo]", "%[rhi]")
+    e.raw("v_mov_b32 v%d, %%[vo0]" % sh.vo)
+    e.raw("v_mov_b32 v%d, %%[vo1]" % (sh.vo + 1))
+    e.raw("v_add_u32 v%d, %%[pass2], v%d" % (sh.vo + 2, sh.vo))
+    e.raw("v_add_u32 v%d, %%[pass2], v%d" % (sh.vo + 3, sh.vo + 1))
+    e.raw("s_sub_u32 s%d, %%[kt], 1" % S_LASTA)
+    e.raw("s_lshl_b32 s%d, s%d, 7" % (S_LASTA, S_LASTA))     # the last stage a request may name
+    e.raw("s_mov_b32 s%d, 0" % S_SOA)
+
+    def dma(buf, k):
+        e.raw("s_add_u32 m0, %%[ldsw], %d" % (buf * EBUF + 8 * k * 128))
+        e.vmem("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (sh.vo + k, RS_A, RS_A + 3, S_SOA), ("st", buf, k))
+
+    def advance():
+        e.raw("s_add_u32 s%d, s%d, 128" % (S_SOA, S_SOA))
+        e.raw("s_min_u32 s%d, s%d, s%d" % (S_SOA, S_SOA, S_LASTA))
+
+    def fread(buf, fset, which, idx):
+        reg = (FA if which == "a" else FW)[fset] + 4 * idx
+        e.lds("ds_read_b128 v[%d:%d], %%[r%s0] offset:%d" % (reg, reg + 3, "A" if which == "a" else "W", buf * EBUF + idx * 32 * 128),
+              ("f" + which, fset, idx))
+
+    for t in range(4):                                       # bias quad t of the block's 32 columns
+        e.vmem("buffer_load_dwordx4 v[%d:%d], %%[voB], s[%d:%d], 0 offen offset:%d" % (sh.bias + 4 * t, sh.bias + 4 * t + 3, RS_B, RS_B + 3, 32 * t),
+               ("bias", t))
+    for b in range(3):                                       # stages 0, 1, 2 requested
+        if b:
+            advance()
+        for k in range(4):
+            dma(b, k)
+    e.need_vm({("st", 1, k) for k in range(4)})              # stages 0 and 1 of this wave have landed
+    e.barrier()
+    for which, idx in FRAG_ORDER:
+        fread(0, 0, which, idx)
+
+    def stage_e(t, first, extra=()):
+        advance()
+        slots = {}
+
+        def put(n, fn):
+            slots.setdefault(n, []).append(fn)
+
+        for r, (which, idx) in enumerate(FRAG_ORDER):
+            put(1 + r, lambda which=which, idx=idx: fread((t + 1) % 4, (t + 1) & 1, which, idx))
+        for k in range(4):
+            put(5 + 2 * k, lambda k=k: dma((t + 3) % 4, k))
+        put(15, lambda: (e.need_vm({("st", (t + 2) % 4, k) for k in range(4)}), e.barrier()))
+        for k, op in enumerate(extra):
+            put([13, 14, 12, 10][k], lambda op=op: op(e))
+        n = 0
+        for c in range(4):
+            for (i, j) in sh.blocks:
+                mfma(e, t & 1, c, i, j, first and c == 0)
+                for fn in slots.get(n, []):
+                    fn()
+                n += 1
+
+    extra = residual_loads(sh)
+    for t in range(4):
+        stage_e(t, t == 0)
+    e.raw("s_lshr_b32 s%d, %%[kt], 2" % S_KL)
+    e.raw("s_sub_u32 s%d, s%d, 2" % (S_KL, S_KL))
+    e.raw("s_cmp_eq_u32 s%d, 0" % S_KL)
+    e.raw("s_cbranch_scc1 3f")
+    head = (list(e.lgkm), list(e.vm))
+    e.raw("1:")
+    for t in range(4):
+        stage_e(t, False)
+    assert (e.lgkm, e.vm) == head, "loop body does not reproduce its head state"
+    e.raw("s_sub_u32 s%d, s%d, 1" % (S_KL, S_KL))
+    e.raw("s_cmp_lg_u32 s%d, 0" % S_KL)
+    e.raw("s_cbranch_scc1 1b")
+    e.raw("3:")
+    for t in range(4):
+        stage_e(t, False, extra if t == 3 else ())
+    epilogue_d(e, sh)
+    e.drain()
+    return e.lines
+
+
 def main():
     clob = ['"memory"', '"scc"', '"vcc"'] + ['"a%d"' % i for i in range(64)] + ['"v%d"' % i for i in range(NV)] + \
            ['"s%d"' % i for i in range(40, 92)]
@@ -538,6 +635,12 @@ def main():
                 f.write('    "%s\\n\\t" \\\n' % ln)
             f.write('    ""\n\n')
             print("PIPS_F32T4_%s_TEXT: %d instructions, %d MFMAs" % (name, len(lines), sum("v_mfma" in ln for ln in lines)))
+        lines = body_e()
+        f.write("#define PIPS_F32T4_E_RES_TEXT \\\n")
+        for ln in lines:
+            f.write('    "%s\\n\\t" \\\n' % ln)
+        f.write('    ""\n\n')
+        print("PIPS_F32T4_E_RES_TEXT: %d instructions, %d MFMAs" % (len(lines), sum("v_mfma" in ln for ln in lines)))
         f.write("#define PIPS_F32T4_CLOBBER " + ", ".join(clob) + "\n")
     print("wrote", OUT)
 
