@@ -16,6 +16,7 @@
 //     D   64 x 64 tile, every wave the whole tile on one of the four groups of 8 K values of each 32-wide stage, the four partial
 //         tiles summed through LDS in a fixed order -- when there are too few 128 x 128 tiles for the chip (the down-projection
 //         at M = 2048: 64 of them)
+//     E   shape D staged by LDS-DMA (no staging registers, no ds_write): what the product runs for shape D's problems; bitwise D
 #include "common.h"
 #ifndef PIPS_F32T4_INC
 #define PIPS_F32T4_INC "gemm_f32_t4_asm.inc"      // tuning builds point this at another schedule of the generator

@@ -13,7 +13,8 @@ Two block shapes:
         and every wave finishes ONE of the four 32 x 32 blocks -- for the problems with too few 128 x 128 tiles to fill the
         chip (M = 2048, N = 512).  (First built with every wave on a quarter of a 128-wide stage: 64 KiB per stage and CU had
         to arrive before the first MFMA, 3 us of prologue.)
-and three epilogues: + bias + exact GELU (U), + bias + residual (U, D).
+    E   shape D with the operands staged by LDS-DMA (see body_e below)
+and three epilogues: + bias + exact GELU (U), + bias + residual (U, D, E).
 
 LDS image of a stage: rows of 32 K values (128 B) at a stride of 144 B -- what makes the ds_read_b128 fragment reads
 (lane -> row l & 31, 16 bytes at 32 kk + 16 (l >> 5)) conflict-free in every lane group; the lane halves take interleaved
