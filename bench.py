@@ -99,8 +99,18 @@ def gemm_roofline(model, device, b, flags=0):
     o = sum(ovh) / len(ovh)
     t_up, t_down = sum(ups) / len(ups) - o, sum(downs) / len(downs) - o
     flops = 2.0 * M * 2048 * 512
-    return {"up_proj(M=%d,N=2048,K=512)" % M: {"ms": t_up, "tflops": flops / t_up / 1e9},
-            "down_proj(M=%d,N=512,K=2048)" % M: {"ms": t_down, "tflops": flops / t_down / 1e9}}
+    tr = gemm_trains(arena, X, flags)
+    return {"up_proj(M=%d,N=2048,K=512)" % M: {"ms": tr["up_proj"], "tflops": flops / tr["up_proj"] / 1e9, "kernel_body_ms": t_up},
+            "down_proj(M=%d,N=512,K=2048)" % M: {"ms": tr["down_proj"], "tflops": flops / tr["down_proj"] / 1e9,
+                                                  "kernel_body_ms": t_down}}
+
+
+def gemm_trains(arena, X, flags=0):
+    """{up_proj, down_proj} ms per launch from launch TRAINS (ops.mixer_gemm_train: the pass's 12 up- / 12 down-projections back
+    to back between one HIP event pair, start to start); median of 5 trains of 48 launches."""
+    from pips_amd import ops
+    runs = [ops.mixer_gemm_train(arena, X, flags=flags, reps=4) for _ in range(6)][1:]
+    return {k: statistics.median(r[k] for r in runs) for k in ("up_proj", "down_proj")}
 
 
 def gemm_kernel_name(M, N, K, epi):
@@ -114,20 +124,55 @@ def gemm_kernel_name(M, N, K, epi):
     return "igemm_f32_kernel<64, 64, 2, 2, %d, false>" % (1 if epi == 1 else 2)
 
 
+def rocprof_avg_us(kernel_substr, stats_glob="r*_kernel_stats.txt"):
+    """Average duration (us) of a kernel in the newest committed rocprofv3 kernel-trace summary of the headline command
+    (profiles/rN_kernel_stats.txt, tools/profile_round.sh).  Returns (us or None, source)."""
+    import glob
+    import re
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", stats_glob)) if re.search(r"r\d+_kernel_stats\.txt$", f)]
+    files.sort(key=lambda f: int(re.search(r"r(\d+)_kernel_stats", f).group(1)))
+    if not files:
+        return None, None
+    try:
+        for line in open(files[-1]):
+            if kernel_substr in line:
+                cols = line.rsplit(None, 4)                       # kernel | calls | total_us | avg_us | pct
+                return float(cols[-2]), "profiles/" + os.path.basename(files[-1])
+    except (OSError, ValueError, IndexError):
+        pass
+    return None, None
+
+
 def roofline_object(kern, fake=False):
+    """The dominant kernel = the slower of the two channel-mix GEMM shapes.  `frac` comes from LAUNCH TRAINS (start-to-start
+    duration of back-to-back launches: what the forward pays per launch and what a rocprofv3 kernel trace of the forward shows);
+    the event-pair-minus-overhead figure of rounds 1-4 (the kernel body without its launch boundary) stays beside it as
+    kernel_body_ms, and the committed rocprofv3 summary's average as launch_ms_rocprof / frac_rocprof."""
     dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
     # HBM-side bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
     # command, committed per round under profiles/ (a live bench run cannot collect PMC counters itself)
     M = int(dom[0].split("M=")[1].split(",")[0])
     name = gemm_kernel_name(M, 2048, 512, 1) if dom[0].startswith("up") else gemm_kernel_name(M, 512, 2048, 2)
     traffic, traffic_src = pmc_traffic(name)
-    # report the slower (dominant) of the two GEMM shapes
-    return {"bound": "mfma", "achieved": dom[1]["tflops"], "peak": PEAK_F32_MFMA_TF,
-            "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_F32_MFMA_TF, "traffic": traffic,
-            "traffic_source": traffic_src,
-            "kernel": name + " " + dom[0], "launch_ms": dom[1]["ms"],
-            "timing": "HIP event pair around each in-situ launch, empty-pair overhead subtracted",
-            "all": kern}
+    flops = 2.0 * M * 2048 * 512
+    rp_us, rp_src = rocprof_avg_us(name.split("(")[0])
+    out = {"bound": "mfma", "achieved": dom[1]["tflops"], "peak": PEAK_F32_MFMA_TF,
+           "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_F32_MFMA_TF, "traffic": traffic,
+           "traffic_source": traffic_src,
+           "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE at the fabric: FETCH_SIZE also counts Infinity-Cache hits (the 104 MB of "
+                           "weights live there), so bytes above the algorithmic count are mostly cache hits, not HBM re-reads",
+           "algorithmic_flop_per_launch": flops,
+           "kernel": name + " " + dom[0], "launch_ms": dom[1]["ms"],
+           "timing": "launch train: the 12 layers' launches of this shape back to back between ONE HIP event pair on the launch "
+                     "stream, x4, median of 5 trains; start-to-start, nothing subtracted (pips_mixer_gemm_train)",
+           "kernel_body_ms": dom[1].get("kernel_body_ms"),
+           "kernel_body_timing": "HIP event pair around each in-situ launch of a mixer pass, empty-pair overhead subtracted "
+                                 "(rounds 1-4 reported this as launch_ms; it leaves the launch boundary out)",
+           "launch_ms_rocprof": None if rp_us is None else rp_us / 1e3,
+           "frac_rocprof": None if rp_us is None else flops / (rp_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TF,
+           "rocprof_source": rp_src,
+           "all": kern}
+    return out
 
 
 def stage_profile(model, xys, rgbs, device, b):
@@ -166,9 +211,11 @@ def stage_profile(model, xys, rgbs, device, b):
         return sum(ups) / len(ups) - o, sum(downs) / len(downs) - o
     t_up, t_down = timed(0)
     flops = 2.0 * M * 2048 * 512
+    tr = gemm_trains(arena, X, 0)                       # start-to-start launch durations: what roofline.frac is quoted on
     kern = {
-        "up_proj(M=%d,N=2048,K=512)" % M: {"ms": t_up, "tflops": flops / t_up / 1e9},
-        "down_proj(M=%d,N=512,K=2048)" % M: {"ms": t_down, "tflops": flops / t_down / 1e9},
+        "up_proj(M=%d,N=2048,K=512)" % M: {"ms": tr["up_proj"], "tflops": flops / tr["up_proj"] / 1e9, "kernel_body_ms": t_up},
+        "down_proj(M=%d,N=512,K=2048)" % M: {"ms": tr["down_proj"], "tflops": flops / tr["down_proj"] / 1e9,
+                                              "kernel_body_ms": t_down},
     }
     s_up, s_down = timed(16)
     split = {
@@ -451,6 +498,9 @@ def cpu_baseline():
         ts.append(time.time() - t0)
     med = statistics.median(ts)
     return {"value": S * NPTS * ITERS / med, "unit": "particle-updates/s", "cores": cores, "kind": "port",
+            "kind_note": "port of nets/pips.py's forward with bit-identical outputs (oracle/check_against_reference.py: 0.0); it skips "
+                         "the dead per-iteration `fcp` score-map upsample (nets/pips.py:504-511, ~10 % of the reference's CPU time), "
+                         "so the unmodified reference would read ~10 % lower; /root/reference does not exist on the bench box",
             "sample": f"{len(ts)} forwards of the same workload (B=1,S=8,368x496,N=256,I=6 fp32), median {med:.3f} s, "
                       f"torch {torch.__version__} CPU ops, oracle/pips_oracle.py"}
 
@@ -464,6 +514,12 @@ class _CpuStandIn:
         preds = [base + i for i in range(iters)]
         return preds, [base, base] + preds + [preds[-1]] * 2, base.sum(-1), None
 
+    def encode(self, rgbs):                      # (the encoder / tracker split of the particle-sharded leg)
+        return rgbs
+
+    def track(self, cache, xys, iters=6, **kw):
+        return self(xys, cache, iters=iters)
+
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
@@ -473,8 +529,10 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config 3/4/5 legs and the torch-ROCm baseline")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3),
-                    help="2 (default, the headline: B=1/GPU fp32) or 3 (B=8/GPU, bf16 MFMA operands)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
+                    help="2 (default, the headline: B=1/GPU fp32), 3 (B=8/GPU, bf16 MFMA operands) or 4 (BASELINE configs[3]: "
+                         "B=4 720x1280 N=4096 fp32 -- with --gpus N the PARTICLES are sharded over the ranks on replicated maps, "
+                         "strong scaling, SURVEY 8(e) secondary axis)")
     ap.add_argument("--leg", default=None, choices=("config3", "config4", "config5", "torch_rocm_baseline"),
                     help="run ONE of the extra legs alone and print its JSON (what the rocprofv3 passes under profiles/ wrap)")
     ap.add_argument("--matmul", default="exact", choices=("exact", "split"),
@@ -527,10 +585,20 @@ def main(argv=None):
     sync = (lambda: None) if fake else torch.cuda.synchronize
 
     from pips_amd import dist as pdist
-    b_per_gpu = 8 if args.config == 3 else 1
+    b_per_gpu = 8 if args.config == 3 else (4 if args.config == 4 else 1)
+    c4_n = 64 if fake else 4096
     if fake:
         model = _CpuStandIn()
-        xys, rgbs = make_inputs(rank, device, b_per_gpu, 32, 32, 16)
+        xys, rgbs = make_inputs(0 if args.config == 4 else rank, device, b_per_gpu, 32, 32, c4_n if args.config == 4 else 16)
+    elif args.config == 4:
+        # BASELINE configs[3]: every rank holds the SAME 4 clips (B < G: nothing to shard on the clip axis) and the 64x64 grid
+        from pips_amd import Pips
+        model = Pips(S=S, stride=STRIDE).to(device).eval()
+        model.matmul = args.matmul
+        g4 = torch.Generator().manual_seed(1)
+        rgbs = torch.randint(0, 256, (4, S, 3, 720, 1280), generator=g4, dtype=torch.uint8).to(device).float()
+        gy, gx = torch.meshgrid(torch.linspace(8, 720 - 8, 64), torch.linspace(8, 1280 - 8, 64), indexing="ij")
+        xys = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1).unsqueeze(0).repeat(4, 1, 1).to(device)
     else:
         from pips_amd import Pips
         model = Pips(S=S, stride=STRIDE).to(device).eval()               # seeded random init (seed 0)
@@ -540,6 +608,8 @@ def main(argv=None):
         xys, rgbs = make_inputs(rank, device, b_per_gpu)
 
     def step():
+        if args.config == 4:          # particles sharded over the ranks on replicated maps + one gather on the particle axis
+            return pdist.track_sharded_particles(model, xys, rgbs, iters=ITERS, encode="replicate")
         preds, _, vis, _ = model(xys, rgbs, iters=ITERS)
         if world > 1:
             pdist.all_gather_result(preds[-1], vis)
@@ -580,8 +650,11 @@ def main(argv=None):
 
     npts = 16 if fake else NPTS
     updates = world * b_per_gpu * S * npts * ITERS * args.steps
+    if args.config == 4:              # the whole job is the 4 clips x N particles, whatever the number of ranks (strong scaling)
+        updates = b_per_gpu * S * c4_n * ITERS * args.steps
     res = {
-        "metric": "particle-updates/sec (B*S*N*iters/s) at S=8 N=256 368x496",
+        "metric": ("particle-updates/sec (B*S*N*iters/s) at S=8 N=4096 720x1280" if args.config == 4 else
+                   "particle-updates/sec (B*S*N*iters/s) at S=8 N=256 368x496"),
         "value": updates / dt,
         "unit": "particle-updates/s",
         "n_gpus": world,
@@ -593,18 +666,23 @@ def main(argv=None):
                               "ms_per_step_median: median of the per-step gaps between HIP events recorded on the launch stream "
                               "(rank 0)",
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.config == 4 else "weak",
         "vs_baseline": None,
         "dtype": ("f32" if args.matmul == "exact" else
                   "f32-grade: split-bf16 (3 exact bf16 terms per fp32 operand, 6 bf16 MFMA products, fp32 accumulate)")
-        if args.config == 2 else "bf16 MFMA operands, fp32 accumulate/state",
+        if args.config in (2, 4) else "bf16 MFMA operands, fp32 accumulate/state",
         "data": "synthetic (uniform 0..255 frames, uniform in-bounds queries, seeded random-init weights)",
         "config": {"workload": ("BASELINE configs[1]: B=1/GPU S=8 368x496 N=256 I=6 fp32 stride 8, encoder included, "
                                 "inputs resident in HBM") if args.config == 2 else
                                ("BASELINE configs[2]: B=8/GPU S=8 368x496 N=256 I=6 bf16 operands stride 8, encoder "
-                                "included, inputs resident in HBM"),
-                   "clips_per_gpu": b_per_gpu, "parallelism": f"clip-sharded x{world}",
-                   "collective": ("none" if world == 1 else f"one all_gather of [x,y,vis] per step, backend "
+                                "included, inputs resident in HBM") if args.config == 3 else
+                               ("BASELINE configs[3]: B=4 S=8 720x1280 N=4096 (64x64 grid) I=6 fp32 stride 8, inputs resident in "
+                                "HBM; every rank encodes the 4 clips (replicated maps) and tracks N/G particles"),
+                   "clips_per_gpu": b_per_gpu,
+                   "parallelism": f"particle-sharded x{world} (pips_amd.dist.track_sharded_particles)" if args.config == 4
+                   else f"clip-sharded x{world}",
+                   "collective": ("none" if world == 1 else f"one all_gather of [x,y,vis] per step"
+                                  f"{' on the particle axis' if args.config == 4 else ''}, backend "
                                   f"{'gloo' if (fake or backend != 'nccl') else 'nccl (RCCL)'}")},
     }
     if fake:

@@ -248,6 +248,14 @@ int    pips_mixer_fwd_timed(const void* arena, const float* X, int M, float* del
 int    pips_mixer_fwd_timed_ex(const void* arena, const float* X, int M, int flags, float* delta,
                                void* workspace, size_t workspace_bytes, void* stream, float* ms_host);
 
+/* Profiling: the two channel-mix Linear shapes (nets/pips.py:102-109) as launch trains -- the 12 layers' up-projections, then
+ * their down-projections, back to back on the layers' own weights between ONE HIP event pair, `reps` times.
+ * ms2_host = {up-projection, down-projection} milliseconds PER LAUNCH, start to start as the forward pays them (no per-launch
+ * marker, nothing subtracted).  The workspace must hold a mixer pass at this M (pips_mixer_fwd* on it first).  bench.py's
+ * roofline.frac comes from this. */
+int    pips_mixer_gemm_train(const void* arena, int M, int flags, void* workspace, size_t workspace_bytes,
+                             void* stream, int reps, float* ms2_host);
+
 /* State update nets/pips.py:525-539 (+ vis head :559 when out_vis != NULL).
  * delta (B*N,1040); ffeats/coords updated in place; coords0 = locked frame-0 coords;
  * out_traj (B,S,N,2) receives coords*stride. */
@@ -290,6 +298,9 @@ int    pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf
  * down-projection at M = 2048).  Same exact-fp32 MFMA arithmetic everywhere; 1 is bitwise igemm_f32_kernel's unsplit form, 2
  * differs from it by the order of the four partial sums.  Host function; needs a current device. */
 int    pips_gemm_f32_route(int M, int N, int K, int epi);
+/* Compute units of the current device (0: no device).  Every "tiles per compute unit" threshold of the route functions is
+ * relative to this number; tests derive their route expectations from it instead of assuming 256. */
+int    pips_device_cus(void);
 
 /* pips_conv_nhwc_f32 with bf16 MFMA operands: the fp32 map is rounded to bf16 while it is staged, wgt_bf16 is the
  * round-to-nearest-even bf16 copy of the [Cout][kh][kw][Cin] weights; fp32 accumulation and output, same stats. */

@@ -68,6 +68,7 @@ SIGNATURES = {
     "pips_mixer_fwd_timed": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p, C.POINTER(c_float)]),
     "pips_mixer_fwd_timed_ex": (c_int, [c_void_p, fp, c_int, c_int, fp, c_void_p, c_size_t, c_void_p,
                                         C.POINTER(c_float)]),
+    "pips_mixer_gemm_train": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int, C.POINTER(c_float)]),
     "pips_state_update": (c_int, [c_void_p, fp, fp, fp, fp, c_int, c_int, c_float, fp, fp, c_void_p]),
     "pips_gemm_f32": (c_int, [fp, c_int, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, c_int, c_void_p]),
     "pips_conv_nhwc_f32": (c_int, [fp, c_int, c_int, c_int, c_int, fp, fp, c_int, c_int, c_int, c_int, fp, fp,
@@ -76,6 +77,7 @@ SIGNATURES = {
                        c_void_p]),
     "pips_gemm_bf16_route": (c_int, [c_int] * 6),
     "pips_gemm_f32_route": (c_int, [c_int] * 4),
+    "pips_device_cus": (c_int, []),
     "pips_conv_nhwc_bf16": (c_int, [fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int, fp, fp,
                                     C.POINTER(c_int), c_void_p]),
     "pips_conv_nhwc_bf16_maps": (c_int, [c_void_p, fp, c_int, c_int, c_int, c_int, c_void_p, fp, c_int, c_int, c_int, c_int,

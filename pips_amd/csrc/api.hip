@@ -90,8 +90,6 @@ static ArenaLayout build_layout(int S) {
     A.h_conv[0] = 0;                                   // the 7x7 stem stays fp32 (VALU kernel)
     for (int i = 1; i < 22; ++i) A.h_conv[i] = take_h((size_t)A.conv[i].cout * A.conv[i].cin * A.conv[i].k * A.conv[i].k);
     A.h_in = take_h((size_t)PIPS_DMIX * PIPS_KIN_PAD);
-    for (int d = 0; d < PIPS_DEPTH; ++d) {
-    }
     A.total_h = hoff;
     size_t toff = 0;
     auto take_t = [&](size_t n) { size_t o = toff; toff += (3 * n + 127) / 128 * 128; return o; };
@@ -791,6 +789,8 @@ int pips_gemm_bf16_route(int M, int N, int K, int epi, int a_bf16, int out_bf16)
     return gemm_bf16_asm_route(g, a_bf16, out_bf16);
 }
 
+int pips_device_cus(void) { return device_cus(); }
+
 int pips_gemm_f32_route(int M, int N, int K, int epi) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     static const float dummy = 0.f;                     // only null-ness of bias / R is inspected
@@ -945,6 +945,70 @@ int pips_mixer_fwd_timed_ex(const void* arena_v, const float* X, int M, int flag
     }
     for (int i = 0; i < 2 * NG; ++i) (void)hipEventDestroy(ev[i]);
     for (int i = 0; i < 2 * NCAL; ++i) (void)hipEventDestroy(cal[i]);
+    return rc;
+}
+
+// The two channel-mix GEMM shapes as launch TRAINS: the 12 layers' up-projections (then their down-projections) back to back on the
+// layers' own weights between ONE event pair, reps times -> ms2_host = {up, down} milliseconds per launch.  No per-launch event and
+// no overhead to subtract: start-to-start durations as the forward pays them (what a rocprofv3 kernel trace of the forward shows).
+// The workspace must hold the activations of a mixer pass at this M (pips_mixer_fwd* on the same workspace first).
+int pips_mixer_gemm_train(const void* arena_v, int M, int flags, void* workspace, size_t workspace_bytes, void* stream, int reps,
+                          float* ms2_host) {
+    PIPS_CHECK_ARG(arena_v && workspace && ms2_host && reps > 0, "mixer_gemm_train: bad argument");
+    PIPS_CHECK_ARG(M > 0 && M % PIPS_S == 0, "mixer_gemm_train: M=%d must be a positive multiple of %d", M, PIPS_S);
+    if (workspace_bytes < pips_mixer_workspace_bytes_s(M, PIPS_S)) {
+        set_error("mixer_gemm_train: workspace %zu < %zu bytes", workspace_bytes, pips_mixer_workspace_bytes_s(M, PIPS_S));
+        return PIPS_E_WORKSPACE;
+    }
+    const int mm = (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0);
+    hipStream_t st = (hipStream_t)stream;
+    const ArenaLayout& A = arena_layout(PIPS_S);
+    const float* arena = (const float*)arena_v;
+    Bump b;
+    float* ws = (float*)workspace;
+    float* x = ws + b.take((size_t)M * PIPS_DMIX);
+    float* xn = ws + b.take((size_t)M * PIPS_DMIX);
+    float* h = ws + b.take((size_t)M * 4 * PIPS_DMIX);
+    const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
+    const unsigned short* tw = hw + A.total_h;
+    hipEvent_t ev[3];
+    for (int i = 0; i < 3; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) { set_error("hipEventCreate failed"); return PIPS_E_LAUNCH; }
+    int rc = PIPS_OK;
+    auto up = [&](int d) {
+        const MixLayerW& L = A.mix[d];
+        if (mm == 2) return pips_gemm_f32x3(xn, PIPS_DMIX, tw + A.t_w1[d], arena + L.b1, h, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX, PIPS_DMIX,
+                                            EPI_GELU, nullptr, 0, stream);
+        if (mm == 1) return gemm_h(xn, 1, PIPS_DMIX, hw + A.h_w1[d], arena + L.b1, h, 1, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX, PIPS_DMIX,
+                                   EPI_GELU, nullptr, 0, st);
+        return pips_gemm_f32(xn, PIPS_DMIX, arena + L.w1, arena + L.b1, h, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX, PIPS_DMIX, EPI_GELU,
+                             nullptr, 0, stream);
+    };
+    auto down = [&](int d) {                            // C = x (in place, like the mixer): R = x
+        const MixLayerW& L = A.mix[d];
+        if (mm == 2) return pips_gemm_f32x3(h, 4 * PIPS_DMIX, tw + A.t_w2[d], arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
+                                            EPI_RESIDUAL, x, PIPS_DMIX, stream);
+        if (mm == 1) return gemm_h(h, 1, 4 * PIPS_DMIX, hw + A.h_w2[d], arena + L.b2, x, 0, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
+                                   EPI_RESIDUAL, x, PIPS_DMIX, st);
+        return pips_gemm_f32(h, 4 * PIPS_DMIX, arena + L.w2, arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX, EPI_RESIDUAL,
+                             x, PIPS_DMIX, stream);
+    };
+    for (int d = 0; d < PIPS_DEPTH && rc == PIPS_OK; ++d) rc = up(d);                   // warm: clocks, caches
+    (void)hipEventRecord(ev[0], st);
+    for (int r = 0; r < reps && rc == PIPS_OK; ++r)
+        for (int d = 0; d < PIPS_DEPTH && rc == PIPS_OK; ++d) rc = up(d);
+    (void)hipEventRecord(ev[1], st);
+    for (int r = 0; r < reps && rc == PIPS_OK; ++r)
+        for (int d = 0; d < PIPS_DEPTH && rc == PIPS_OK; ++d) rc = down(d);
+    (void)hipEventRecord(ev[2], st);
+    if (rc == PIPS_OK && hipEventSynchronize(ev[2]) != hipSuccess) rc = PIPS_E_LAUNCH;
+    if (rc == PIPS_OK) {
+        (void)hipEventElapsedTime(&ms2_host[0], ev[0], ev[1]);
+        (void)hipEventElapsedTime(&ms2_host[1], ev[1], ev[2]);
+        ms2_host[0] /= (float)(reps * PIPS_DEPTH);
+        ms2_host[1] /= (float)(reps * PIPS_DEPTH);
+    }
+    for (int i = 0; i < 3; ++i) (void)hipEventDestroy(ev[i]);
     return rc;
 }
 

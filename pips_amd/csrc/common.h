@@ -290,10 +290,10 @@ int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st
 int launch_conv_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st, int in_bf16 = 0, int out_bf16 = 0);
 // 3x3 / 64 -> 64 channels with the weights of all taps and the tile's halo patch resident in LDS (conv_bf16_c64.hip); 1 = not taken
 int launch_conv3x3_c64_bf16(const GemmArgs& a, int frames, int* tiles_m, hipStream_t st, int in_bf16 = 0, int out_bf16 = 0);
-bool conv3x3_c64_takes(int H, int W, int frames);
+bool conv3x3_c64_takes(int H, int W, int frames);      // whether that kernel takes a 64 -> 64 3x3 layer of this size
 // 96 -> 96, 3x3, stride 1 on bf16 maps at >= 4 tiles of 256 pixels per compute unit: four-wave implicit GEMM + a statistics pass (conv_bf16_t4c.hip)
 bool conv_c96_t4_takes(const GemmArgs& a, int frames, int in_bf16, int out_bf16);
-int launch_conv_c96_t4(const GemmArgs& a, int frames, int* parts_out, hipStream_t st);      // whether that kernel takes a 64 -> 64 3x3 layer of this size
+int launch_conv_c96_t4(const GemmArgs& a, int frames, int* parts_out, hipStream_t st);
 int gemm_bf16_asm_route(const GemmArgs& a, int a_bf16, int out_bf16);   // 0 register-staged, 3 / 4 the kernels of gemm_bf16_t4.hip
 // the large-M bf16 down-projection (+ bias + fp32 residual) on 128x256 tiles, four waves, 16x16x32 MFMAs (gemm_bf16_t4.hip)
 bool gemm_bf16_t4_takes(const GemmArgs& a, int a_bf16, int out_bf16);

@@ -137,16 +137,29 @@ __global__ __launch_bounds__(256) void conv_stats_bf16_c96_kernel(const unsigned
 // and enough tiles for the blocks' tile runs to balance (>= 4 tiles per compute unit).
 bool conv_c96_t4_takes(const GemmArgs& a, int frames, int in_bf16, int out_bf16) {
     if (!PIPS_TUNE("PIPS_CONV_C96_T4", 1)) return false;
-    if (!in_bf16 || !out_bf16 || a.in_norm != nullptr || a.Cin != T4C_C || a.N != T4C_C || a.KH != 3 || a.KW != 3 || a.cstride != 1 || a.pad != 1)
+    // (the generated kernel always reads the bias through a buffer descriptor: a layer without one stays on the register-staged kernel)
+    if (!in_bf16 || !out_bf16 || a.in_norm != nullptr || a.bias == nullptr || a.Cin != T4C_C || a.N != T4C_C || a.KH != 3 || a.KW != 3 ||
+        a.cstride != 1 || a.pad != 1)
         return false;
     if (a.Ho != a.H || a.Wo != a.Win || a.Win < 3 || (unsigned long long)a.M * T4C_C * 2ull >= (1ull << 31)) return false;
+    // pixel -> image row by multiplication with ceil(2^32 / W) is exact only while (M + W) * W < 2^32
+    if ((unsigned long long)((unsigned long long)a.M + (unsigned)a.Win + 1ull) * (unsigned)a.Win >= (1ull << 32)) return false;
     const int cus = device_cus();
-    const long tiles = (long)cdiv(a.M, T4C_PIX) * frames;
+    const int ptiles = cdiv(a.M, T4C_PIX);
+    if (a.stats != nullptr) {                                              // one statistics partial per tile: a route decision, not a late error
+        const int cap = a.stats_parts_cap > 0 ? a.stats_parts_cap : 2 * cdiv(a.M, 64) + 4;
+        if (ptiles > cap) return false;
+    }
+    const long tiles = (long)ptiles * frames;
     return cus > 0 && tiles >= 4L * cus;
 }
 
 int launch_conv_c96_t4(const GemmArgs& a, int frames, int* parts_out, hipStream_t st) {
     const int tiles = cdiv(a.M, T4C_PIX), cus = device_cus();
+    if (a.stats != nullptr) {                                               // (conv_c96_t4_takes already routed such a layer away)
+        const int cap = a.stats_parts_cap > 0 ? a.stats_parts_cap : 2 * cdiv(a.M, 64) + 4;
+        PIPS_CHECK_ARG(tiles <= cap, "conv_c96_t4: %d statistics partials per frame, room for %d", tiles, cap);
+    }
     int bpf = max(1, min(tiles, cdiv(cus, frames)));                        // blocks per frame: about one block per compute unit
     static std::atomic<unsigned long long> raised{0};
     const int rc = ensure_dynamic_lds(raised, (const void*)conv3x3_c96_t4_kernel, T4C_LDS);
@@ -156,8 +169,6 @@ int launch_conv_c96_t4(const GemmArgs& a, int frames, int* parts_out, hipStream_
                        reinterpret_cast<const unsigned short*>(a.W), a.bias, reinterpret_cast<unsigned short*>(a.C), a.M, a.Win, invW, bpf, tiles);
     PIPS_CHECK_LAUNCH("conv3x3_c96_t4_kernel");
     if (a.stats != nullptr) {
-        const int cap = a.stats_parts_cap > 0 ? a.stats_parts_cap : 2 * cdiv(a.M, 64) + 4;
-        PIPS_CHECK_ARG(tiles <= cap, "conv_c96_t4: %d statistics partials per frame, room for %d", tiles, cap);
         hipLaunchKernelGGL(conv_stats_bf16_c96_kernel, dim3(frames * tiles), dim3(256), 0, st, reinterpret_cast<const unsigned short*>(a.C), a.M,
                            tiles, reinterpret_cast<float4*>(a.stats));
         PIPS_CHECK_LAUNCH("conv_stats_bf16_c96_kernel");

@@ -110,6 +110,8 @@ int conv_f32_t4_config(const GemmArgs& a, int frames) {
     else return -1;
     if (!((PIPS_TUNE("PIPS_CONV_F32_T4_MASK", 7) >> cfg) & 1)) return -1;
     if ((unsigned long long)a.M * (unsigned)max(a.Cin, a.N) * 4ull >= (1ull << 31)) return -1;
+    // pixel -> image row by multiplication with ceil(2^32 / W) is exact only while (M + W) * W < 2^32
+    if ((unsigned long long)((unsigned long long)a.M + (unsigned)a.Win + 1ull) * (unsigned)a.Win >= (1ull << 32)) return -1;
     const int cus = device_cus();
     const long tiles = (long)cdiv(a.M, px) * ncol * frames;
     if (cus <= 0 || tiles * 100 < (long)cus * PIPS_TUNE("PIPS_CONV_F32_T4_MINPCT", 250)) return -1;

@@ -37,6 +37,9 @@ def pack_more(arena, sections, S=8):
     with torch.cuda.device(arena.device):
         _lib.check(lib.pips_repack_weights_s(None, 0, _lib.ptr(arena), int(S), int(sections) & ~PACK_FP32, _stream()),
                    "pips_repack_weights_s")
+        # the arena is shared by every stream that drives the module: the new sections must be complete before another
+        # thread's stream can read them (pack_weights synchronises for the same reason)
+        torch.cuda.current_stream().synchronize()
     return arena
 
 
@@ -251,6 +254,25 @@ def mixer_fwd_timed(arena, X, flags=0):
         _lib.check(lib.pips_mixer_fwd_timed_ex(_lib.ptr(arena), _lib.ptr(X), M, flags, _lib.ptr(delta), _lib.ptr(ws), nb,
                                                _stream(), ms), "pips_mixer_fwd_timed_ex")
     return delta, {"in_proj": ms[0], "up_proj": ms[1], "down_proj": ms[2], "head": ms[3], "event_overhead": ms[4]}
+
+
+def mixer_gemm_train(arena, X, flags=0, reps=4):
+    """Profiling: a mixer pass on X, then the 12 up-projections / 12 down-projections of the pass as back-to-back launch
+    trains between ONE event pair each (pips_mixer_gemm_train).  Returns {up_proj, down_proj} milliseconds per launch,
+    start to start -- durations that tile the forward's timeline (no per-launch markers, nothing subtracted)."""
+    lib = _lib.load()
+    X = _f32(X)
+    M = X.shape[0]
+    delta = torch.empty(M // S, NOUT, dtype=torch.float32, device=X.device)
+    nb = lib.pips_mixer_workspace_bytes(M)
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
+    ms = (C.c_float * 2)()
+    with torch.cuda.device(X.device):
+        _lib.check(lib.pips_mixer_fwd_s(_lib.ptr(arena), _lib.ptr(X), M, S, flags, _lib.ptr(delta), _lib.ptr(ws), nb, _stream()),
+                   "pips_mixer_fwd_s")
+        _lib.check(lib.pips_mixer_gemm_train(_lib.ptr(arena), M, flags, _lib.ptr(ws), nb, _stream(), reps, ms),
+                   "pips_mixer_gemm_train")
+    return {"up_proj": ms[0], "down_proj": ms[1]}
 
 
 def state_update(arena, delta, ffeats, coords, coords0, B, N, stride, want_vis=False):

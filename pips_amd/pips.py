@@ -173,6 +173,8 @@ class Pips(nn.Module):
             arena = self._packed(dev)
             if self._times is None or self._times.device != dev:
                 self._times = ops.times_table(dev, self.S)
+                # shared by every stream that drives the module: complete before another thread's stream reads it
+                torch.cuda.current_stream(dev).synchronize()
             return arena, self._times
 
     # ------------------------------------------------------------------ forward

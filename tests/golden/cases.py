@@ -20,6 +20,9 @@ CASES = {
     "s4_raw_i2": dict(B=1, N=16, H=96, W=128, stride=4, iters=2, tamed=False, border=True),
     "s8_init_i2": dict(B=1, N=7, H=128, W=160, stride=8, iters=2, tamed=True, border=False, init=True),
     "demo_half_s4_i2": dict(B=1, N=16, H=180, W=320, stride=4, iters=2, tamed=True, border=False, demo=True),
+    # BASELINE configs[0] at its OWN size: the first 8 demo_images as demo.py feeds them (640x360, no resize needed),
+    # Pips(stride=4), the 4x4 grid of demo.py:32-36, I = 2
+    "demo_full_s4_i2": dict(B=1, N=16, H=360, W=640, stride=4, iters=2, tamed=True, border=False, demo="full"),
 }
 
 # Pips(S != 8): the reference sizes the token-mixing weights and the head by S (nets/pips.py:295-301, 401-402).  An odd S
@@ -37,7 +40,8 @@ def make_inputs(case: dict, seed: int = 1, S: int = 8):
     B, N, H, W = case["B"], case["N"], case["H"], case["W"]
     g = torch.Generator().manual_seed(seed)
     if case.get("demo"):
-        frames = np.load(os.path.join(HERE, "demo_half_frames.npz"))["frames"]      # (8,180,320,3) uint8
+        # (8,180,320,3) uint8, or the frames at their native (8,360,640,3)
+        frames = np.load(os.path.join(HERE, "demo_full_frames.npz" if case["demo"] == "full" else "demo_half_frames.npz"))["frames"]
         rgbs = torch.from_numpy(frames).permute(0, 3, 1, 2).float().unsqueeze(0)
         # demo.py:32-36: uniform sqrt(N) x sqrt(N) grid with an 8 px margin
         n_ = int(round(N ** 0.5))

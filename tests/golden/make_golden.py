@@ -33,6 +33,10 @@ def make_demo_frames():
     names = sorted(f for f in os.listdir(d) if f.endswith(".jpg"))[:8]
     frames = [np.asarray(Image.open(os.path.join(d, n)).convert("RGB").resize((320, 180), Image.BILINEAR)) for n in names]
     np.savez_compressed(os.path.join(HERE, "demo_half_frames.npz"), frames=np.stack(frames).astype(np.uint8))
+    # BASELINE configs[0]: the same eight frames at the size demo.py:24-27 runs them (640x360 on disk = H_, W_: its resize is the identity)
+    full = [np.asarray(Image.open(os.path.join(d, n)).convert("RGB")) for n in names]
+    assert full[0].shape == (360, 640, 3)
+    np.savez_compressed(os.path.join(HERE, "demo_full_frames.npz"), frames=np.stack(full).astype(np.uint8))
 
 
 def run_case(name, case):
@@ -93,6 +97,11 @@ def main_losses(name="s8_raw_i3"):
 
 
 if __name__ == "__main__":
+    if "--demo-full" in sys.argv:            # only BASELINE configs[0] at its own size
+        assert R.available(), "reference not mounted at /root/reference"
+        make_demo_frames()
+        run_case("demo_full_s4_i2", G.CASES["demo_full_s4_i2"])
+        sys.exit(0)
     if "--windows" in sys.argv:              # only the Pips(S != 8) fixtures
         main_windows()
         main_losses("w5_tamed_i3")

@@ -1,4 +1,6 @@
-"""The multi-rank path on real devices: clips sharded over the ranks, ONE all-gather of [x, y, vis].
+"""The multi-rank path on real devices: clips sharded over the ranks, ONE all-gather of [x, y, vis]; and the
+secondary axis for B < G -- particles sharded on replicated or frame-sharded maps (``track_sharded_particles``,
+``track_chained_sharded``).
 
 * ``test_rccl_*`` need >= 2 visible GPUs and skip on the 1-GPU gpurun box; on a multi-GPU node they are the first thing
   that sends the real ``Pips`` through ``init_process_group("nccl", device_id=...)`` (RCCL over xGMI).
@@ -51,6 +53,31 @@ def _worker(rank, world, port, backend, share_device, q):
             lo, hi = pd.shard_range(B, r, world)
             out = m(xys[lo:hi], rgbs[lo:hi], iters=3)
             ok = ok and torch.equal(out[0][-1], trajs[lo:hi]) and torch.equal(out[2], vis[lo:hi])
+        # ---- SURVEY 8(e) secondary axis (B < G): one clip, particles split over the ranks on replicated / frame-sharded maps
+        from pips_amd import drivers
+        xy1, clip = xys[:1, :23], rgbs[:1]                                  # 23 queries: padded to the world size inside
+        xp, n = pd.pad_to_world(xy1, world, dim=1)
+        cache = m.encode(clip)
+        for mode in ("replicate", "frames") if 8 % world == 0 else ("replicate",):
+            tp, vp = pd.track_sharded_particles(m, xy1, clip, iters=3, encode=mode)
+            ok = ok and tuple(tp.shape) == (1, 8, 23, 2) and tuple(vp.shape) == (1, 8, 23)
+            for r in range(world):
+                lo, hi = pd.shard_range(xp.shape[1], r, world)
+                out = m.track(cache, xp[:, lo:hi], iters=3)
+                a, b = out[0][-1][:, :, :max(min(hi, n) - lo, 0)], tp[:, :, lo:min(hi, n)]
+                # replicated maps: the shard's own single-rank result bit for bit; frame-sharded maps: encoded 8/G frames at
+                # a time (other tile shapes than the 8-frame pass), per-frame InstanceNorm keeps that to round-off
+                ok = ok and (torch.equal(a, b) if mode == "replicate" else float((a - b).abs().max()) < 1e-3)
+        # ---- the chained long-video loop, particles split over the ranks (chain_demo.py:40: one particle at a time)
+        video = torch.cat([clip, clip.flip(1)[:, :5]], dim=1)                   # T = 13
+        xy0 = xy1[:, :5] * 0.8 + 10.0
+        got = pd.track_chained_sharded(m, video, xy0, iters=3)
+        xq, nq = pd.pad_to_world(xy0, world, dim=1)
+        for r in range(world):
+            lo, hi = pd.shard_range(xq.shape[1], r, world)
+            ref = drivers.track_chained(m, video, xq[:, lo:hi], iters=3)
+            ok = ok and torch.equal(ref[:, :, :max(min(hi, nq) - lo, 0)], got[:, :, lo:min(hi, nq)])
+        ok = ok and tuple(got.shape) == (1, 13, 5, 2)
         q.put((rank, bool(ok), dist.get_backend()))
         dist.barrier()
     finally:
@@ -107,6 +134,7 @@ def test_two_ranks_share_one_gpu_gloo():
     assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res), res
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "two_ranks_one_gpu_gloo.log"), "w") as f:
-        f.write("tests/test_dist_gpu.py::test_two_ranks_share_one_gpu_gloo: 2 ranks on cuda:0, real Pips, track_sharded over gloo\n")
+        f.write("tests/test_dist_gpu.py::test_two_ranks_share_one_gpu_gloo: 2 ranks on cuda:0, real Pips, track_sharded (clips), "
+                "track_sharded_particles (replicated and frame-sharded maps) and track_chained_sharded over gloo\n")
         for r in sorted(res):
             f.write(f"rank {r[0]}: gathered == per-shard single-rank results bit for bit: {r[1]}  backend {r[2]}\n")

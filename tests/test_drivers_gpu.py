@@ -82,6 +82,32 @@ def test_chained_tracking_matches_reference_loop(weights_tamed):
     assert err < 1e-3
 
 
+def test_chained_tracking_against_reference_loop_text_golden(weights_tamed):
+    """drivers.track_chained held DIRECTLY to tests/golden/chain_t13.npz -- the output of the reference's own loop text
+    (chain_demo.py:39-83 executed verbatim with the unmodified model, tests/golden/make_chain_golden.py): same window
+    starts, same hop steps, trajectories within 1e-3 px.  (Until round 5 this was transitive: HIP = oracle = golden.)"""
+    import os
+    import numpy as np
+    from pips_amd import drivers
+    case = G.CHAIN_CASE
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(G.__file__)), "chain_t13.npz"))
+    video, xy0 = G.make_chain_inputs(case)
+    got, hops = drivers.track_chained(_model(weights_tamed, case["stride"]), video.to(DEV), xy0.to(DEV), iters=case["iters"],
+                                      return_hops=True)
+    starts = []
+    for seq in hops:                                  # the generator logged each window's first frame, particle by particle
+        cur = 0
+        for si in seq:
+            starts.append(cur)
+            cur += si
+    assert starts == gold["window_starts"].tolist()
+    assert [si for seq in hops for si in seq[:-1]] == gold["hop_steps"].tolist()
+    assert [len(seq) - 1 for seq in hops] == gold["hops_per_particle"].tolist()
+    err = float((got.cpu() - torch.from_numpy(gold["trajs_e"])).abs().max())
+    print("HIP chained tracking vs reference loop text: max |dtraj| = %.2e px" % err)
+    assert tuple(got.shape) == (1, case["T"], case["N"], 2) and err < 1e-3
+
+
 def test_skip_scan_matches_reference_scan():
     from pips_amd import drivers
     g = torch.Generator().manual_seed(0)

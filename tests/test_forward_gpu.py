@@ -481,3 +481,44 @@ def test_two_threads_two_streams_one_module(weights_tamed):
         assert len(got[i]) == 12
         for tr, vis in got[i]:
             assert torch.equal(tr, serial[i][0][-1]) and torch.equal(vis, serial[i][2])
+
+
+def test_two_threads_cold_start_and_mode_switch(weights_tamed):
+    """The same contract from a COLD module: both threads' first calls race for the packing of the fp32 arena and the frame-time
+    table, and after a switch to matmul='split' for the split planes (ops.pack_more) -- work enqueued on ONE thread's stream that
+    the other thread's stream reads; _aux / pack_more synchronise before handing the shared buffers out."""
+    import threading
+    ins = []
+    for seed in (5, 6):
+        xys, rgbs = _config2_inputs(B=1, N=32, H=128, W=160, seed=seed)
+        ins.append((xys.to(DEV), rgbs.to(DEV)))
+    ref = _model(weights_tamed, 8)
+    serial = {}
+    for mode in ("exact", "split"):
+        ref.matmul = mode
+        serial[mode] = [ref(x, r, iters=3) for x, r in ins]
+    torch.cuda.synchronize()
+    m = _model(weights_tamed, 8)                       # nothing packed yet
+    for mode in ("exact", "split"):
+        m.matmul = mode
+        got, errs, gate = [None, None], [], threading.Barrier(2)
+
+        def work(i):
+            try:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    gate.wait()
+                    out = m(ins[i][0], ins[i][1], iters=3)
+                    got[i] = (out[0][-1], out[2])
+                st.synchronize()
+            except Exception as e:
+                errs.append(e)
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs
+        for i in range(2):
+            assert torch.equal(got[i][0], serial[mode][i][0][-1]) and torch.equal(got[i][1], serial[mode][i][2]), (mode, i)
+

@@ -19,6 +19,12 @@ def _oracle():
     return O
 
 
+def _cus():
+    """compute units of the device: the route thresholds ("tiles per compute unit") are relative to it"""
+    from pips_amd import _lib
+    return _lib.load().pips_device_cus()
+
+
 def _rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
@@ -209,7 +215,7 @@ def test_conv_nhwc(F_, H, W, Cin, Cout, k, s, p):
     # fp32 accumulation over K = k*k*Cin terms (igemm_f32_kernel's order in every kernel); conv2's 3744-term sums at 5.8 M outputs reach 2.0e-6
     assert _rel_err(out.double(), ref) < (2e-6 if k * k * Cin < 2000 else 4e-6)
     px, ncol = (256, 1) if Cin == 64 else (128, 4 if Cin == 416 else 1)
-    if k == 3 and s == 1 and (Cin, Cout) in ((64, 64), (96, 96), (416, 256)) and F_ * ncol * ((H * W + px - 1) // px) >= 640:
+    if k == 3 and s == 1 and (Cin, Cout) in ((64, 64), (96, 96), (416, 256)) and F_ * ncol * ((H * W + px - 1) // px) * 2 >= 5 * _cus():
         # conv_f32_t4.hip was taken (>= 2.5 tiles per compute unit): one partial per wave (px / 4 pixels)
         assert stats.shape[1] == (H * W + px // 4 - 1) // (px // 4)
     s1, s2 = ops.partial_sums(stats.cpu())                     # (F, Cout) each
@@ -285,7 +291,7 @@ def test_conv_nhwc_bf16_maps(F_, H, W, Cin, Cout, k, s, norm, out_bf16):
     else:
         assert _rel_err(out.double(), ref) < 2e-6
     s1, s2 = ops.partial_sums(stats.cpu())
-    t4c = out_bf16 and Cin == 96 and Cout == 96 and k == 3 and s == 1 and F_ * ((H * W + 255) // 256) >= 1024
+    t4c = out_bf16 and Cin == 96 and Cout == 96 and k == 3 and s == 1 and F_ * ((H * W + 255) // 256) >= 4 * _cus()
     if t4c:
         # conv_bf16_t4c.hip: the statistics are those of the STORED bf16 map (what autocast's instance_norm sees)
         assert _rel_err(s1, out.double().sum(dim=(1, 2))) < 1e-5
@@ -294,6 +300,23 @@ def test_conv_nhwc_bf16_maps(F_, H, W, Cin, Cout, k, s, norm, out_bf16):
     else:
         assert _rel_err(s1, ref.sum(dim=(1, 2))) < 1e-5            # statistics come from the fp32 accumulators
         assert _rel_err(s2, (ref * ref).sum(dim=(1, 2))) < 1e-5
+
+
+def test_conv_nhwc_bf16_maps_without_bias():
+    """pips_conv_nhwc_bf16_maps documents bias as '[N] or null'.  The four-wave 96 -> 96 kernel always reads a bias through a
+    buffer descriptor, so a layer without one must stay on the register-staged kernel (conv_c96_t4_takes) -- at the shape
+    that otherwise takes the four-wave route, and with a statistics capacity that only suits the generic kernel's partition."""
+    from pips_amd import ops
+    F_, H, W, Cc = 24, 92, 124, 96
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(F_, H, W, Cc, generator=g) * 1.5 + 0.3).bfloat16()
+    w = (torch.randn(Cc, 3, 3, Cc, generator=g) / math.sqrt(Cc * 9)).bfloat16()
+    out, stats = ops.conv_nhwc_bf16_maps(x.to(DEV), w.to(DEV), None, 3, 1, 1, out_bf16=True, want_stats=True)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None, stride=1, padding=1).permute(0, 2, 3, 1)
+    err = (out.cpu().double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-5).all()), float((err / (ref.abs() + 1e-3)).max())
+    s1, s2 = ops.partial_sums(stats.cpu())
+    assert _rel_err(s1, ref.sum(dim=(1, 2))) < 1e-5 and _rel_err(s2, (ref * ref).sum(dim=(1, 2))) < 1e-5   # fp32 accumulators: generic kernel
 
 
 # ----------------------------------------------------------------------------- encoder
