@@ -223,6 +223,20 @@ int    pips_mixer_input_build_tiled_timed(const float* pyramid, int B, int S, in
                                           const float* ffeats, const float* coords, const float* times,
                                           int N, float* X, void* scratch, size_t scratch_bytes, void* stream,
                                           float* ms3_host);
+/* The same with flags.  PIPS_FLAG_BF16_MAPS: the bf16 mode of a dense query set -- under torch.autocast the reference correlates
+ * bf16 features with bf16 maps (nets/pips.py:394-397), so the work items of the tiled path run on the matrix cores
+ * (gather_mfma_kernel: the tile's region of the pyramid's bf16 MIRROR times all of the item's particles' features, rounded to
+ * bf16, as v_mfma_f32_32x32x16_bf16 products with fp32 sums; each particle keeps its 8 x 8 window; same blend, same taps).
+ * pips_forward / pips_track take this route by themselves when PIPS_FLAG_BF16_MAPS is set and the query set is dense.
+ * ms3_host != NULL: as the _timed form ({bin_particles, embed_rows, gather} ms; synchronises the stream). */
+/* Which correlation-gather kernel pips_forward / pips_track (8 frames per clip, no per-particle windows) run for this query set:
+ * 0 = the direct kernel (mixer_input_kernel, or mixer_input_bf16maps_kernel with PIPS_FLAG_BF16_MAPS), 1 = gather_tiled_kernel
+ * (fp32, LDS-tiled), 2 = gather_mfma_kernel (PIPS_FLAG_BF16_MAPS on a dense query set).  Host function; needs a current device. */
+int    pips_gather_route(int B, int N, int H8, int W8, int flags);
+int    pips_mixer_input_build_tiled_ex(const float* pyramid, int B, int S, int H8, int W8,
+                                       const float* ffeats, const float* coords, const float* times,
+                                       int N, int flags, float* X, void* scratch, size_t scratch_bytes,
+                                       void* stream, float* ms3_host);
 
 /* MLPMixer (nets/pips.py:111-123): X (M,544) -> delta (M/8, 1040).  M = B*N*8. */
 size_t pips_mixer_workspace_bytes(int M);

@@ -61,6 +61,9 @@ SIGNATURES = {
                                              c_void_p]),
     "pips_mixer_input_build_tiled_timed": (c_int, [fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, fp, c_void_p,
                                                    c_size_t, c_void_p, C.POINTER(c_float)]),
+    "pips_gather_route": (c_int, [c_int] * 5),
+    "pips_mixer_input_build_tiled_ex": (c_int, [fp, c_int, c_int, c_int, c_int, fp, fp, fp, c_int, c_int, fp, c_void_p, c_size_t,
+                                                c_void_p, C.POINTER(c_float)]),
     "pips_mixer_workspace_bytes": (c_size_t, [c_int]),
     "pips_mixer_fwd": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),
     "pips_mixer_fwd_bf16": (c_int, [c_void_p, fp, c_int, fp, c_void_p, c_size_t, c_void_p]),

@@ -699,8 +699,9 @@ static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const
     const bool can_tile = scratch != nullptr && win_start == nullptr && S == PIPS_S && Sw == PIPS_S &&
                           scratch_bytes >= tiled_gather_scratch_bytes(B, N, H8, W8);
     const bool tiled = force_tiled >= 0 ? (force_tiled != 0) : tiled_gather_wanted(B, N, H8, W8);
-    if (tiled && can_tile)
-        return launch_mixer_input_tiled(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, scratch, scratch_bytes, st, ev);
+    if (tiled && can_tile)      // (bf16 mode: the same work items on the matrix cores, reading the bf16 mirror behind the fp32 levels)
+        return launch_mixer_input_tiled(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, scratch, scratch_bytes, st, ev,
+                                        bf16_maps ? reinterpret_cast<const unsigned short*>(pyramid + o) : nullptr);
     PIPS_CHECK_ARG(force_tiled != 1, "tiled gather needs scratch of %zu bytes, no win_start and 8 frames per clip",
                    tiled_gather_scratch_bytes(B, N, H8, W8));
     if (bf16_maps) return launch_mixer_input_bf16maps(pyramid + o, off, lh, lw, B, S, ffeats, coords, times, N, win_start, X, st, Sw);
@@ -746,6 +747,33 @@ int pips_mixer_input_build_tiled_timed(const float* pyramid, int B, int S, int H
         if (hipEventCreate(&ev[i]) != hipSuccess) { set_error("hipEventCreate failed"); return PIPS_E_LAUNCH; }
     int rc = mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, nullptr, X, (hipStream_t)stream, scratch,
                          scratch_bytes, 1, ev);
+    if (rc == PIPS_OK && hipEventSynchronize(ev[3]) != hipSuccess) rc = PIPS_E_LAUNCH;
+    if (rc == PIPS_OK)
+        for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms3_host[i], ev[i], ev[i + 1]);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
+int pips_gather_route(int B, int N, int H8, int W8, int flags) {
+    if (B <= 0 || N <= 0 || H8 <= 0 || W8 <= 0) return 0;
+    if (!tiled_gather_wanted(B, N, H8, W8)) return 0;
+    return (flags & PIPS_FLAG_BF16_MAPS) ? 2 : 1;
+}
+
+int pips_mixer_input_build_tiled_ex(const float* pyramid, int B, int S, int H8, int W8, const float* ffeats, const float* coords,
+                                    const float* times, int N, int flags, float* X, void* scratch, size_t scratch_bytes,
+                                    void* stream, float* ms3_host) {
+    PIPS_CHECK_ARG(pyramid && ffeats && coords && times && X && scratch, "mixer_input_tiled: null pointer");
+    PIPS_CHECK_ARG(S == PIPS_S && B > 0 && N > 0, "mixer_input_tiled: S must be %d", PIPS_S);
+    const bool bf16_maps = (flags & PIPS_FLAG_BF16_MAPS) != 0;
+    if (ms3_host == nullptr)
+        return mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, nullptr, X, (hipStream_t)stream, scratch, scratch_bytes, 1,
+                           nullptr, PIPS_S, bf16_maps);
+    hipEvent_t ev[4];
+    for (int i = 0; i < 4; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) { set_error("hipEventCreate failed"); return PIPS_E_LAUNCH; }
+    int rc = mixer_input(pyramid, B, S, H8, W8, ffeats, coords, times, N, nullptr, X, (hipStream_t)stream, scratch, scratch_bytes, 1,
+                         ev, PIPS_S, bf16_maps);
     if (rc == PIPS_OK && hipEventSynchronize(ev[3]) != hipSuccess) rc = PIPS_E_LAUNCH;
     if (rc == PIPS_OK)
         for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms3_host[i], ev[i], ev[i + 1]);

@@ -379,7 +379,8 @@ bool tiled_gather_wanted(int B, int N, int H8, int W8);
 // ev != null: 4 events recorded around the three launches (bin, embed, gather)
 int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B,
                              int S, const float* ffeats, const float* coords, const float* times, int N,
-                             float* X, void* scratch, size_t scratch_bytes, hipStream_t st, hipEvent_t* ev = nullptr);
+                             float* X, void* scratch, size_t scratch_bytes, hipStream_t st, hipEvent_t* ev = nullptr,
+                             const unsigned short* mirror = nullptr);   // mirror: the bf16 mode's matrix-core kernel on the pyramid's bf16 mirror
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
                      hipStream_t st, int xn_bf16 = 0, int Sw = PIPS_S);
 int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,

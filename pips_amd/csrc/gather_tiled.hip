@@ -503,6 +503,201 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------- tiled gather on the bf16 mirror (matrix cores)
+// The bf16 mode of the same work items (PIPS_FLAG_BF16_MAPS + a dense query set).  Under torch.autocast the reference
+// correlates bf16 operands (`torch.matmul(fmap1, fmap2s)`, nets/pips.py:394-397: BOTH the track features and the maps are cast
+// to bf16), so the faithful arithmetic is a bf16 x bf16 -> fp32 product -- which is the matrix cores' native form, 16x the
+// rate of the vector ALUs' fp32 FMAs.  That changes the right formulation: instead of lane = window pixel with one FMA chain
+// per (particle, level, pixel) out of LDS fragments (gather_tiled_kernel: 4 B of LDS traffic per FMA, bound by LDS -> VGPR
+// bandwidth), the tile's region is multiplied against ALL of the item's particles,
+//        D[region pixel][particle] = sum_c map[pixel][c] * feat[particle][c]        (v_mfma_f32_32x32x16_bf16)
+// -- CorrBlock.corr restricted to the tile -- and each particle then keeps the 8 x 8 window it needs.  The products outside the
+// windows are redundant (x 3.5 at level 0 ... x 1.5 at level 3) and still cost less than a tenth of the vector-ALU form.
+//   * one block (6 waves) per work item; two blocks per compute unit, so one block's staging overlaps the other's products;
+//   * B operand (features): wave = (particle block pb of 32, pixel-block group): the lane's 8 x 16-byte fragments of ITS particle
+//     are converted fp32 -> bf16 (RNE) once per item and stay in registers;
+//   * A operand (maps): the region is cut into PIXEL BLOCKS of 8 x 4 pixels (= the 32 rows of one MFMA); a chunk of four blocks
+//     (32 KiB: all 128 channels) is staged global -> registers -> LDS, the next chunk's loads in flight under this chunk's
+//     products; 256-byte rows with the 16-byte chunk index XORed with (row & 15): fragment reads and staging writes are
+//     conflict-free; slots outside the region are staged as zeros;
+//   * the accumulator layout does the window test almost for free: a lane holds, for ITS particle (column), the 4 x 4 pixels
+//     x = 4 half + (r & 3), y = r >> 2 of the block, so the window coordinate of register r is (dx0 + (r & 3), dy0 + (r >> 2)) with
+//     ONE (dx0, dy0) per lane and block, the target address in the per-level window buffer win[particle][8][8] (+1 float of
+//     padding per particle: the 32 lanes of a write are 32 particles) is one base +
+//     immediates, and the validity of a value is the AND of an x- and a y-compare: 16 masked ds_write_b32 per block;
+//   * per level: win zeroed (zeros padding outside the map, nets/pips.py:324), chunks, then the 2 x 2 blend of the 8 x 8
+//     correlations to the 49 taps in the reference's transposed order (k = ix * 7 + iy, :379-381) -- the same weights, scaling
+//     and operation order as gather_tiled_kernel's epilogue -- and coalesced 49-float stores into X.
+constexpr int GM_WAVES = 6, GM_THREADS = GM_WAVES * 64;
+constexpr int GM_PB = GMAX / 32;                  // particle blocks per item
+constexpr int GM_GROUPS = GM_WAVES / GM_PB;       // wave groups sharing a chunk's pixel blocks
+constexpr int GM_CHUNK = 4;                       // pixel blocks per stage
+constexpr int GM_BLK_BYTES = 32 * C * 2;          // 8 KiB: 32 pixels x 128 channels bf16
+constexpr int GM_STAGE = GM_CHUNK * GM_BLK_BYTES;
+constexpr int GM_WIN_OFF = GM_STAGE + 128;        // (the scatter's per-lane base may lie up to 108 bytes below a particle's window)
+constexpr int GM_WIN_ROW = 65;                    // floats per particle window: 64 + 1, so that the 32 particles (lanes) of a scatter hit 32 banks
+constexpr int GM_WIN_BYTES = GMAX * GM_WIN_ROW * 4;
+constexpr int GM_REC_OFF = GM_WIN_OFF + GM_WIN_BYTES;
+constexpr int GM_ENT_OFF = GM_REC_OFF + GMAX * PIPS_LEVELS * 16;
+constexpr int GM_LDS = GM_ENT_OFF + 16;
+constexpr int GM_PIECES = (GM_CHUNK * 32 * 16 + GM_THREADS - 1) / GM_THREADS;      // 16-byte pieces per thread and chunk (6)
+static_assert(GM_PB * GM_GROUPS == GM_WAVES && GM_CHUNK % GM_GROUPS == 0, "wave <-> (particle block, pixel-block group)");
+static_assert(GM_THREADS == GMAX * PIPS_LEVELS, "one record per thread");
+static_assert(GM_LDS <= 64 * 1024 && GM_WIN_BYTES % 16 == 0 && GM_WIN_OFF % 16 == 0, "two blocks per compute unit; float4 zeroing");
+
+typedef __bf16 bf16x8_gm __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(GM_THREADS, 3) void gather_mfma_kernel(const unsigned short* __restrict__ mirror, TiledLevels lv,
+                                                                 const float* __restrict__ ffeats, int N, int max_items, int F,
+                                                                 const int4* __restrict__ order, const int4* __restrict__ items,
+                                                                 const int* __restrict__ nitems, int tiles_x,
+                                                                 float* __restrict__ X) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = wave % GM_PB, grp = wave / GM_PB;
+    const int xcd = blockIdx.x & 7, J = gridDim.x >> 3, jb = blockIdx.x >> 3;
+    int4* rec = reinterpret_cast<int4*>(smem + GM_REC_OFF);
+    int4* ent = reinterpret_cast<int4*>(smem + GM_ENT_OFF);
+    const int jme = pb * 32 + l31;                                   // this lane's particle (MFMA column) within the item
+    for (int it = 0;; ++it) {
+        // ---- this block's next work item: entry jb + it * J of the XCD's list (frames xcd, xcd + 8, ... one after another)
+        __syncthreads();                                             // (the previous item's blend is done with rec / win / ent)
+        if (tid == 0) {
+            int gi = jb + it * J, fr = xcd;
+            int4 e = make_int4(0, 0, 0, -1);
+            for (; fr < F; fr += 8) {
+                const int n = nitems[fr];
+                if (gi < n) break;
+                gi -= n;
+            }
+            if (fr < F) { e = items[(size_t)fr * max_items + gi]; e.w = fr; }
+            *ent = e;
+        }
+        __syncthreads();
+        const int4 ev = *ent;
+        const int tile = __builtin_amdgcn_readfirstlane(ev.x), first = __builtin_amdgcn_readfirstlane(ev.y),
+                  count = __builtin_amdgcn_readfirstlane(ev.z), f = __builtin_amdgcn_readfirstlane(ev.w);
+        if (f < 0) break;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        // ---- records: thread 4 j + l holds (particle j, level l); slots past the item's particles get a far-away anchor
+        {
+            const int j = tid >> 2;
+            int4 r = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);
+            if (j < count) r = order[((size_t)f * N + first) * PIPS_LEVELS + tid];
+            rec[tid] = r;
+        }
+        // ---- B operand: the lane's particle's features as 8 MFMA fragments (channels 16 ks + 8 half ... + 8), fp32 -> bf16 RNE
+        uint4 bfr[8];
+        {
+            int m = -1;
+            if (jme < count) m = order[((size_t)f * N + first + jme) * PIPS_LEVELS].w;
+            const float* fp = ffeats + (size_t)max(m, 0) * C + half * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float4 a = *reinterpret_cast<const float4*>(fp + ks * 16), b = *reinterpret_cast<const float4*>(fp + ks * 16 + 4);
+                bfr[ks] = m >= 0 ? make_uint4(pack2_bf16(a.x, a.y), pack2_bf16(a.z, a.w), pack2_bf16(b.x, b.y), pack2_bf16(b.z, b.w))
+                                 : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        const bool active = pb * 32 < count;                         // (wave-uniform) this wave's particle block holds particles
+#pragma unroll
+        for (int l = 0; l < PIPS_LEVELS; ++l) {
+            // ---- the level's staged region: the same rectangle as lane_geom() (window reach of every particle binned into the tile)
+            const int Wl = lv.W[l], Hl = lv.H[l];
+            const int Tx = (tx * TS) >> l, Ty = (ty * TS) >> l, w = TS >> l, h = l == 0 ? 3 : 4;
+            int x0 = max(Tx - h, 0), y0 = max(Ty - h, 0);
+            const int x1 = min(Tx + w + h, Wl - 1), y1 = min(Ty + w + h, Hl - 1);
+            int RW = max(x1 - x0 + 1, 1), RH = max(y1 - y0 + 1, 1);
+            if (x1 < x0 || y1 < y0) { x0 = y0 = 0; RW = RH = 1; }   // (tile beyond this level's map)
+            const int nbx = (RW + 7) >> 3, nby = (RH + 3) >> 2, nblk = nbx * nby;
+            const unsigned inv_nbx = (65536u + (unsigned)nbx - 1u) / (unsigned)nbx;           // block -> block row: exact for < 256 blocks
+            const unsigned short* mp = mirror + lv.off[l] + (size_t)f * Hl * Wl * C;
+            __syncthreads();                                         // records in LDS (first level) / the previous level's blend has read win
+            int bxr, byr;                                            // this lane's particle's window anchor in region coordinates
+            {
+                const int rx_ = rec[jme * PIPS_LEVELS + l].x;
+                bxr = (int)(short)(rx_ & 0xffff) - x0;
+                byr = (rx_ >> 16) - y0;
+            }
+            for (int k = tid; k < GM_WIN_BYTES / 16; k += GM_THREADS)
+                reinterpret_cast<float4*>(smem + GM_WIN_OFF)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint4 pre[GM_PIECES];
+            auto prefetch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < GM_PIECES; ++k) {
+                    const int q = tid + k * GM_THREADS;              // piece: pixel block q >> 9, row (q >> 4) & 31, 16-byte chunk q & 15
+                    const int gb = c0 + (q >> 9), i = (q >> 4) & 31, c = q & 15;
+                    const int byi = (int)(((unsigned)gb * inv_nbx) >> 16), bxi = gb - byi * nbx;
+                    const int rx = bxi * 8 + (i & 7), ry = byi * 4 + (i >> 3);
+                    const bool ok = q < GM_CHUNK * 512 && gb < nblk && rx < RW && ry < RH;
+                    // (clamped: always a valid address; a frame's level is < 4 GiB: 32-bit byte offset from a scalar base)
+                    const unsigned so = (unsigned)((y0 + min(ry, RH - 1)) * Wl + x0 + min(rx, RW - 1)) * (unsigned)(C * 2) + (unsigned)(c * 16);
+                    const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(mp) + so);
+                    pre[k] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+                }
+            };
+            prefetch(0);
+            for (int c0 = 0; c0 < nblk; c0 += GM_CHUNK) {
+                __syncthreads();                                     // the stage is free (and, first chunk, win is zeroed)
+#pragma unroll
+                for (int k = 0; k < GM_PIECES; ++k) {
+                    const int q = tid + k * GM_THREADS;
+                    const int i = (q >> 4) & 31, c = q & 15;
+                    if (q < GM_CHUNK * 512)
+                        *reinterpret_cast<uint4*>(smem + (q >> 9) * GM_BLK_BYTES + i * 256 + ((c ^ (i & 15)) << 4)) = pre[k];
+                }
+                __syncthreads();
+                if (c0 + GM_CHUNK < nblk) prefetch(c0 + GM_CHUNK);
+                asm volatile("" ::: "memory");                       // keep the next chunk's loads ahead of the products
+                if (active) {
+#pragma unroll
+                    for (int b2 = 0; b2 < GM_CHUNK / GM_GROUPS; ++b2) {
+                        const int bl = grp + b2 * GM_GROUPS, gb = c0 + bl;
+                        if (gb >= nblk) break;
+                        f32x16 acc;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                        const char* ap = smem + bl * GM_BLK_BYTES + l31 * 256;
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks) {
+                            const uint4 a = *reinterpret_cast<const uint4*>(ap + (((ks * 2 + half) ^ (l31 & 15)) << 4));
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_gm*>(&a),
+                                                                          *reinterpret_cast<const bf16x8_gm*>(&bfr[ks]), acc, 0, 0, 0);
+                        }
+                        const int byi = (int)(((unsigned)gb * inv_nbx) >> 16), bxi = gb - byi * nbx;
+                        const int dx0 = bxi * 8 + 4 * half - bxr, dy0 = byi * 4 - byr;
+                        char* wb = smem + GM_WIN_OFF + jme * (GM_WIN_ROW * 4) + dy0 * 32 + dx0 * 4;
+#pragma unroll
+                        for (int y = 0; y < 4; ++y)
+#pragma unroll
+                            for (int x = 0; x < 4; ++x)
+                                if ((unsigned)(dx0 + x) < 8u && (unsigned)(dy0 + y) < 8u)
+                                    *reinterpret_cast<float*>(wb + y * 32 + x * 4) = acc[y * 4 + x];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- 2x2 blend of the 8x8 correlations to the 49 taps, k = ix*7 + iy (transposed, nets/pips.py:379-381)
+            const float* winf = reinterpret_cast<const float*>(smem + GM_WIN_OFF);
+            for (int idx = tid; idx < count * PIPS_NCORR; idx += GM_THREADS) {
+                const int j = idx / PIPS_NCORR, t = idx - j * PIPS_NCORR;
+                const int ti = t / 7, tj = t - ti * 7;
+                const int4 r = rec[j * PIPS_LEVELS + l];
+                const float wx = __int_as_float(r.y), wy = __int_as_float(r.z);
+                const float* wv = winf + j * GM_WIN_ROW + tj * 8 + ti;
+                const float e = 1.0f - wx, so = 1.0f - wy;
+                const float k128 = 0.08838834764831845f;                                  // the 1/sqrt(128) of :397 rides on the weights
+                const float w0 = __fmul_rn(__fmul_rn(so, e), k128), w1 = __fmul_rn(__fmul_rn(so, wx), k128),
+                            w2 = __fmul_rn(__fmul_rn(wy, e), k128), w3 = __fmul_rn(__fmul_rn(wy, wx), k128);
+                float o = __fmul_rn(w0, wv[0]);
+                o = fmaf(w1, wv[1], o); o = fmaf(w2, wv[8], o); o = fmaf(w3, wv[9], o);
+                X[(size_t)r.w * PIPS_KIN_PAD + C + PIPS_NCORR * l + t] = o;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------- host side
 static int tiled_max_items(int N, int H8, int W8) { return cdiv(W8, TS) * cdiv(H8, TS) + N / GMAX + 1; }
 
@@ -533,9 +728,12 @@ bool tiled_gather_wanted(int B, int N, int H8, int W8) {
     return (long)N >= 16L * cdiv(W8, TS) * cdiv(H8, TS) && N >= 1024;
 }
 
+// mirror != nullptr: the bf16 mode -- the work items run on gather_mfma_kernel, which reads the pyramid's bf16 mirror (element
+// offsets of the fp32 levels) and needs no tile tables
 int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B,
                              int S_, const float* ffeats, const float* coords, const float* times, int N,
-                             float* X, void* scratch, size_t scratch_bytes, hipStream_t st, hipEvent_t* ev) {
+                             float* X, void* scratch, size_t scratch_bytes, hipStream_t st, hipEvent_t* ev,
+                             const unsigned short* mirror) {
     const int F = B * S, H8 = lvlH[0], W8 = lvlW[0];
     PIPS_CHECK_ARG(S_ == S, "tiled gather: the map buffer must hold %d frames per clip", S);
     if (scratch_bytes < tiled_gather_scratch_bytes(B, N, H8, W8)) {
@@ -566,8 +764,10 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     hipLaunchKernelGGL(bin_particles_kernel, dim3(F), dim3(1024), bin_lds, st, coords, N, lv, tiles_x, tiles_y, max_items,
                        order, items, nitems);
     PIPS_CHECK_LAUNCH("bin_particles_kernel");
-    hipLaunchKernelGGL(tile_table_kernel, dim3(ntiles), dim3(NW * 64), 0, st, lv, tiles_x, gpk_tab, doff_tab);
-    PIPS_CHECK_LAUNCH("tile_table_kernel");
+    if (mirror == nullptr) {
+        hipLaunchKernelGGL(tile_table_kernel, dim3(ntiles), dim3(NW * 64), 0, st, lv, tiles_x, gpk_tab, doff_tab);
+        PIPS_CHECK_LAUNCH("tile_table_kernel");
+    }
     const int M = B * N * S;
     if (ev) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(embed_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ffeats, coords, times, M, X);
@@ -585,6 +785,13 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     }
     const int grid = max(cus / 8, 1) * 8;
     if (ev) (void)hipEventRecord(ev[2], st);
+    if (mirror != nullptr) {                     // two blocks of six waves per compute unit
+        hipLaunchKernelGGL(gather_mfma_kernel, dim3(2 * grid), dim3(GM_THREADS), GM_LDS, st, mirror, lv, ffeats, N, max_items, F,
+                           order, items, nitems, tiles_x, X);
+        if (ev) (void)hipEventRecord(ev[3], st);
+        PIPS_CHECK_LAUNCH("gather_mfma_kernel");
+        return PIPS_OK;
+    }
     hipLaunchKernelGGL(gather_tiled_kernel, dim3(grid), dim3(NW * 64), LDS_BYTES_V3, st, pyramid, fs, S_, ffeats,
                        N, max_items, F, order, items, nitems, gpk_tab, doff_tab, X);
     if (ev) (void)hipEventRecord(ev[3], st);

@@ -163,8 +163,10 @@ def pyramid_mirror(pyr, F, H, W, stride):
     return pyr
 
 
-def mixer_input_build_tiled(pyr, B, H8, W8, ffeats, coords, out=None):
-    """Same as mixer_input_build through the LDS-tiled kernel for dense query sets."""
+def mixer_input_build_tiled(pyr, B, H8, W8, ffeats, coords, out=None, bf16_maps=False):
+    """Same as mixer_input_build through the tiled kernels for dense query sets.  bf16_maps: the bf16 mode's matrix-core kernel on
+    the bf16 mirror behind the fp32 levels of ``pyr`` (PIPS_FLAG_BF16_MAPS; features rounded to bf16 as well, like the
+    reference under autocast)."""
     lib = _lib.load()
     ffeats, coords = _f32(ffeats), _f32(coords)
     M = ffeats.shape[0]
@@ -174,13 +176,13 @@ def mixer_input_build_tiled(pyr, B, H8, W8, ffeats, coords, out=None):
     nb = lib.pips_gather_scratch_bytes(B, N, H8, W8)
     scratch = torch.empty(nb, dtype=torch.uint8, device=ffeats.device)
     with torch.cuda.device(ffeats.device):
-        _lib.check(lib.pips_mixer_input_build_tiled(_lib.ptr(pyr), B, S, H8, W8, _lib.ptr(ffeats), _lib.ptr(coords),
-                                                    _lib.ptr(tt), N, _lib.ptr(X), _lib.ptr(scratch), nb, _stream()),
-                   "pips_mixer_input_build_tiled")
+        _lib.check(lib.pips_mixer_input_build_tiled_ex(_lib.ptr(pyr), B, S, H8, W8, _lib.ptr(ffeats), _lib.ptr(coords),
+                                                       _lib.ptr(tt), N, 32 if bf16_maps else 0, _lib.ptr(X), _lib.ptr(scratch), nb,
+                                                       _stream(), None), "pips_mixer_input_build_tiled_ex")
     return X
 
 
-def mixer_input_build_tiled_timed(pyr, B, H8, W8, ffeats, coords):
+def mixer_input_build_tiled_timed(pyr, B, H8, W8, ffeats, coords, bf16_maps=False):
     """(X, {"bin": ms, "embed": ms, "gather": ms}): HIP-event durations of the three launches of the tiled path."""
     lib = _lib.load()
     ffeats, coords = _f32(ffeats), _f32(coords)
@@ -192,9 +194,9 @@ def mixer_input_build_tiled_timed(pyr, B, H8, W8, ffeats, coords):
     scratch = torch.empty(nb, dtype=torch.uint8, device=ffeats.device)
     ms = (C.c_float * 3)()
     with torch.cuda.device(ffeats.device):
-        _lib.check(lib.pips_mixer_input_build_tiled_timed(_lib.ptr(pyr), B, S, H8, W8, _lib.ptr(ffeats), _lib.ptr(coords),
-                                                          _lib.ptr(tt), N, _lib.ptr(X), _lib.ptr(scratch), nb, _stream(), ms),
-                   "pips_mixer_input_build_tiled_timed")
+        _lib.check(lib.pips_mixer_input_build_tiled_ex(_lib.ptr(pyr), B, S, H8, W8, _lib.ptr(ffeats), _lib.ptr(coords),
+                                                       _lib.ptr(tt), N, 32 if bf16_maps else 0, _lib.ptr(X), _lib.ptr(scratch), nb,
+                                                       _stream(), ms), "pips_mixer_input_build_tiled_ex")
     return X, {"bin": ms[0], "embed": ms[1], "gather": ms[2]}
 
 

@@ -62,6 +62,81 @@ def test_config4_gather_direct_and_tiled_vs_oracle():
     assert torch.equal(Xd[:, :128], Xt[:, :128]) and torch.equal(Xd[:, 324:], Xt[:, 324:])
 
 
+def test_config4_gather_bf16_matrix_cores_vs_oracle():
+    """The bf16 mode at config-4 geometry (90x160 maps, the 64x64 grid + jitter): gather_mfma_kernel against the oracle's
+    CorrBlock on bf16-rounded maps and features in fp64, all 4096 x 8 x 196 taps, and against the direct bf16-map kernel."""
+    from pips_amd import ops, _lib
+    from oracle import pips_oracle as O
+    lib = _lib.load()
+    B, H8, W8, N = 1, 90, 160, 4096
+    assert lib.pips_gather_route(B, N, H8, W8, 32) == 2 and lib.pips_gather_route(B, N, H8, W8, 0) == 1
+    assert lib.pips_gather_route(1, 256, 46, 62, 32) == 0                  # BASELINE configs[2]: sparse, the direct kernel
+    g = torch.Generator().manual_seed(22)
+    fmaps = torch.randn(B, 8, 128, H8, W8, generator=g)
+    ffeats = torch.randn(B, 8, N, 128, generator=g)
+    coords = (_grid(N, H8 * 8, W8 * 8) / 8.0).reshape(1, 1, N, 2).repeat(B, 8, 1, 1) + torch.randn(B, 8, N, 2, generator=g) * 1.5
+    coords[0, :, 0] = torch.tensor([-6.0, 3.0])
+    coords[0, :, 1] = torch.tensor([W8 + 40.0, H8 + 2.0])
+    coords[0, :, 2] = torch.tensor([31.999998, 16.0])
+    coords[0, :, 3] = torch.tensor([16.0, 47.999996])
+    pyr_ref = O.build_pyramid(fmaps)
+    pyr_bf = [p.bfloat16().double() for p in pyr_ref]
+    ffb = ffeats.bfloat16().double()
+    ref = torch.cat([O.corr_sample(pyr_bf, ffb[:, :, n0:n0 + 256], coords[:, :, n0:n0 + 256].double())
+                     for n0 in range(0, N, 256)], dim=2)
+    buf = torch.zeros(lib.pips_pyramid_floats(B * 8, H8 * 8, W8 * 8, 8))
+    for l, p in enumerate(pyr_ref):
+        off = lib.pips_pyramid_offset(B * 8, H8 * 8, W8 * 8, 8, l)
+        buf[off:off + p.numel()] = p.reshape(B * 8, 128, p.shape[-2], p.shape[-1]).permute(0, 2, 3, 1).reshape(-1)
+    pyr = ops.pyramid_mirror(buf.to(DEV), B * 8, H8 * 8, W8 * 8, 8)
+    ff, co = _pm(ffeats).to(DEV), _pm(coords).to(DEV)
+    Xm = ops.mixer_input_build_tiled(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu()
+    Xd = ops.mixer_input_build(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu()
+    err = float((Xm[:, 128:324].double() - _pm(ref)).abs().max())
+    dd = float((Xm[:, 128:324] - Xd[:, 128:324]).abs().max())
+    print(f"config-4 geometry, bf16 mode: matrix-core gather vs fp64 oracle on bf16 operands {err:.2e}, vs the direct bf16-map kernel {dd:.2e}")
+    assert err < 1.5e-4 and dd < 0.2        # (sample positions are fp32 here, fp64 in the yardstick: ~5e-5 at 160-pixel-wide maps)
+    assert torch.equal(Xm[8:16, 128:324], torch.zeros(8, 196))
+    assert torch.equal(Xd[:, :128], Xm[:, :128]) and torch.equal(Xd[:, 324:], Xm[:, 324:])
+
+
+def test_config4_geometry_bf16_mode_end_to_end_against_autocast_oracle(weights_tamed):
+    """The bf16 mode x dense grid combination of the product path, compared for the first time (round 5): one clip of 8 x 720x1280
+    frames, the 64x64 grid, I=6, ``torch.autocast`` around the module -> bf16 encoder, bf16 mixer, and the correlation gather on
+    the matrix cores (pips_gather_route = 2).  Against the oracle on the same GPU under ``torch.autocast("cuda", bfloat16)`` (the way
+    the reference itself would be run in bf16) and against its fp32 run: the config-3 gate, 2e-2 px on tamed weights."""
+    from pips_amd import Pips, _lib
+    from oracle import pips_oracle as O
+    B, H, W, N = 1, 720, 1280, 4096
+    assert _lib.load().pips_gather_route(B, N, H // 8, W // 8, 32) == 2
+    g = torch.Generator().manual_seed(6)
+    rgbs = torch.randint(0, 256, (B, 8, 3, H, W), generator=g).float().to(DEV)
+    xys = (_grid(N, H, W).unsqueeze(0) + torch.rand(B, N, 2, generator=g) * 4.0).to(DEV)
+    sd = {k: v.to(DEV) for k, v in weights_tamed.items()}
+    with torch.no_grad():
+        ref32 = [p.cpu() for p in O.forward(sd, xys, rgbs, iters=6, stride=8)[0]]
+        torch.cuda.empty_cache()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = O.forward(sd, xys, rgbs, iters=6, stride=8)
+        refbf, visbf = [p.float().cpu() for p in out[0]], out[2].float().cpu()
+    del sd, out
+    torch.cuda.empty_cache()
+    m = Pips(stride=8)
+    m.load_state_dict(weights_tamed)
+    m = m.to(DEV).eval()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        preds, _, vis, _ = m(xys, rgbs, iters=6)
+    preds = [p.cpu() for p in preds]
+    assert all(torch.isfinite(p).all() for p in preds)
+    e_bf = max(float((p - r).abs().max()) for p, r in zip(preds, refbf))
+    e_32 = max(float((p - r).abs().max()) for p, r in zip(preds, ref32))
+    e_ref = max(float((a - b).abs().max()) for a, b in zip(refbf, ref32))
+    e_vis = float((vis.cpu() - visbf).abs().max())
+    print(f"config-4 geometry, bf16 mode end to end (B=1, N=4096, I=6): HIP vs bf16-autocast oracle {e_bf:.2e} px (vis logits {e_vis:.2e}), "
+          f"HIP vs fp32 oracle {e_32:.2e} px, autocast oracle vs fp32 oracle {e_ref:.2e} px")
+    assert e_bf < 2e-2 and e_32 < 2e-2 and e_vis < 0.15
+
+
 def test_config4_teacher_forced_iteration(weights_raw):
     """B=1, 8 x 720x1280 frames, N=4096 grid, one update iteration through the product path (encoder -> tiled gather
     -> mixer -> update).  Particles are independent given the maps, so the oracle (CPU) runs a 256-particle subset."""

@@ -435,6 +435,40 @@ def _pm(t):
     return t.permute(0, 2, 1, 3).reshape(B * N * S, X).contiguous()
 
 
+@pytest.mark.parametrize("B,N,H8,W8,spread", [(1, 300, 46, 62, 0.7), (2, 1024, 33, 40, 3.0), (1, 77, 16, 20, 0.0), (1, 256, 46, 62, 4.0),
+                                              (1, 700, 17, 24, 0.5)])
+def test_mixer_input_build_tiled_bf16_mfma(B, N, H8, W8, spread):
+    """The bf16 mode's tiled gather on the matrix cores (gather_mfma_kernel, PIPS_FLAG_BF16_MAPS): under autocast the reference
+    correlates bf16 features with bf16 maps (nets/pips.py:394-397).  Against the oracle's CorrBlock on maps AND features rounded
+    to bf16, evaluated in fp64 (the products of two bf16 numbers are exact in fp32, so only the order of the fp32 sums differs:
+    fp32 tolerance) -- dense grid in one frame (items of > 96 particles are split), far-out points, windows half outside the map,
+    tile / pixel boundaries, a tile with a single particle, maps smaller than a tile."""
+    from pips_amd import ops
+    O = _oracle()
+    fmaps, ffeats, coords = _random_state(B, N, H8, W8, seed=19, spread=spread)
+    n_ = int(N ** 0.5)
+    gy, gx = torch.meshgrid(torch.linspace(0, H8 - 1, n_), torch.linspace(0, W8 - 1, n_), indexing="ij")
+    coords[0, 0, :n_ * n_] = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1)
+    coords[0, 6, 1] = torch.tensor([-40.0, 3.0])
+    coords[0, 7, 1] = torch.tensor([W8 + 3.5, H8 + 9.0])
+    coords[0, 5, 2] = torch.tensor([min(15.999999, W8 - 1.0), min(16.0, H8 - 1.0)])            # on a tile boundary
+    coords[0, 5, 3] = torch.tensor([-2.0, 1.5])                                                  # window partly outside
+    coords[0, 1, :] = torch.tensor([W8 * 0.5, H8 * 0.5])                                         # a whole frame in ONE cell: items split at 96
+    pyr_ref = O.build_pyramid(fmaps)
+    pyr_bf = [p.bfloat16().double() for p in pyr_ref]
+    ref = O.corr_sample(pyr_bf, ffeats.bfloat16().double(), coords.double())                     # (B,8,N,196)
+    pyr = ops.pyramid_mirror(_pack_pyramid(pyr_ref, B, H8 * 8, W8 * 8, 8), B * 8, H8 * 8, W8 * 8, 8)
+    ff, co = _pm(ffeats).to(DEV), _pm(coords).to(DEV)
+    X = ops.mixer_input_build_tiled(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu()
+    Xd = ops.mixer_input_build(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu()                    # direct kernel: fp32 features x bf16 maps
+    assert torch.equal(X[:, :128], Xd[:, :128]) and torch.equal(X[:, 324:], Xd[:, 324:])       # features, embedding, padding
+    err = float((X[:, 128:324].double() - _pm(ref)).abs().max())
+    dd = float((X[:, 128:324] - Xd[:, 128:324]).abs().max())
+    print(f"bf16 matrix-core gather vs fp64 oracle on bf16 operands {err:.2e}; vs the direct bf16-map kernel (fp32 features) {dd:.2e}")
+    assert err < 1e-4 and dd < 0.2          # (sample positions: fp32 here, fp64 in the yardstick)
+    assert torch.equal(X.view(B * N, 8, 544)[1, 6, 128:324], torch.zeros(196))                   # fully outside the map: zeros padding
+
+
 @pytest.mark.parametrize("B,N,H8,W8", [(1, 33, 46, 62), (2, 7, 17, 25)])
 def test_score_map_terms(B, N, H8, W8):
     """The dense score maps of nets/pips.py:501-511 (four levels upsampled with align_corners=True and summed) and the two

@@ -15,16 +15,36 @@ ffeats = torch.randn(M, 128, generator=g).to(dev)
 n = 64
 gy, gx = torch.meshgrid(torch.linspace(1, H8 - 2, n), torch.linspace(1, W8 - 2, n), indexing="ij")
 grid = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1)
+ops.pyramid_mirror(pyr, F, H8 * 8, W8 * 8, 8)                 # the bf16 mode's kernel reads the bf16 mirror
+lv = sum((H8 >> l) * (W8 >> l) for l in range(4))
 for name, c in (("grid", grid.reshape(1, N, 1, 2).repeat(B, 1, S, 1)),
                 ("grid + 2 px noise", grid.reshape(1, N, 1, 2).repeat(B, 1, S, 1) + torch.randn(B, N, S, 2, generator=g) * 2)):
     c = c.reshape(M, 2).contiguous().to(dev)
-    ts = {"bin": [], "embed": [], "gather": []}
-    for i in range(14):
-        _, t = ops.mixer_input_build_tiled_timed(pyr, B, H8, W8, ffeats, c)
-        if i >= 4:
-            for k in ts: ts[k].append(t[k])
-    lv = sum((H8 >> l) * (W8 >> l) for l in range(4))
-    comp = F * (lv * 512 + N * 512 + N * 8 + N * 196 * 4)
-    tg = statistics.mean(ts["gather"])
-    print(f"{name}: bin {statistics.mean(ts['bin'])*1e3:.1f} us  embed {statistics.mean(ts['embed'])*1e3:.1f} us  gather {tg*1e3:.1f} us"
-          f" = {comp/tg/1e6:.0f} GB/s compulsory = {comp/tg/1e6/8000:.3f} of 8 TB/s")
+    for bf in (False, True):
+        ts = {"bin": [], "embed": [], "gather": []}
+        for i in range(14):
+            _, t = ops.mixer_input_build_tiled_timed(pyr, B, H8, W8, ffeats, c, bf16_maps=bf)
+            if i >= 4:
+                for k in ts: ts[k].append(t[k])
+        # pyramid + features + coordinates + fcorrs; bf16 mode: bf16 pyramid and features, fp32 out
+        comp = F * (lv * (256 if bf else 512) + N * (256 if bf else 512) + N * 8 + N * 196 * 4)
+        tg = statistics.mean(ts["gather"])
+        print(f"{name}, {'bf16 mode (gather_mfma_kernel)' if bf else 'fp32 (gather_tiled_kernel)'}: bin {statistics.mean(ts['bin'])*1e3:.1f} us  "
+              f"embed {statistics.mean(ts['embed'])*1e3:.1f} us  gather {tg*1e3:.1f} us = {comp/1e6:.1f} MB / launch = {comp/tg/1e6:.0f} GB/s "
+              f"compulsory = {comp/tg/1e6/8000:.3f} of 8 TB/s")
+# BASELINE configs[2] geometry (B=8, 46x62 maps, N=256: ~21 particles per tile): the direct bf16-map kernel against the tiled matrix-core path
+B3, H3, W3, N3 = 8, 46, 62, 256
+F3, M3 = B3 * 8, B3 * N3 * 8
+pyr3 = ops.pyramid_mirror(torch.randn(lib.pips_pyramid_floats(F3, H3 * 8, W3 * 8, 8), generator=g).to(dev), F3, H3 * 8, W3 * 8, 8)
+ff3 = torch.randn(M3, 128, generator=g).to(dev)
+c3 = (torch.rand(M3, 2, generator=g) * torch.tensor([W3 - 1.0, H3 - 1.0])).to(dev)
+ev = lambda fn, n=20: (lambda e0, e1: (e0.record(), [fn() for _ in range(n)], e1.record(), e1.synchronize(), e0.elapsed_time(e1) / n)[-1])(
+    torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+ops.mixer_input_build(pyr3, B3, H3, W3, ff3, c3, bf16_maps=True)
+print(f"config-3 geometry: direct bf16-map kernel {ev(lambda: ops.mixer_input_build(pyr3, B3, H3, W3, ff3, c3, bf16_maps=True))*1e3:.1f} us", end="")
+ts = {"bin": [], "embed": [], "gather": []}
+for i in range(14):
+    _, t = ops.mixer_input_build_tiled_timed(pyr3, B3, H3, W3, ff3, c3, bf16_maps=True)
+    if i >= 4:
+        for k in ts: ts[k].append(t[k])
+print("; tiled matrix-core path: bin %.1f + embed %.1f + gather %.1f us" % tuple(statistics.mean(ts[k]) * 1e3 for k in ("bin", "embed", "gather")))
