@@ -540,12 +540,16 @@ constexpr int GM_WIN_BYTES = GMAX * GM_WIN_ROW * 4;
 constexpr int GM_REC_OFF = GM_WIN_OFF + GM_WIN_BYTES;
 constexpr int GM_ENT_OFF = GM_REC_OFF + GMAX * PIPS_LEVELS * 16;
 constexpr int GM_LDS = GM_ENT_OFF + 16;
+constexpr int GM_TAPS = 49;                      // (2 r + 1)^2 taps per level (PIPS_NCORR = 4 x 49 is a mixer row's whole correlation block)
 constexpr int GM_PIECES = (GM_CHUNK * 32 * 16 + GM_THREADS - 1) / GM_THREADS;      // 16-byte pieces per thread and chunk (6)
 static_assert(GM_PB * GM_GROUPS == GM_WAVES && GM_CHUNK % GM_GROUPS == 0, "wave <-> (particle block, pixel-block group)");
 static_assert(GM_THREADS == GMAX * PIPS_LEVELS, "one record per thread");
 static_assert(GM_LDS <= 64 * 1024 && GM_WIN_BYTES % 16 == 0 && GM_WIN_OFF % 16 == 0, "two blocks per compute unit; float4 zeroing");
 
 typedef __bf16 bf16x8_gm __attribute__((ext_vector_type(8)));
+#ifndef GM_ABLATE
+#define GM_ABLATE 0      // debugging builds only: 1 no map loads, 2 no products / scatter, 4 no stores, 8 no feature loads, 16 items only
+#endif
 
 __global__ __launch_bounds__(GM_THREADS, 3) void gather_mfma_kernel(const unsigned short* __restrict__ mirror, TiledLevels lv,
                                                                  const float* __restrict__ ffeats, int N, int max_items, int F,
@@ -579,6 +583,7 @@ __global__ __launch_bounds__(GM_THREADS, 3) void gather_mfma_kernel(const unsign
         const int tile = __builtin_amdgcn_readfirstlane(ev.x), first = __builtin_amdgcn_readfirstlane(ev.y),
                   count = __builtin_amdgcn_readfirstlane(ev.z), f = __builtin_amdgcn_readfirstlane(ev.w);
         if (f < 0) break;
+        if (GM_ABLATE & 16) continue;
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         // ---- records: thread 4 j + l holds (particle j, level l); slots past the item's particles get a far-away anchor
         {
@@ -592,6 +597,7 @@ __global__ __launch_bounds__(GM_THREADS, 3) void gather_mfma_kernel(const unsign
         {
             int m = -1;
             if (jme < count) m = order[((size_t)f * N + first + jme) * PIPS_LEVELS].w;
+            if (GM_ABLATE & 8) m = -1;
             const float* fp = ffeats + (size_t)max(m, 0) * C + half * 8;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(GM_THREADS, 3) void gather_mfma_kernel(const unsign
                     const int gb = c0 + (q >> 9), i = (q >> 4) & 31, c = q & 15;
                     const int byi = (int)(((unsigned)gb * inv_nbx) >> 16), bxi = gb - byi * nbx;
                     const int rx = bxi * 8 + (i & 7), ry = byi * 4 + (i >> 3);
-                    const bool ok = q < GM_CHUNK * 512 && gb < nblk && rx < RW && ry < RH;
+                    const bool ok = q < GM_CHUNK * 512 && gb < nblk && rx < RW && ry < RH && !(GM_ABLATE & 1);
                     // (clamped: always a valid address; a frame's level is < 4 GiB: 32-bit byte offset from a scalar base)
                     const unsigned so = (unsigned)((y0 + min(ry, RH - 1)) * Wl + x0 + min(rx, RW - 1)) * (unsigned)(C * 2) + (unsigned)(c * 16);
                     const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(mp) + so);
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(GM_THREADS, 3) void gather_mfma_kernel(const unsign
                 __syncthreads();
                 if (c0 + GM_CHUNK < nblk) prefetch(c0 + GM_CHUNK);
                 asm volatile("" ::: "memory");                       // keep the next chunk's loads ahead of the products
-                if (active) {
+                if (active && !(GM_ABLATE & 2)) {
 #pragma unroll
                     for (int b2 = 0; b2 < GM_CHUNK / GM_GROUPS; ++b2) {
                         const int bl = grp + b2 * GM_GROUPS, gb = c0 + bl;
@@ -680,8 +686,8 @@ __global__ __launch_bounds__(GM_THREADS, 3) void gather_mfma_kernel(const unsign
             __syncthreads();
             // ---- 2x2 blend of the 8x8 correlations to the 49 taps, k = ix*7 + iy (transposed, nets/pips.py:379-381)
             const float* winf = reinterpret_cast<const float*>(smem + GM_WIN_OFF);
-            for (int idx = tid; idx < count * PIPS_NCORR; idx += GM_THREADS) {
-                const int j = idx / PIPS_NCORR, t = idx - j * PIPS_NCORR;
+            for (int idx = tid; idx < count * GM_TAPS; idx += GM_THREADS) {
+                const int j = idx / GM_TAPS, t = idx - j * GM_TAPS;
                 const int ti = t / 7, tj = t - ti * 7;
                 const int4 r = rec[j * PIPS_LEVELS + l];
                 const float wx = __int_as_float(r.y), wy = __int_as_float(r.z);
@@ -692,7 +698,7 @@ __global__ __launch_bounds__(GM_THREADS, 3) void gather_mfma_kernel(const unsign
                             w2 = __fmul_rn(__fmul_rn(wy, e), k128), w3 = __fmul_rn(__fmul_rn(wy, wx), k128);
                 float o = __fmul_rn(w0, wv[0]);
                 o = fmaf(w1, wv[1], o); o = fmaf(w2, wv[8], o); o = fmaf(w3, wv[9], o);
-                X[(size_t)r.w * PIPS_KIN_PAD + C + PIPS_NCORR * l + t] = o;
+                if (!(GM_ABLATE & 4)) X[(size_t)r.w * PIPS_KIN_PAD + C + GM_TAPS * l + t] = o;
             }
         }
     }

@@ -8,6 +8,6 @@ mkdir -p "$ROOT/build"
 cd "$ROOT/pips_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc "$@" -c gather_tiled.hip -o "$ROOT/build/gather_$NAME.o"
 OBJS=""
-for f in gemm encoder track scoremap gemm_bf16 gemm_bf16_t4 conv_bf16_c64 gemm_x3 api; do OBJS="$OBJS $f.o"; done
+for f in $(python -c "import sys; sys.path.insert(0, '$ROOT'); from pips_amd import _build; print(' '.join(s[:-4] for s in _build.SOURCES if s != 'gather_tiled.hip'))"); do OBJS="$OBJS $f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build/libpips_$NAME.so" $OBJS "$ROOT/build/gather_$NAME.o"
 echo "$ROOT/build/libpips_$NAME.so"
