@@ -409,6 +409,23 @@ def config4_leg(device):
                      "embed_rows_kernel_ms": statistics.mean(ts["embed"]), "direct_kernel_ms(mixer_input_kernel)": t_direct,
                      "achieved_GBs": comp / tg / 1e6, "frac_of_8TBs": comp / tg / 1e6 / PEAK_HBM_GBS}
     dom = out["iter0_grid"]
+    # the bf16 mode of the same query set (PIPS_FLAG_BF16_MAPS: bf16 features x bf16 maps, the reference's arithmetic under autocast):
+    # gather_mfma_kernel on the bf16 mirror of the same maps, against ITS algorithmic bytes (bf16 pyramid + bf16
+    # features + coordinates + fp32 fcorrs = 293.8 MB)
+    ops.pyramid_mirror(pyr, F, h, w, STRIDE)
+    comp_bf = F * (lv * 256 + n * 256 + n * 8 + n * 196 * 4)
+    c0 = (xys / STRIDE).unsqueeze(1).expand(b, S, n, 2).permute(0, 2, 1, 3).reshape(M, 2).contiguous()
+    tb = []
+    for i in range(12):
+        _, t = ops.mixer_input_build_tiled_timed(pyr, b, H8, W8, ffeats, c0, bf16_maps=True)
+        if i >= 2:
+            tb.append(t["gather"])
+    tgb = statistics.mean(tb)
+    traffic_b, traffic_b_src = pmc_traffic("gather_mfma_kernel")
+    gather_bf16 = {"bound": "hbm", "kernel": "gather_mfma_kernel (bf16 mode: PIPS_FLAG_BF16_MAPS on a dense query set)", "launch_ms": tgb,
+                   "achieved": comp_bf / tgb / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": comp_bf / tgb / 1e6 / PEAK_HBM_GBS,
+                   "traffic": traffic_b, "traffic_source": traffic_b_src, "algorithmic_bytes_per_launch": comp_bf,
+                   "timing": "HIP event pair around the kernel launch, mean of 10 launches on the real maps (iteration-0 grid)"}
     traffic, traffic_src = pmc_traffic("gather_tiled_kernel")
     valu_floor_ms = b * S * n * 4 * 64 * 128 / (105.0 * 256 * 2.4e9) * 1e3
     lds_floor_ms = 0.78 * b * S * n * 4 * 64 * 128 * 4 / (256.0 * 256 * 2.4e9) * 1e3
@@ -430,6 +447,7 @@ def config4_leg(device):
                                                "2.4 GHz; lds: 17.2 GB of window fragments x 0.78 (anchor sharing) at 256 B/clk/CU",
                                 "timing": "HIP event pair around the kernel launch (pips_mixer_input_build_tiled_timed), "
                                           "mean of 10 launches on the real maps"},
+            "gather_roofline_bf16": gather_bf16,
             "gather": out}
 
 

@@ -570,7 +570,13 @@ size_t pips_pyramid_mirror_offset(int F, int H, int W, int stride) {
 }
 size_t pips_pyramid_floats(int F, int H, int W, int stride) {
     const size_t n = pips_pyramid_mirror_offset(F, H, W, stride);
-    return n + (n / 2 + 63) / 64 * 64;
+    // behind the mirror: a slack of a few map rows of the coarsest level (+ a pixel block).  gather_mfma_kernel fetches whole
+    // 8 x 4 pixel blocks; the slots of a border block that hang over the last level's last frame must still lie inside the buffer
+    // (their values are never used)
+    int lh[PIPS_LEVELS], lw[PIPS_LEVELS];
+    pyramid_dims(H, W, stride, lh, lw);
+    const size_t slack = ((size_t)4 * lw[PIPS_LEVELS - 1] + 16) * PIPS_C / 2;          // floats: (4 rows + 16 pixels) of bf16 channels
+    return n + (n / 2 + 63) / 64 * 64 + (slack + 63) / 64 * 64;
 }
 int pips_pyramid_mirror(float* pyramid, int F, int H, int W, int stride, void* stream) {
     PIPS_CHECK_ARG(pyramid != nullptr && F > 0, "pyramid_mirror: bad argument");

@@ -513,62 +513,89 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
 //        D[region pixel][particle] = sum_c map[pixel][c] * feat[particle][c]        (v_mfma_f32_32x32x16_bf16)
 // -- CorrBlock.corr restricted to the tile -- and each particle then keeps the 8 x 8 window it needs.  The products outside the
 // windows are redundant (x 3.5 at level 0 ... x 1.5 at level 3) and still cost less than a tenth of the vector-ALU form.
-//   * one block (6 waves) per work item; two blocks per compute unit, so one block's staging overlaps the other's products;
-//   * B operand (features): wave = (particle block pb of 32, pixel-block group): the lane's 8 x 16-byte fragments of ITS particle
-//     are converted fp32 -> bf16 (RNE) once per item and stay in registers;
-//   * A operand (maps): the region is cut into PIXEL BLOCKS of 8 x 4 pixels (= the 32 rows of one MFMA); a chunk of four blocks
-//     (32 KiB: all 128 channels) is staged global -> registers -> LDS, the next chunk's loads in flight under this chunk's
-//     products; 256-byte rows with the 16-byte chunk index XORed with (row & 15): fragment reads and staging writes are
-//     conflict-free; slots outside the region are staged as zeros;
+//   * ONE persistent block of 16 waves per compute unit, the waves SPECIALISED: 12 product waves and 4 loader waves.  The first cut
+//     (every wave loading, multiplying and storing; two blocks per compute unit for overlap) ran 350 us where its parts, timed
+//     alone, needed 65 (map loads) + 75 (products) + 40 (stores) + 42 (the rest): a wave's vector-memory counter is in order, so
+//     a wait for map loads also waited for the tap stores issued before them, and every step exposed a memory round trip.  Now a
+//     product wave issues no load at all (its stores are never waited for) and a loader wave nothing but loads;
+//   * an item's pixel blocks -- the region of each level cut into blocks of 8 x 4 pixels = the 32 rows of one MFMA -- form ONE
+//     sequence of chunks of four blocks (32 KiB: all 128 channels) over the four levels; in step s the loaders write chunk s + 1
+//     (requested two steps earlier; slots outside the region as zeros) into stage buffer (s + 1) & 1 and request chunk s + 3,
+//     the product waves work on chunk s out of buffer s & 1; ONE barrier per step.  256-byte rows with the 16-byte chunk index
+//     XORed with (row & 15): fragment reads and staging writes are conflict-free;
+//   * B operand (features): the loaders convert the item's features fp32 -> bf16 (RNE) into LDS once per item; a product wave
+//     = (particle block pb of 32, block-in-chunk) keeps the 8 fragments of ITS lane's particle in registers for the item;
 //   * the accumulator layout does the window test almost for free: a lane holds, for ITS particle (column), the 4 x 4 pixels
 //     x = 4 half + (r & 3), y = r >> 2 of the block, so the window coordinate of register r is (dx0 + (r & 3), dy0 + (r >> 2)) with
 //     ONE (dx0, dy0) per lane and block, the target address in the per-level window buffer win[particle][8][8] (+1 float of
-//     padding per particle: the 32 lanes of a write are 32 particles) is one base +
-//     immediates, and the validity of a value is the AND of an x- and a y-compare: 16 masked ds_write_b32 per block;
-//   * per level: win zeroed (zeros padding outside the map, nets/pips.py:324), chunks, then the 2 x 2 blend of the 8 x 8
-//     correlations to the 49 taps in the reference's transposed order (k = ix * 7 + iy, :379-381) -- the same weights, scaling
-//     and operation order as gather_tiled_kernel's epilogue -- and coalesced 49-float stores into X.
-constexpr int GM_WAVES = 6, GM_THREADS = GM_WAVES * 64;
+//     padding per particle: the 32 lanes of a write are 32 particles) is one base + immediates, and the validity of a value is
+//     the AND of an x- and a y-compare: 16 masked ds_write_b32 per block;
+//   * two window buffers (level parity): the 2 x 2 blend of level l's 8 x 8 correlations to the 49 taps, in the reference's
+//     transposed order (k = ix * 7 + iy, :379-381) with the weights, scaling and operation order of gather_tiled_kernel's
+//     epilogue, runs in the step after the level's last chunk, beside the next level's products.  A window pixel outside the map is
+//     never written: the blend tests its four neighbours against the map (zeros padding, :324) instead of clearing the buffer.
+constexpr int GM_PWAVES = 12, GM_LWAVES = 4, GM_WAVES = GM_PWAVES + GM_LWAVES, GM_THREADS = GM_WAVES * 64;
+constexpr int GM_PTHREADS = GM_PWAVES * 64, GM_LTHREADS = GM_LWAVES * 64;
 constexpr int GM_PB = GMAX / 32;                  // particle blocks per item
-constexpr int GM_GROUPS = GM_WAVES / GM_PB;       // wave groups sharing a chunk's pixel blocks
-constexpr int GM_CHUNK = 4;                       // pixel blocks per stage
+constexpr int GM_CHUNK = GM_PWAVES / GM_PB;       // pixel blocks per chunk = product waves per particle block (4)
 constexpr int GM_BLK_BYTES = 32 * C * 2;          // 8 KiB: 32 pixels x 128 channels bf16
-constexpr int GM_STAGE = GM_CHUNK * GM_BLK_BYTES;
-constexpr int GM_WIN_OFF = GM_STAGE + 128;        // (the scatter's per-lane base may lie up to 108 bytes below a particle's window)
+constexpr int GM_STAGE = GM_CHUNK * GM_BLK_BYTES; // 32 KiB
 constexpr int GM_WIN_ROW = 65;                    // floats per particle window: 64 + 1, so that the 32 particles (lanes) of a scatter hit 32 banks
 constexpr int GM_WIN_BYTES = GMAX * GM_WIN_ROW * 4;
-constexpr int GM_REC_OFF = GM_WIN_OFF + GM_WIN_BYTES;
-constexpr int GM_ENT_OFF = GM_REC_OFF + GMAX * PIPS_LEVELS * 16;
-constexpr int GM_LDS = GM_ENT_OFF + 16;
-constexpr int GM_TAPS = 49;                      // (2 r + 1)^2 taps per level (PIPS_NCORR = 4 x 49 is a mixer row's whole correlation block)
-constexpr int GM_PIECES = (GM_CHUNK * 32 * 16 + GM_THREADS - 1) / GM_THREADS;      // 16-byte pieces per thread and chunk (6)
-static_assert(GM_PB * GM_GROUPS == GM_WAVES && GM_CHUNK % GM_GROUPS == 0, "wave <-> (particle block, pixel-block group)");
-static_assert(GM_THREADS == GMAX * PIPS_LEVELS, "one record per thread");
-static_assert(GM_LDS <= 64 * 1024 && GM_WIN_BYTES % 16 == 0 && GM_WIN_OFF % 16 == 0, "two blocks per compute unit; float4 zeroing");
+constexpr int GM_WIN_OFF = 2 * GM_STAGE + 128;    // (the scatter's per-lane base may lie up to 108 bytes below a particle's window)
+constexpr int GM_REC_OFF = GM_WIN_OFF + 2 * GM_WIN_BYTES;
+constexpr int GM_FEAT_OFF = GM_REC_OFF + GMAX * PIPS_LEVELS * 16;
+constexpr int GM_ENTS = 64;                       // work-item entries looked up at a time
+constexpr int GM_ENT_OFF = GM_FEAT_OFF + GMAX * C * 2;
+constexpr int GM_LDS = GM_ENT_OFF + GM_ENTS * 16;
+constexpr int GM_TAPS = 49;                       // (2 r + 1)^2 taps per level (PIPS_NCORR = 4 x 49 is a mixer row's whole correlation block)
+constexpr int GM_PIECES = GM_CHUNK * 32 * 16 / GM_LTHREADS;                        // 16-byte pieces per loader thread and chunk (8)
+static_assert(GM_PB * GM_CHUNK == GM_PWAVES && GM_CHUNK * 32 * 16 % GM_LTHREADS == 0, "wave <-> (particle block, block of the chunk)");
+static_assert(GM_LDS <= 160 * 1024 && GM_WIN_OFF % 16 == 0 && GM_REC_OFF % 16 == 0 && GM_FEAT_OFF % 16 == 0, "LDS layout");
 
 typedef __bf16 bf16x8_gm __attribute__((ext_vector_type(8)));
 #ifndef GM_ABLATE
 #define GM_ABLATE 0      // debugging builds only: 1 no map loads, 2 no products / scatter, 4 no stores, 8 no feature loads, 16 items only
 #endif
 
-__global__ __launch_bounds__(GM_THREADS, 3) void gather_mfma_kernel(const unsigned short* __restrict__ mirror, TiledLevels lv,
-                                                                 const float* __restrict__ ffeats, int N, int max_items, int F,
-                                                                 const int4* __restrict__ order, const int4* __restrict__ items,
-                                                                 const int* __restrict__ nitems, int tiles_x,
-                                                                 float* __restrict__ X) {
+// the level's staged region: the same rectangle as lane_geom() (window reach of every particle binned into the tile), cut into
+// pixel blocks of 8 x 4.  P = x0 | y0 << 16 (map coordinates of the region's corner), Q = RW | RH << 8 | nbx << 16 | nblk << 24
+__device__ __forceinline__ void gm_level_geom(int l, int tx, int ty, int Wl, int Hl, int& P, int& Q) {
+    const int Tx = (tx * TS) >> l, Ty = (ty * TS) >> l, w = TS >> l, h = l == 0 ? 3 : 4;
+    int x0 = max(Tx - h, 0), y0 = max(Ty - h, 0);
+    const int x1 = min(Tx + w + h, Wl - 1), y1 = min(Ty + w + h, Hl - 1);
+    int RW = max(x1 - x0 + 1, 1), RH = max(y1 - y0 + 1, 1);
+    if (x1 < x0 || y1 < y0) { x0 = y0 = 0; RW = RH = 1; }   // (tile beyond this level's map)
+    const int nbx = (RW + 7) >> 3, nblk = nbx * ((RH + 3) >> 2);
+    P = x0 | (y0 << 16);
+    Q = RW | (RH << 8) | (nbx << 16) | (nblk << 24);
+}
+
+__global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned short* __restrict__ mirror, TiledLevels lv,
+                                                                const float* __restrict__ ffeats, int N, int max_items, int F,
+                                                                const int4* __restrict__ order, const int4* __restrict__ items,
+                                                                const int* __restrict__ nitems, int tiles_x,
+                                                                float* __restrict__ X) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pb = wave % GM_PB, grp = wave / GM_PB;
+    const bool loader = wave >= GM_PWAVES;                           // (wave-uniform)
+    const int ltid = tid - GM_PTHREADS;                              // loader thread id (0..255)
+    const int pb = wave % GM_PB, bl = wave / GM_PB;                  // product wave = (particle block, block of the chunk)
     const int xcd = blockIdx.x & 7, J = gridDim.x >> 3, jb = blockIdx.x >> 3;
     int4* rec = reinterpret_cast<int4*>(smem + GM_REC_OFF);
     int4* ent = reinterpret_cast<int4*>(smem + GM_ENT_OFF);
-    const int jme = pb * 32 + l31;                                   // this lane's particle (MFMA column) within the item
-    for (int it = 0;; ++it) {
-        // ---- this block's next work item: entry jb + it * J of the XCD's list (frames xcd, xcd + 8, ... one after another)
-        __syncthreads();                                             // (the previous item's blend is done with rec / win / ent)
-        if (tid == 0) {
-            int gi = jb + it * J, fr = xcd;
+    const int jme = pb * 32 + l31;                                   // a product lane's particle (MFMA column) within the item
+    // the levels' map sizes and offsets as scalars (static indices: a dynamically indexed kernel-argument array goes to scratch)
+    const int W0 = lv.W[0], W1 = lv.W[1], W2 = lv.W[2], W3 = lv.W[3], H0 = lv.H[0], H1 = lv.H[1], H2 = lv.H[2], H3 = lv.H[3];
+    const size_t o0 = lv.off[0], o1 = lv.off[1], o2 = lv.off[2], o3 = lv.off[3];
+#define GM_SEL4(l_, a0, a1, a2, a3) ((l_) == 0 ? (a0) : ((l_) == 1 ? (a1) : ((l_) == 2 ? (a2) : (a3))))
+    for (int base = 0;; base += GM_ENTS) {
+        // ---- this block's next (up to) 64 work items: item i of the block is entry jb + i J of the XCD's list (frames xcd,
+        //      xcd + 8, ... one after another); lane-parallel look-up, entries {tile, first, count, frame} in LDS
+        lds_barrier();
+        if (wave == 0) {
+            int gi = jb + (base + lane) * J, fr = xcd;
             int4 e = make_int4(0, 0, 0, -1);
             for (; fr < F; fr += 8) {
                 const int n = nitems[fr];
@@ -576,132 +603,193 @@ __global__ __launch_bounds__(GM_THREADS, 3) void gather_mfma_kernel(const unsign
                 gi -= n;
             }
             if (fr < F) { e = items[(size_t)fr * max_items + gi]; e.w = fr; }
-            *ent = e;
+            ent[lane] = e;
         }
         __syncthreads();
-        const int4 ev = *ent;
-        const int tile = __builtin_amdgcn_readfirstlane(ev.x), first = __builtin_amdgcn_readfirstlane(ev.y),
-                  count = __builtin_amdgcn_readfirstlane(ev.z), f = __builtin_amdgcn_readfirstlane(ev.w);
-        if (f < 0) break;
-        if (GM_ABLATE & 16) continue;
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        // ---- records: thread 4 j + l holds (particle j, level l); slots past the item's particles get a far-away anchor
-        {
-            const int j = tid >> 2;
-            int4 r = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);
-            if (j < count) r = order[((size_t)f * N + first) * PIPS_LEVELS + tid];
-            rec[tid] = r;
-        }
-        // ---- B operand: the lane's particle's features as 8 MFMA fragments (channels 16 ks + 8 half ... + 8), fp32 -> bf16 RNE
-        uint4 bfr[8];
-        {
-            int m = -1;
-            if (jme < count) m = order[((size_t)f * N + first + jme) * PIPS_LEVELS].w;
-            if (GM_ABLATE & 8) m = -1;
-            const float* fp = ffeats + (size_t)max(m, 0) * C + half * 8;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const float4 a = *reinterpret_cast<const float4*>(fp + ks * 16), b = *reinterpret_cast<const float4*>(fp + ks * 16 + 4);
-                bfr[ks] = m >= 0 ? make_uint4(pack2_bf16(a.x, a.y), pack2_bf16(a.z, a.w), pack2_bf16(b.x, b.y), pack2_bf16(b.z, b.w))
-                                 : make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
-        const bool active = pb * 32 < count;                         // (wave-uniform) this wave's particle block holds particles
-#pragma unroll
-        for (int l = 0; l < PIPS_LEVELS; ++l) {
-            // ---- the level's staged region: the same rectangle as lane_geom() (window reach of every particle binned into the tile)
-            const int Wl = lv.W[l], Hl = lv.H[l];
-            const int Tx = (tx * TS) >> l, Ty = (ty * TS) >> l, w = TS >> l, h = l == 0 ? 3 : 4;
-            int x0 = max(Tx - h, 0), y0 = max(Ty - h, 0);
-            const int x1 = min(Tx + w + h, Wl - 1), y1 = min(Ty + w + h, Hl - 1);
-            int RW = max(x1 - x0 + 1, 1), RH = max(y1 - y0 + 1, 1);
-            if (x1 < x0 || y1 < y0) { x0 = y0 = 0; RW = RH = 1; }   // (tile beyond this level's map)
-            const int nbx = (RW + 7) >> 3, nby = (RH + 3) >> 2, nblk = nbx * nby;
-            const unsigned inv_nbx = (65536u + (unsigned)nbx - 1u) / (unsigned)nbx;           // block -> block row: exact for < 256 blocks
-            const unsigned short* mp = mirror + lv.off[l] + (size_t)f * Hl * Wl * C;
-            __syncthreads();                                         // records in LDS (first level) / the previous level's blend has read win
-            int bxr, byr;                                            // this lane's particle's window anchor in region coordinates
-            {
-                const int rx_ = rec[jme * PIPS_LEVELS + l].x;
-                bxr = (int)(short)(rx_ & 0xffff) - x0;
-                byr = (rx_ >> 16) - y0;
-            }
-            for (int k = tid; k < GM_WIN_BYTES / 16; k += GM_THREADS)
-                reinterpret_cast<float4*>(smem + GM_WIN_OFF)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint4 pre[GM_PIECES];
-            auto prefetch = [&](int c0) __attribute__((always_inline)) {
-#pragma unroll
-                for (int k = 0; k < GM_PIECES; ++k) {
-                    const int q = tid + k * GM_THREADS;              // piece: pixel block q >> 9, row (q >> 4) & 31, 16-byte chunk q & 15
-                    const int gb = c0 + (q >> 9), i = (q >> 4) & 31, c = q & 15;
-                    const int byi = (int)(((unsigned)gb * inv_nbx) >> 16), bxi = gb - byi * nbx;
-                    const int rx = bxi * 8 + (i & 7), ry = byi * 4 + (i >> 3);
-                    const bool ok = q < GM_CHUNK * 512 && gb < nblk && rx < RW && ry < RH && !(GM_ABLATE & 1);
-                    // (clamped: always a valid address; a frame's level is < 4 GiB: 32-bit byte offset from a scalar base)
-                    const unsigned so = (unsigned)((y0 + min(ry, RH - 1)) * Wl + x0 + min(rx, RW - 1)) * (unsigned)(C * 2) + (unsigned)(c * 16);
-                    const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(mp) + so);
-                    pre[k] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+        bool more = true;
+        for (int it = 0; it < GM_ENTS; ++it) {
+            const int4 ev = ent[it];
+            const int tile = __builtin_amdgcn_readfirstlane(ev.x), first = __builtin_amdgcn_readfirstlane(ev.y),
+                      count = __builtin_amdgcn_readfirstlane(ev.z), f = __builtin_amdgcn_readfirstlane(ev.w);
+            if (f < 0) { more = false; break; }
+            if (GM_ABLATE & 16) continue;
+            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            // ---- per-level geometry of the item (wave-uniform; named scalars and packed fields, selected by ternaries: an array
+            //      indexed by the run-time level goes to scratch); a level's blocks fill whole chunks
+            int P0, P1, P2, P3, Q0, Q1, Q2, Q3;                           // P = x0 | y0 << 16;  Q = RW | RH << 8 | nbx << 16 | nblk << 24
+            gm_level_geom(0, tx, ty, W0, H0, P0, Q0);
+            gm_level_geom(1, tx, ty, W1, H1, P1, Q1);
+            gm_level_geom(2, tx, ty, W2, H2, P2, Q2);
+            gm_level_geom(3, tx, ty, W3, H3, P3, Q3);
+            const int cs1 = (((unsigned)Q0 >> 24) + GM_CHUNK - 1) / GM_CHUNK;                   // first chunk of level 1, 2, 3; number of chunks
+            const int cs2 = cs1 + (((unsigned)Q1 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+            const int cs3 = cs2 + (((unsigned)Q2 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+            const int nchunks = cs3 + (((unsigned)Q3 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+#define GM_LEVEL_OF(ci_) (((ci_) >= cs1) + ((ci_) >= cs2) + ((ci_) >= cs3))
+            if (loader) {
+                // =================================================================== loader waves: nothing but loads (and LDS writes)
+                // request: thread = (rows i = ltid >> 4 and i + 16 of every block, 16-byte chunk c = ltid & 15); a block's source is a
+                // wave-uniform base (SGPRs) + one of two per-lane offsets.  No mask and no clamp: a slot outside the region holds
+                // whatever lies there in the buffer (a slack behind the mirror keeps the last level's last rows inside it,
+                // pips_pyramid_floats) -- a window pixel that falls on such a slot lies outside the map, and the blend tests that
+#define GM_REQUEST(ci_, pre)                                                                                                    \
+                {                                                                                                               \
+                    const int l_ = GM_LEVEL_OF(ci_);                                                                            \
+                    const int c0_ = ((ci_) - GM_SEL4(l_, 0, cs1, cs2, cs3)) * GM_CHUNK;                                         \
+                    const int P_ = GM_SEL4(l_, P0, P1, P2, P3), Q_ = GM_SEL4(l_, Q0, Q1, Q2, Q3);                               \
+                    const int x0_ = P_ & 0xffff, y0_ = (unsigned)P_ >> 16, nbx_ = (Q_ >> 16) & 0xff, nblk_ = (unsigned)Q_ >> 24; \
+                    const int Wl_ = GM_SEL4(l_, W0, W1, W2, W3), Hl_ = GM_SEL4(l_, H0, H1, H2, H3);                             \
+                    const size_t ol_ = GM_SEL4(l_, o0, o1, o2, o3);                                                             \
+                    const unsigned inv_ = (65536u + (unsigned)nbx_ - 1u) / (unsigned)nbx_;   /* block -> block row: exact for < 256 blocks */ \
+                    const char* mp_ = reinterpret_cast<const char*>(mirror + ol_ + (size_t)f * Hl_ * Wl_ * C);                  \
+                    const unsigned offA_ = (unsigned)(((ltid >> 7) * Wl_ + ((ltid >> 4) & 7)) * (C * 2) + (ltid & 15) * 16);    \
+                    const unsigned offB_ = offA_ + (unsigned)(2 * Wl_ * C * 2);          /* row i + 16: two image rows further down */ \
+                    _Pragma("unroll") for (int b_ = 0; b_ < GM_CHUNK; ++b_) {                                                   \
+                        const int gb = min(c0_ + b_, nblk_ - 1);      /* (a chunk's blocks past the level's last repeat it: never used) */ \
+                        const int byi = (int)(((unsigned)gb * inv_) >> 16), bxi = gb - byi * nbx_;                              \
+                        const char* sb_ = mp_ + (size_t)((unsigned)((y0_ + byi * 4) * Wl_ + x0_ + bxi * 8) * (unsigned)(C * 2)); \
+                        pre[2 * b_] = (GM_ABLATE & 1) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(sb_ + offA_); \
+                        pre[2 * b_ + 1] = (GM_ABLATE & 1) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(sb_ + offB_); \
+                    }                                                                                                           \
                 }
-            };
-            prefetch(0);
-            for (int c0 = 0; c0 < nblk; c0 += GM_CHUNK) {
-                __syncthreads();                                     // the stage is free (and, first chunk, win is zeroed)
-#pragma unroll
-                for (int k = 0; k < GM_PIECES; ++k) {
-                    const int q = tid + k * GM_THREADS;
-                    const int i = (q >> 4) & 31, c = q & 15;
-                    if (q < GM_CHUNK * 512)
-                        *reinterpret_cast<uint4*>(smem + (q >> 9) * GM_BLK_BYTES + i * 256 + ((c ^ (i & 15)) << 4)) = pre[k];
+#define GM_DELIVER(ci_, pre)                                                                                                    \
+                {                                                                                                               \
+                    char* st_ = smem + ((ci_) & 1) * GM_STAGE + ldsA;                                                           \
+                    _Pragma("unroll") for (int b_ = 0; b_ < GM_CHUNK; ++b_) {                                                   \
+                        *reinterpret_cast<uint4*>(st_ + b_ * GM_BLK_BYTES) = pre[2 * b_];                                       \
+                        *reinterpret_cast<uint4*>(st_ + b_ * GM_BLK_BYTES + 16 * 256) = pre[2 * b_ + 1];                        \
+                    }                                                                                                           \
                 }
-                __syncthreads();
-                if (c0 + GM_CHUNK < nblk) prefetch(c0 + GM_CHUNK);
-                asm volatile("" ::: "memory");                       // keep the next chunk's loads ahead of the products
-                if (active && !(GM_ABLATE & 2)) {
+                const int ldsA = (ltid >> 4) * 256 + (((ltid & 15) ^ ((ltid >> 4) & 15)) << 4);      // row i (and i + 16: same swizzle), chunk c
+                uint4 preA[GM_PIECES], preB[GM_PIECES], preC[GM_PIECES];   // chunks 3 k, 3 k + 1, 3 k + 2: three requests in flight
+                GM_REQUEST(0, preA)                                      // (first in the queue: what the first step needs)
+                // (order: everything that depends on nothing but the entry first -- the map chunk above, the records, the six
+                //  feature-row indices -- then the feature rows, which need the indices: two memory round trips, not one per batch)
+                int4 r0 = order[((size_t)f * N + first) * PIPS_LEVELS + min(ltid, count * PIPS_LEVELS - 1)];
+                int4 r1 = order[((size_t)f * N + first) * PIPS_LEVELS + min(ltid + GM_LTHREADS, count * PIPS_LEVELS - 1)];
+                {
+                    // thread -> (particle j = k * 16 + (ltid >> 4), chunk c = ltid & 15 of 8 channels), k = 0..5
+                    const int c = ltid & 15;
+                    int mrow[GMAX / 16];
 #pragma unroll
-                    for (int b2 = 0; b2 < GM_CHUNK / GM_GROUPS; ++b2) {
-                        const int bl = grp + b2 * GM_GROUPS, gb = c0 + bl;
-                        if (gb >= nblk) break;
-                        f32x16 acc;
+                    for (int k = 0; k < GMAX / 16; ++k)
+                        mrow[k] = order[((size_t)f * N + first + min(k * 16 + (ltid >> 4), count - 1)) * PIPS_LEVELS].w;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                        const char* ap = smem + bl * GM_BLK_BYTES + l31 * 256;
+                    for (int hb = 0; hb < 2; ++hb) {                     // (two batches of three rows: register budget)
+                        float4 fa[GMAX / 32], fb[GMAX / 32];
 #pragma unroll
-                        for (int ks = 0; ks < 8; ++ks) {
-                            const uint4 a = *reinterpret_cast<const uint4*>(ap + (((ks * 2 + half) ^ (l31 & 15)) << 4));
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_gm*>(&a),
-                                                                          *reinterpret_cast<const bf16x8_gm*>(&bfr[ks]), acc, 0, 0, 0);
+                        for (int k = 0; k < GMAX / 32; ++k) {
+                            const float* fp = ffeats + (size_t)mrow[hb * (GMAX / 32) + k] * C + c * 8;
+                            fa[k] = *reinterpret_cast<const float4*>(fp);
+                            fb[k] = *reinterpret_cast<const float4*>(fp + 4);
                         }
-                        const int byi = (int)(((unsigned)gb * inv_nbx) >> 16), bxi = gb - byi * nbx;
-                        const int dx0 = bxi * 8 + 4 * half - bxr, dy0 = byi * 4 - byr;
-                        char* wb = smem + GM_WIN_OFF + jme * (GM_WIN_ROW * 4) + dy0 * 32 + dx0 * 4;
 #pragma unroll
-                        for (int y = 0; y < 4; ++y)
-#pragma unroll
-                            for (int x = 0; x < 4; ++x)
-                                if ((unsigned)(dx0 + x) < 8u && (unsigned)(dy0 + y) < 8u)
-                                    *reinterpret_cast<float*>(wb + y * 32 + x * 4) = acc[y * 4 + x];
+                        for (int k = 0; k < GMAX / 32; ++k) {
+                            const int j = (hb * (GMAX / 32) + k) * 16 + (ltid >> 4);
+                            const unsigned keep = (j < count && !(GM_ABLATE & 8)) ? 0xffffffffu : 0u;
+                            *reinterpret_cast<uint4*>(smem + GM_FEAT_OFF + j * 256 + ((c ^ (j & 15)) << 4)) =
+                                make_uint4(pack2_bf16(fa[k].x, fa[k].y) & keep, pack2_bf16(fa[k].z, fa[k].w) & keep,
+                                           pack2_bf16(fb[k].x, fb[k].y) & keep, pack2_bf16(fb[k].z, fb[k].w) & keep);
+                        }
                     }
                 }
+                if (nchunks > 1) GM_REQUEST(1, preB)                     // (after the features: register budget of a 16-wave block)
+                if (nchunks > 2) GM_REQUEST(2, preC)
+                if ((ltid >> 2) >= count) r0 = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);
+                if (((ltid + GM_LTHREADS) >> 2) >= count) r1 = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);
+                rec[ltid] = r0;
+                if (ltid + GM_LTHREADS < GMAX * PIPS_LEVELS) rec[ltid + GM_LTHREADS] = r1;
+                GM_DELIVER(0, preA)
+                if (nchunks > 3) GM_REQUEST(3, preA)
+                lds_barrier();                                           // (A) records, features and chunk 0 are in LDS
+                // step s: deliver chunk s + 1 (requested three steps earlier), request chunk s + 4 into its registers
+                for (int s = 0; s <= nchunks; s += 3) {
+                    if (s + 1 < nchunks) { GM_DELIVER(s + 1, preB) if (s + 4 < nchunks) GM_REQUEST(s + 4, preB) }
+                    lds_barrier();
+                    if (s + 1 > nchunks) break;
+                    if (s + 2 < nchunks) { GM_DELIVER(s + 2, preC) if (s + 5 < nchunks) GM_REQUEST(s + 5, preC) }
+                    lds_barrier();
+                    if (s + 2 > nchunks) break;
+                    if (s + 3 < nchunks) { GM_DELIVER(s + 3, preA) if (s + 6 < nchunks) GM_REQUEST(s + 6, preA) }
+                    lds_barrier();
+                }
+#undef GM_REQUEST
+#undef GM_DELIVER
+            } else {
+                // =================================================================== product waves: no loads; LDS, MFMA, stores
+                lds_barrier();                                           // (A)
+                uint4 bfr[8];                                            // B operand: this lane's particle, channels 16 ks + 8 half ... + 8
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    bfr[ks] = *reinterpret_cast<const uint4*>(smem + GM_FEAT_OFF + jme * 256 + (((ks * 2 + half) ^ (jme & 15)) << 4));
+                const bool active = pb * 32 < count;                     // (wave-uniform) this wave's particle block holds particles
+                for (int s = 0; s <= nchunks; ++s) {
+                    if (s < nchunks && active && !(GM_ABLATE & 2)) {
+                        // ---- products of chunk s: this wave's block of the chunk x its particle block, scattered into the windows
+                        const int l = GM_LEVEL_OF(s);
+                        const int c0 = (s - GM_SEL4(l, 0, cs1, cs2, cs3)) * GM_CHUNK;
+                        const int P = GM_SEL4(l, P0, P1, P2, P3), Q = GM_SEL4(l, Q0, Q1, Q2, Q3);
+                        const int nbx = (Q >> 16) & 0xff, nblk = (unsigned)Q >> 24;
+                        const int gb = c0 + bl;
+                        if (gb < nblk) {
+                            const int rx_ = rec[jme * PIPS_LEVELS + l].x;            // window anchor in region coordinates
+                            const int bxr = (int)(short)(rx_ & 0xffff) - (P & 0xffff), byr = (rx_ >> 16) - (int)((unsigned)P >> 16);
+                            f32x16 acc;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                            const char* ap = smem + (s & 1) * GM_STAGE + bl * GM_BLK_BYTES + l31 * 256;
+#pragma unroll
+                            for (int ks = 0; ks < 8; ++ks) {
+                                const uint4 a = *reinterpret_cast<const uint4*>(ap + (((ks * 2 + half) ^ (l31 & 15)) << 4));
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_gm*>(&a),
+                                                                              *reinterpret_cast<const bf16x8_gm*>(&bfr[ks]), acc, 0, 0, 0);
+                            }
+                            const unsigned inv_nbx = (65536u + (unsigned)nbx - 1u) / (unsigned)nbx;
+                            const int byi = (int)(((unsigned)gb * inv_nbx) >> 16), bxi = gb - byi * nbx;
+                            const int dx0 = bxi * 8 + 4 * half - bxr, dy0 = byi * 4 - byr;
+                            char* wb = smem + GM_WIN_OFF + (l & 1) * GM_WIN_BYTES + jme * (GM_WIN_ROW * 4) + dy0 * 32 + dx0 * 4;
+#pragma unroll
+                            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                                for (int x = 0; x < 4; ++x)
+                                    if ((unsigned)(dx0 + x) < 8u && (unsigned)(dy0 + y) < 8u)
+                                        *reinterpret_cast<float*>(wb + y * 32 + x * 4) = acc[y * 4 + x];
+                        }
+                    }
+                    if (s > 0 && (s == cs1 || s == cs2 || s == cs3 || s == nchunks)) {
+                        // ---- the step after a level's last chunk: 2x2 blend of its 8x8 correlations to the 49 taps, k = ix*7 + iy
+                        //      (transposed, :379-381); neighbours outside the map count as zero (:324)
+                        const int l = GM_LEVEL_OF(s - 1);
+                        const int Wl = GM_SEL4(l, W0, W1, W2, W3), Hl = GM_SEL4(l, H0, H1, H2, H3);
+                        const float* winf = reinterpret_cast<const float*>(smem + GM_WIN_OFF + (l & 1) * GM_WIN_BYTES);
+                        for (int idx = tid; idx < count * GM_TAPS; idx += GM_PTHREADS) {
+                            const int j = idx / GM_TAPS, t = idx - j * GM_TAPS;
+                            const int ti = t / 7, tj = t - ti * 7;
+                            const int4 r = rec[j * PIPS_LEVELS + l];
+                            const float wx = __int_as_float(r.y), wy = __int_as_float(r.z);
+                            const int px = (int)(short)(r.x & 0xffff) + ti, py = (r.x >> 16) + tj;        // map pixel of the tap's north-west neighbour
+                            const bool x0in = (unsigned)px < (unsigned)Wl, x1in = (unsigned)(px + 1) < (unsigned)Wl,
+                                       y0in = (unsigned)py < (unsigned)Hl, y1in = (unsigned)(py + 1) < (unsigned)Hl;
+                            const float* wv = winf + j * GM_WIN_ROW + tj * 8 + ti;
+                            const float nw = (x0in && y0in) ? wv[0] : 0.f, ne = (x1in && y0in) ? wv[1] : 0.f,
+                                        sw = (x0in && y1in) ? wv[8] : 0.f, se = (x1in && y1in) ? wv[9] : 0.f;
+                            const float e = 1.0f - wx, so = 1.0f - wy;
+                            const float k128 = 0.08838834764831845f;                              // the 1/sqrt(128) of :397 rides on the weights
+                            const float w0 = __fmul_rn(__fmul_rn(so, e), k128), w1 = __fmul_rn(__fmul_rn(so, wx), k128),
+                                        w2 = __fmul_rn(__fmul_rn(wy, e), k128), w3 = __fmul_rn(__fmul_rn(wy, wx), k128);
+                            float o = __fmul_rn(w0, nw);
+                            o = fmaf(w1, ne, o); o = fmaf(w2, sw, o); o = fmaf(w3, se, o);
+                            if (!(GM_ABLATE & 4)) X[(size_t)r.w * PIPS_KIN_PAD + C + GM_TAPS * l + t] = o;
+                        }
+                    }
+                    lds_barrier();
+                }
             }
-            __syncthreads();
-            // ---- 2x2 blend of the 8x8 correlations to the 49 taps, k = ix*7 + iy (transposed, nets/pips.py:379-381)
-            const float* winf = reinterpret_cast<const float*>(smem + GM_WIN_OFF);
-            for (int idx = tid; idx < count * GM_TAPS; idx += GM_THREADS) {
-                const int j = idx / GM_TAPS, t = idx - j * GM_TAPS;
-                const int ti = t / 7, tj = t - ti * 7;
-                const int4 r = rec[j * PIPS_LEVELS + l];
-                const float wx = __int_as_float(r.y), wy = __int_as_float(r.z);
-                const float* wv = winf + j * GM_WIN_ROW + tj * 8 + ti;
-                const float e = 1.0f - wx, so = 1.0f - wy;
-                const float k128 = 0.08838834764831845f;                                  // the 1/sqrt(128) of :397 rides on the weights
-                const float w0 = __fmul_rn(__fmul_rn(so, e), k128), w1 = __fmul_rn(__fmul_rn(so, wx), k128),
-                            w2 = __fmul_rn(__fmul_rn(wy, e), k128), w3 = __fmul_rn(__fmul_rn(wy, wx), k128);
-                float o = __fmul_rn(w0, wv[0]);
-                o = fmaf(w1, wv[1], o); o = fmaf(w2, wv[8], o); o = fmaf(w3, wv[9], o);
-                if (!(GM_ABLATE & 4)) X[(size_t)r.w * PIPS_KIN_PAD + C + GM_TAPS * l + t] = o;
-            }
+#undef GM_LEVEL_OF
         }
+        if (!more) break;
     }
+#undef GM_SEL4
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -791,8 +879,11 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     }
     const int grid = max(cus / 8, 1) * 8;
     if (ev) (void)hipEventRecord(ev[2], st);
-    if (mirror != nullptr) {                     // two blocks of six waves per compute unit
-        hipLaunchKernelGGL(gather_mfma_kernel, dim3(2 * grid), dim3(GM_THREADS), GM_LDS, st, mirror, lv, ffeats, N, max_items, F,
+    if (mirror != nullptr) {                     // one persistent block of 12 product + 4 loader waves per compute unit
+        static std::atomic<unsigned long long> raised_gm{0};
+        const int rc = ensure_dynamic_lds(raised_gm, (const void*)gather_mfma_kernel, GM_LDS);
+        if (rc != PIPS_OK) return rc;
+        hipLaunchKernelGGL(gather_mfma_kernel, dim3(grid), dim3(GM_THREADS), GM_LDS, st, mirror, lv, ffeats, N, max_items, F,
                            order, items, nitems, tiles_x, X);
         if (ev) (void)hipEventRecord(ev[3], st);
         PIPS_CHECK_LAUNCH("gather_mfma_kernel");
