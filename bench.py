@@ -46,6 +46,7 @@ S, H, W, NPTS, ITERS, STRIDE = 8, 368, 496, 256, 6, 8
 PEAK_F32_MFMA_TF = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TF = 2500.0         # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (16x the fp32 MFMA rate)
 PEAK_HBM_GBS = 8000.0              # spec; 6290 measured-achievable
+MIXER_STREAM = None                # --mixer-stream f32|bf16: the bf16 legs' residual-stream type (None: the module's default)
 
 
 def respawn_under_launcher(gpus):
@@ -280,6 +281,8 @@ def config3_leg(device, world=1, rank=0, fake=False, on_device_collectives=True)
         from pips_amd import Pips
         model = Pips(S=S, stride=STRIDE).to(device).eval()
         model.mixer_dtype = model.encoder_dtype = torch.bfloat16
+        if MIXER_STREAM is not None:                            # (tuning: --mixer-stream; the default is the module's own)
+            model.mixer_stream_dtype = torch.bfloat16 if MIXER_STREAM == "bf16" else torch.float32
         xys, rgbs = make_inputs(rank, device, b)
         npts = NPTS
     sync = (lambda: None) if fake else torch.cuda.synchronize
@@ -555,10 +558,14 @@ def main(argv=None):
                     help="run ONE of the extra legs alone and print its JSON (what the rocprofv3 passes under profiles/ wrap)")
     ap.add_argument("--matmul", default="exact", choices=("exact", "split"),
                     help="config 2 only: exact-fp32 MFMA (default, the headline) or the fp32-grade split-bf16 path")
+    ap.add_argument("--mixer-stream", default=None, choices=("f32", "bf16"),
+                    help="tuning only: residual-stream type of the bf16 mixer in the config-3 legs (default: the module's own)")
     ap.add_argument("--lib", default=None, help="tuning only: bind pips_amd to this build of the library (tools/ab_c3.sh); the "
                                                 "driver's runs never pass it")
     args = ap.parse_args(argv)
     gpus = max(1, args.gpus)
+    global MIXER_STREAM
+    MIXER_STREAM = args.mixer_stream
     if args.lib:
         from pips_amd import _lib as _pl
         _pl.use_library(args.lib)
@@ -622,6 +629,8 @@ def main(argv=None):
         model = Pips(S=S, stride=STRIDE).to(device).eval()               # seeded random init (seed 0)
         if args.config == 3:
             model.mixer_dtype = model.encoder_dtype = torch.bfloat16     # BASELINE configs[2]
+            if MIXER_STREAM is not None:
+                model.mixer_stream_dtype = torch.bfloat16 if MIXER_STREAM == "bf16" else torch.float32
         model.matmul = args.matmul
         xys, rgbs = make_inputs(rank, device, b_per_gpu)
 

@@ -66,6 +66,10 @@ extern "C" {
 #define PIPS_FLAG_BF16_MIXER  2   /* bf16 MFMA operands in the channel-mix and head Linear layers (BASELINE
                                      config 3); accumulation, norms, GELU, residual stream, gather stay fp32 */
 
+#define PIPS_FLAG_BF16_STREAM 64  /* with PIPS_FLAG_BF16_MIXER (window length 8): the mixer's residual stream is a bf16 tensor, as
+                                     PreNormResidual's `fn(norm(x)) + x` is under autocast (nets/pips.py:93-100: both terms bf16) --
+                                     token mixing and the down-projections read it, add in fp32 and round once on the way out;
+                                     LayerNorm statistics, GELU and accumulation stay fp32 */
 #define PIPS_FLAG_BF16_MAPS   32  /* pips_track / pips_mixer_input_build_ex: the correlation gather reads the bf16 MIRROR of the
                                      pyramid (behind the fp32 levels, pips_pyramid_mirror_offset; written by the bf16 encoder or
                                      pips_pyramid_mirror) -- the reference's rounding point under autocast, where the encoder's

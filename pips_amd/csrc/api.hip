@@ -839,9 +839,21 @@ int pips_gemm_f32_route(int M, int N, int K, int epi) {
 // 2048-wide hidden activation stored as bf16, everything else fp32); the 544-wide input projection rides
 // 32-element K blocks (544 = 17 x 32).
 // S: the window length the arena was packed for (tokens per particle); delta rows are nout_pad(S) wide.
+// matrix mode of the mixer from the PIPS_FLAG_* word: 0 exact fp32, 1 bf16 operands, 2 split-bf16, 3 bf16 operands + bf16 residual stream
+static int mixer_mode(int flags) {
+    if (flags & PIPS_FLAG_SPLIT_BF16) return 2;
+    if (flags & PIPS_FLAG_BF16_MIXER) return (flags & PIPS_FLAG_BF16_STREAM) ? 3 : 1;
+    return 0;
+}
+
+// bf16 == 3: bf16 operands AND a bf16 residual stream (PIPS_FLAG_BF16_STREAM, S = 8): x is stored as bf16 -- written by the input
+// projection, read and rewritten by token mixing and the down-projection (whose fp32 sums take the bf16 residual and are rounded
+// once), read by the final LayerNorm; what PreNormResidual holds under autocast (nets/pips.py:93-100).
 static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, void* workspace,
                       size_t workspace_bytes, void* stream, hipEvent_t* ev, int bf16 = 0, int S = PIPS_S) {
     PIPS_CHECK_ARG(arena_v && X && delta && workspace, "mixer: null pointer");
+    const int xb = (bf16 == 3 && S == PIPS_S) ? 1 : 0;
+    if (bf16 == 3) bf16 = 1;
     PIPS_CHECK_ARG(S >= 1 && S <= PIPS_S_MAX, "mixer: S=%d outside 1..%d", S, PIPS_S_MAX);
     PIPS_CHECK_ARG(M > 0 && M % S == 0, "mixer: M=%d must be a positive multiple of S=%d", M, S);
     if (workspace_bytes < pips_mixer_workspace_bytes_s(M, S)) {
@@ -887,7 +899,7 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
     }
     if (bf16) {
         const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
-        TIMED(gemm_h(X, 0, PIPS_KIN_PAD, hw + A.h_in, arena + A.b_in, x, 0, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
+        TIMED(gemm_h(X, 0, PIPS_KIN_PAD, hw + A.h_in, arena + A.b_in, x, xb, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
                      EPI_BIAS, nullptr, 0, st));
     } else {
         TIMED(pips_gemm_f32(X, PIPS_KIN_PAD, arena + A.w_in, arena + A.b_in, x, PIPS_DMIX, M, PIPS_DMIX, PIPS_KIN_PAD,
@@ -895,13 +907,13 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
     }
     for (int d = 0; d < PIPS_DEPTH; ++d) {
         const MixLayerW& L = A.mix[d];
-        RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1, S));
+        RUN(launch_token_mix(arena, L, x, xn, P, st, bf16 == 1, S, xb));
         if (bf16) {
             const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
             TIMED(gemm_h(xn, 1, PIPS_DMIX, hw + A.h_w1[d], arena + L.b1, h, 1, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX,
                          PIPS_DMIX, EPI_GELU, nullptr, 0, st));
-            TIMED(gemm_h(h, 1, 4 * PIPS_DMIX, hw + A.h_w2[d], arena + L.b2, x, 0, PIPS_DMIX, M, PIPS_DMIX,
-                         4 * PIPS_DMIX, EPI_RESIDUAL, x, PIPS_DMIX, st));
+            TIMED(gemm_h(h, 1, 4 * PIPS_DMIX, hw + A.h_w2[d], arena + L.b2, x, xb, PIPS_DMIX, M, PIPS_DMIX,
+                         4 * PIPS_DMIX, EPI_RESIDUAL | (xb ? EPI_RES_BF16 : 0), x, PIPS_DMIX, st));
             continue;
         }
         TIMED(pips_gemm_f32(xn, PIPS_DMIX, arena + L.w1, arena + L.b1, h, 4 * PIPS_DMIX, M, 4 * PIPS_DMIX, PIPS_DMIX,
@@ -909,7 +921,7 @@ static int mixer_impl(const void* arena_v, const float* X, int M, float* delta, 
         TIMED(pips_gemm_f32(h, 4 * PIPS_DMIX, arena + L.w2, arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
                             EPI_RESIDUAL, x, PIPS_DMIX, stream));
     }
-    RUN(launch_ln_mean(x, arena + A.lnf_g, arena + A.lnf_b, pooled, P, st, S));
+    RUN(launch_ln_mean(x, arena + A.lnf_g, arena + A.lnf_b, pooled, P, st, S, xb));
     if (bf16) {
         const unsigned short* hw = reinterpret_cast<const unsigned short*>(arena + A.total);
         TIMED(gemm_h(pooled, 0, PIPS_DMIX, hw + A.h_head, arena + A.b_head, delta, 0, NOUT, P, NOUT,
@@ -939,8 +951,7 @@ int pips_mixer_fwd_x3(const void* arena_v, const float* X, int M, float* delta, 
 
 int pips_mixer_fwd_s(const void* arena_v, const float* X, int M, int S, int flags, float* delta, void* workspace,
                      size_t workspace_bytes, void* stream) {
-    return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr,
-                      (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0), S);
+    return mixer_impl(arena_v, X, M, delta, workspace, workspace_bytes, stream, nullptr, mixer_mode(flags), S);
 }
 
 int pips_mixer_fwd_timed(const void* arena_v, const float* X, int M, float* delta, void* workspace,
@@ -951,7 +962,7 @@ int pips_mixer_fwd_timed(const void* arena_v, const float* X, int M, float* delt
 int pips_mixer_fwd_timed_ex(const void* arena_v, const float* X, int M, int flags, float* delta, void* workspace,
                             size_t workspace_bytes, void* stream, float* ms_host) {
     PIPS_CHECK_ARG(ms_host != nullptr, "mixer_timed: null output");
-    const int mm = (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0);
+    const int mm = mixer_mode(flags);
     constexpr int NG = 2 * PIPS_DEPTH + 2;
     constexpr int NCAL = 8;                      // empty event pairs: the marker-to-marker overhead
     hipEvent_t ev[2 * NG], cal[2 * NCAL];
@@ -1207,7 +1218,7 @@ static int track_impl(const void* arena, const float* pyramid, int B, int T, int
         RUN(mixer_input(pyramid, B, T, H8, W8, ffeats, coords, times, N, win_start, ws + P.X, st, ws + P.mixer,
                         pips_mixer_workspace_bytes_s(M, S), -1, nullptr, S, (flags & PIPS_FLAG_BF16_MAPS) != 0));
         RUN(mixer_impl(arena, ws + P.X, M, ws + P.delta, ws + P.mixer, pips_mixer_workspace_bytes_s(M, S), stream, nullptr,
-                       (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0), S));
+                       mixer_mode(flags), S));
         RUN(launch_state_update((const float*)arena, ws + P.delta, ffeats, coords, coords0, B, N, (float)stride,
                                 out_trajs + (size_t)(it + 1) * traj_sz, it + 1 == iters ? out_vis : nullptr, st, S));
     }

@@ -198,6 +198,9 @@ int device_cus();
 
 // ---------------------------------------------------------------- GEMM / conv core
 enum Epilogue { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
+// flag in GemmArgs::epi beside EPI_RESIDUAL (bf16-operand GEMMs with a bf16 output): the residual R is bf16 as well -- the mixer's
+// residual stream under autocast (nets/pips.py:93-100 adds two bf16 tensors)
+constexpr int EPI_RES_BF16 = 0x1000;
 
 struct GemmArgs {
     const float* A;      // plain: [M][lda]; conv: NHWC input of frame 0
@@ -225,7 +228,7 @@ struct GemmArgs {
 // every bias / residual load issued before the first use, GELU on packed pairs (shared by the
 // fp32 and bf16-operand kernels; OUT_BF16 stores the tile as bf16).  The lane holds
 // C^T: acc[i][j][4g..4g+3] = C[row = i*32 + l31][col = j*32 + 8g + 4*half + 0..3].
-template <int E, bool OUT_BF16, int TM, int TN>
+template <int E, bool OUT_BF16, int TM, int TN, bool R_BF16 = false>
 __device__ __forceinline__ void epilogue_full_tile(const f32x16 (&acc)[TM][TN], const float* __restrict__ bias,
                                                    const float* __restrict__ R, int ldr, void* __restrict__ Cv,
                                                    int ldc, int row0, int col0) {
@@ -244,8 +247,15 @@ __device__ __forceinline__ void epilogue_full_tile(const f32x16 (&acc)[TM][TN], 
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    r4[j][g] = *reinterpret_cast<const float4*>(R + row * ldr + col0 + j * 32 + 8 * g);
+                for (int g = 0; g < 4; ++g) {
+                    if (R_BF16) {           // four bf16 = 8 bytes, widened to fp32
+                        const uint2 rb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(R) + row * ldr + col0 + j * 32 + 8 * g);
+                        r4[j][g] = make_float4(__uint_as_float(rb.x << 16), __uint_as_float(rb.x & 0xffff0000u),
+                                               __uint_as_float(rb.y << 16), __uint_as_float(rb.y & 0xffff0000u));
+                    } else {
+                        r4[j][g] = *reinterpret_cast<const float4*>(R + row * ldr + col0 + j * 32 + 8 * g);
+                    }
+                }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -381,10 +391,11 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
                              int S, const float* ffeats, const float* coords, const float* times, int N,
                              float* X, void* scratch, size_t scratch_bytes, hipStream_t st, hipEvent_t* ev = nullptr,
                              const unsigned short* mirror = nullptr);   // mirror: the bf16 mode's matrix-core kernel on the pyramid's bf16 mirror
+// x_bf16: the residual stream x is bf16 in memory (bf16 mixer, S = 8 only)
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
-                     hipStream_t st, int xn_bf16 = 0, int Sw = PIPS_S);
+                     hipStream_t st, int xn_bf16 = 0, int Sw = PIPS_S, int x_bf16 = 0);
 int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,
-                   hipStream_t st, int Sw = PIPS_S);
+                   hipStream_t st, int Sw = PIPS_S, int x_bf16 = 0);
 int launch_score_upsum(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int F, float* U,
                        hipStream_t st);
 int launch_score_terms(const float* U, int B, int S, int H8, int W8, const float* ffeats, int N, const float* tgt,

@@ -287,6 +287,8 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
     if (m0 + BM <= p.M && n0 + BN <= p.N && (epi != EPI_RESIDUAL || (p.ldr & 3) == 0)) {
         const int row0 = m0 + wm * WTM + l31, col0 = n0 + wn * WTN + 4 * half;
         if (epi == EPI_GELU) epilogue_full_tile<EPI_GELU, OUT_BF16, TM, TN>(acc, p.bias, p.R, p.ldr, p.C, p.ldc, row0, col0);
+        else if (epi == EPI_RESIDUAL && OUT_BF16 && (p.epi & EPI_RES_BF16))
+            epilogue_full_tile<EPI_RESIDUAL, OUT_BF16, TM, TN, true>(acc, p.bias, p.R, p.ldr, p.C, p.ldc, row0, col0);
         else if (epi == EPI_RESIDUAL) epilogue_full_tile<EPI_RESIDUAL, OUT_BF16, TM, TN>(acc, p.bias, p.R, p.ldr, p.C, p.ldc, row0, col0);
         else epilogue_full_tile<EPI_BIAS, OUT_BF16, TM, TN>(acc, p.bias, p.R, p.ldr, p.C, p.ldc, row0, col0);
         return;
@@ -310,8 +312,14 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64, (BM * BN >= 128 * 128 && WGM *
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
                 } else if (epi == EPI_RESIDUAL) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(p.R + (size_t)row * p.ldr + col);
-                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                    if (OUT_BF16 && (p.epi & EPI_RES_BF16)) {
+                        const uint2 rb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.R) + (size_t)row * p.ldr + col);
+                        v[0] += __uint_as_float(rb.x << 16); v[1] += __uint_as_float(rb.x & 0xffff0000u);
+                        v[2] += __uint_as_float(rb.y << 16); v[3] += __uint_as_float(rb.y & 0xffff0000u);
+                    } else {
+                        const float4 r4 = *reinterpret_cast<const float4*>(p.R + (size_t)row * p.ldr + col);
+                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                    }
                 }
                 if (OUT_BF16) {
                     typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -39,6 +39,9 @@ __device__ __forceinline__ unsigned t4_sgpr(unsigned v) { return (unsigned)__bui
 #define T4_LO(ptr) t4_sgpr((unsigned)(unsigned long long)reinterpret_cast<uintptr_t>(ptr))
 #define T4_HI(ptr) t4_sgpr((unsigned)((unsigned long long)reinterpret_cast<uintptr_t>(ptr) >> 32))
 
+// SB: the residual stream is bf16 -- R and C are bf16 (the reference's PreNormResidual under autocast adds two bf16 tensors,
+// nets/pips.py:93-100): the residual tile is widened into the accumulators, the result rounded once (RNE) on the way out.
+template <bool SB>
 __global__ __launch_bounds__(256) void gemm_bf16_t4_res_kernel(GemmArgs p, int tiles_n, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,11 +74,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_res_kernel(GemmArgs p, int t
     const unsigned rW0 = lds0 + T4_BM * 128 + (128 * wn + r16) * 128 + ((g ^ sw) * 16);          // + j * 2048
     const unsigned rA1 = lds0 + ((rA0 - lds0) ^ 64), rW1 = lds0 + ((rW0 - lds0) ^ 64);
     // ---- residual / output / bias: acc tile (i, j) = R[m0 + 64 wm + 16 i + r16][n0 + 128 wn + 16 j + 4 g .. + 3]
-    const float* Rb = p.R + (size_t)(m0 + 64 * wm) * p.ldr + n0 + 128 * wn;
-    const float* Cb = p.C + (size_t)(m0 + 64 * wm) * p.ldc + n0 + 128 * wn;
+    constexpr int ES = SB ? 2 : 4;                                                          // bytes per element of R and C
+    const char* Rb = reinterpret_cast<const char*>(p.R) + ((size_t)(m0 + 64 * wm) * p.ldr + n0 + 128 * wn) * ES;
+    const char* Cb = reinterpret_cast<const char*>(p.C) + ((size_t)(m0 + 64 * wm) * p.ldc + n0 + 128 * wn) * ES;
     const float* Bb = p.bias + n0 + 128 * wn;
-    const unsigned voR = (unsigned)((r16 * p.ldr + 4 * g) * 4), voC = (unsigned)((r16 * p.ldc + 4 * g) * 4), voB = (unsigned)(16 * g);
-    const unsigned rstep = (unsigned)(16 * p.ldr * 4), cstep = (unsigned)(16 * p.ldc * 4);
+    const unsigned voR = (unsigned)((r16 * p.ldr + 4 * g) * ES), voC = (unsigned)((r16 * p.ldc + 4 * g) * ES), voB = (unsigned)(16 * g);
+    const unsigned rstep = (unsigned)(16 * p.ldr * ES), cstep = (unsigned)(16 * p.ldc * ES);
     const unsigned kt = (unsigned)(p.K / T4_BK);
 #define T4_OPERANDS \
                  : [rA0] "v"(rA0), [rW0] "v"(rW0), [rA1] "v"(rA1), [rW1] "v"(rW1), [wA] "v"(wA), [wW] "v"(wW), [voA] "v"(voA), \
@@ -83,7 +87,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_res_kernel(GemmArgs p, int t
                    [wlo] "s"(T4_LO(Wb)), [whi] "s"(T4_HI(Wb)), [rlo] "s"(T4_LO(Rb)), [rhi] "s"(T4_HI(Rb)), [clo] "s"(T4_LO(Cb)), \
                    [chi] "s"(T4_HI(Cb)), [blo] "s"(T4_LO(Bb)), [bhi] "s"(T4_HI(Bb)), [passA] "s"(t4_sgpr(passA)), \
                    [passW] "s"(t4_sgpr(passW)), [rstep] "s"(t4_sgpr(rstep)), [cstep] "s"(t4_sgpr(cstep)), [kt] "s"(t4_sgpr(kt))
-    asm volatile(PIPS_T4_TEXT : T4_OPERANDS : PIPS_T4_CLOBBER);
+    if (SB) asm volatile(PIPS_T4B_TEXT : T4_OPERANDS : PIPS_T4_CLOBBER);
+    else asm volatile(PIPS_T4_TEXT : T4_OPERANDS : PIPS_T4_CLOBBER);
 #undef T4_OPERANDS
 }
 
@@ -163,7 +168,10 @@ int launch_gemm_bf16_t4up(const GemmArgs& a, int tpb, hipStream_t st) {
 // Whether the down-projection form (bf16 A, fp32 C, + bias + fp32 residual) of a bf16-operand GEMM goes to this kernel.
 bool gemm_bf16_t4_takes(const GemmArgs& a, int a_bf16, int out_bf16) {
     const int mode = PIPS_TUNE("PIPS_BF16_T4", 1);          // tuning hook: 0 = off, 2 = any tile count
-    if (!mode || !a_bf16 || out_bf16 || (a.epi & 0xff) != EPI_RESIDUAL || a.R == nullptr || a.bias == nullptr) return false;
+    // fp32 residual stream (fp32 R, fp32 C) or bf16 residual stream (EPI_RES_BF16: bf16 R, bf16 C)
+    if (!mode || !a_bf16 || (out_bf16 != 0) != ((a.epi & EPI_RES_BF16) != 0) || (a.epi & 0xff) != EPI_RESIDUAL || a.R == nullptr ||
+        a.bias == nullptr)
+        return false;
     if (a.M % T4_BM != 0 || a.N % T4_BN != 0 || a.K % T4_BK != 0 || a.K < 2 * T4_BK) return false;
     if (a.lda % 8 != 0 || a.ldc % 4 != 0 || a.ldr % 4 != 0) return false;
     if ((unsigned long long)80 * a.ldr * 4ull >= (1ull << 31) || (unsigned long long)80 * a.ldc * 4ull >= (1ull << 31)) return false;   // (buffer offsets inside a wave tile)
@@ -176,7 +184,8 @@ bool gemm_bf16_t4_takes(const GemmArgs& a, int a_bf16, int out_bf16) {
 
 int launch_gemm_bf16_t4(const GemmArgs& a, hipStream_t st) {
     const int tiles_n = a.N / T4_BN, ntiles = (a.M / T4_BM) * tiles_n;
-    hipLaunchKernelGGL(gemm_bf16_t4_res_kernel, dim3(ntiles), dim3(256), T4_LDS, st, a, tiles_n, ntiles);
+    if (a.epi & EPI_RES_BF16) hipLaunchKernelGGL(gemm_bf16_t4_res_kernel<true>, dim3(ntiles), dim3(256), T4_LDS, st, a, tiles_n, ntiles);
+    else hipLaunchKernelGGL(gemm_bf16_t4_res_kernel<false>, dim3(ntiles), dim3(256), T4_LDS, st, a, tiles_n, ntiles);
     PIPS_CHECK_LAUNCH("gemm_bf16_t4_res_kernel");
     return PIPS_OK;
 }

@@ -622,6 +622,9 @@ typedef __bf16 bf16x8_tm __attribute__((ext_vector_type(8)));
 // -2.4 % on the bf16 mixer pass.  TWO waves per particle (half the tile and ~120 registers per wave, four waves per SIMD, the
 // LayerNorm halves meeting in LDS) was built and measured: +2 % with the 12-register spill of a 128-register budget, the same as
 // one wave per particle when held to three waves per SIMD (profiles/r4_probe_token_mix_bf16_variants.txt) -- not kept.
+// XB: the residual stream x is bf16 in memory (round 5: what the reference's PreNormResidual holds under autocast, nets/pips.py:93-100;
+// 84 -> 50 MB per launch at 2048 particles); all arithmetic stays fp32, the new stream is rounded once (RNE) on the way out.
+template <bool XB>
 __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __restrict__ arena, MixLayerW L, float* __restrict__ x,
                                                                 unsigned* __restrict__ xn, int particles) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -630,13 +633,19 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
     if (p >= particles) return;
     // ---- the particle's tile first: its 16 loads are the long ones (HBM / Infinity Cache), the weights below hit L2
     float* xp = x + ((size_t)p * S + 4 * half) * PIPS_DMIX + 4 * l31;         // + r * 512 + g * 128
+    unsigned short* xh = reinterpret_cast<unsigned short*>(x) + ((size_t)p * S + 4 * half) * PIPS_DMIX + 4 * l31;   // the same elements of a bf16 stream
     float xv[4][16];                                                          // [token r][g * 4 + q]
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4*>(xp + r * PIPS_DMIX + g * 128);
-            xv[r][4 * g] = v.x; xv[r][4 * g + 1] = v.y; xv[r][4 * g + 2] = v.z; xv[r][4 * g + 3] = v.w;
+            if (XB) {
+                const uint2 v = *reinterpret_cast<const uint2*>(xh + r * PIPS_DMIX + g * 128);
+                xv[r][4 * g] = bf16_lo(v.x); xv[r][4 * g + 1] = bf16_hi(v.x); xv[r][4 * g + 2] = bf16_lo(v.y); xv[r][4 * g + 3] = bf16_hi(v.y);
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(xp + r * PIPS_DMIX + g * 128);
+                xv[r][4 * g] = v.x; xv[r][4 * g + 1] = v.y; xv[r][4 * g + 2] = v.z; xv[r][4 * g + 3] = v.w;
+            }
         }
     // ---- weights as MFMA A fragments
     uint4 a1, a2[2];
@@ -732,8 +741,16 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
         // the new residual stream of these 128 channels goes out while the next group is computed (all waves of the
         // launch run in one round, in lock-step: stores held back to the end would queue behind one another)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<float4*>(xp + r * PIPS_DMIX + g * 128) = make_float4(xv[r][4 * g], xv[r][4 * g + 1], xv[r][4 * g + 2], xv[r][4 * g + 3]);
+        for (int r = 0; r < 4; ++r) {
+            if (XB) {
+                // the stored stream is what every later reader sees: LayerNorm 2 below works on the ROUNDED values too
+                const uint2 o = make_uint2(pack2_bf16(xv[r][4 * g], xv[r][4 * g + 1]), pack2_bf16(xv[r][4 * g + 2], xv[r][4 * g + 3]));
+                *reinterpret_cast<uint2*>(xh + r * PIPS_DMIX + g * 128) = o;
+                xv[r][4 * g] = bf16_lo(o.x); xv[r][4 * g + 1] = bf16_hi(o.x); xv[r][4 * g + 2] = bf16_lo(o.y); xv[r][4 * g + 3] = bf16_hi(o.y);
+            } else {
+                *reinterpret_cast<float4*>(xp + r * PIPS_DMIX + g * 128) = make_float4(xv[r][4 * g], xv[r][4 * g + 1], xv[r][4 * g + 2], xv[r][4 * g + 3]);
+            }
+        }
     }
     ln_stats(xv, mean, rstd);
     unsigned* xnp = xn + ((size_t)p * S + 4 * half) * (PIPS_DMIX / 2) + 2 * l31;
@@ -865,12 +882,16 @@ static int launch_token_mix_any(const float* arena, const MixLayerW& L, float* x
 }
 
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
-                     hipStream_t st, int xn_bf16, int Sw) {
+                     hipStream_t st, int xn_bf16, int Sw, int x_bf16) {
+    PIPS_CHECK_ARG(!x_bf16 || (xn_bf16 && Sw == PIPS_S), "token_mix: a bf16 residual stream needs the bf16 mixer and S = %d", PIPS_S);
     if (Sw != PIPS_S)
         return launch_token_mix_any<PIPS_S_MAX>(arena, L, x, xn, particles, st, xn_bf16, Sw);
-    if (xn_bf16 && PIPS_TUNE("PIPS_TOKEN_MFMA", 1)) {
+    if (xn_bf16 && (x_bf16 || PIPS_TUNE("PIPS_TOKEN_MFMA", 1))) {
         // bf16-operand mixer: token MLP on the matrix cores, one wave per particle
-        hipLaunchKernelGGL(token_mix_mfma_kernel, dim3(cdiv(particles, 4)), dim3(256), 0, st, arena, L, x, reinterpret_cast<unsigned*>(xn), particles);
+        if (x_bf16)
+            hipLaunchKernelGGL(token_mix_mfma_kernel<true>, dim3(cdiv(particles, 4)), dim3(256), 0, st, arena, L, x, reinterpret_cast<unsigned*>(xn), particles);
+        else
+            hipLaunchKernelGGL(token_mix_mfma_kernel<false>, dim3(cdiv(particles, 4)), dim3(256), 0, st, arena, L, x, reinterpret_cast<unsigned*>(xn), particles);
         PIPS_CHECK_LAUNCH("token_mix_mfma_kernel");
         return PIPS_OK;
     }
@@ -884,14 +905,19 @@ int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn
 
 // ------------------------------------------------------------------------ final LN + mean
 // nn.LayerNorm(512) then Reduce('b n c -> b c','mean') (nets/pips.py:120-121).
+template <bool XB>           // XB: x is the bf16 residual stream
 __global__ __launch_bounds__(256) void ln_mean_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                       const float* __restrict__ bta, float* __restrict__ out) {
     __shared__ float red[4][S];
     const float* xp = x + (size_t)blockIdx.x * S * PIPS_DMIX;
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(x) + (size_t)blockIdx.x * S * PIPS_DMIX;
     const int c0 = threadIdx.x, c1 = threadIdx.x + 256;
     float x0[S], x1[S], mean[S], rstd[S];
 #pragma unroll
-    for (int t = 0; t < S; ++t) { x0[t] = xp[t * PIPS_DMIX + c0]; x1[t] = xp[t * PIPS_DMIX + c1]; }
+    for (int t = 0; t < S; ++t) {
+        if (XB) { x0[t] = __uint_as_float((unsigned)xh[t * PIPS_DMIX + c0] << 16); x1[t] = __uint_as_float((unsigned)xh[t * PIPS_DMIX + c1] << 16); }
+        else { x0[t] = xp[t * PIPS_DMIX + c0]; x1[t] = xp[t * PIPS_DMIX + c1]; }
+    }
     ln_stats(x0, x1, mean, rstd, red);
     const float g0 = g[c0], g1 = g[c1], b0 = bta[c0], b1 = bta[c1];
     float a0 = 0.f, a1 = 0.f;
@@ -924,13 +950,15 @@ __global__ __launch_bounds__(256) void ln_mean_any_kernel(const float* __restric
 }
 
 int launch_ln_mean(const float* x, const float* g, const float* b, float* out, int particles,
-                   hipStream_t st, int Sw) {
+                   hipStream_t st, int Sw, int x_bf16) {
+    PIPS_CHECK_ARG(!x_bf16 || Sw == PIPS_S, "ln_mean: a bf16 residual stream needs S = %d", PIPS_S);
     if (Sw != PIPS_S) {
         hipLaunchKernelGGL(ln_mean_any_kernel<PIPS_S_MAX>, dim3(particles), dim3(256), 0, st, x, g, b, out, Sw);
         PIPS_CHECK_LAUNCH("ln_mean_any_kernel");
         return PIPS_OK;
     }
-    hipLaunchKernelGGL(ln_mean_kernel, dim3(particles), dim3(256), 0, st, x, g, b, out);
+    if (x_bf16) hipLaunchKernelGGL(ln_mean_kernel<true>, dim3(particles), dim3(256), 0, st, x, g, b, out);
+    else hipLaunchKernelGGL(ln_mean_kernel<false>, dim3(particles), dim3(256), 0, st, x, g, b, out);
     PIPS_CHECK_LAUNCH("ln_mean_kernel");
     return PIPS_OK;
 }

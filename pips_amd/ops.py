@@ -216,13 +216,23 @@ def score_map_terms(pyr, B, H8, W8, ffeats, tgt):
     return out
 
 
-def mixer_fwd(arena, X, bf16=False, split=False, S=8):
+def mixer_fwd(arena, X, bf16=False, split=False, S=8, stream_bf16=False):
     """X (M,544) -> delta (M/S, S*130).  bf16: bf16 MFMA operands in the channel-mix/head GEMMs;
     split: every GEMM on the fp32-grade split-bf16 path.  S != 8 (arena packed for that S):
-    pips_mixer_fwd_s, whose rows are pips_delta_stride(S) apart (cut back to S*130 here)."""
+    pips_mixer_fwd_s, whose rows are pips_delta_stride(S) apart (cut back to S*130 here).
+    stream_bf16 (with bf16, S = 8): the residual stream is a bf16 tensor (PIPS_FLAG_BF16_STREAM)."""
     lib = _lib.load()
     X = _f32(X)
     M = X.shape[0]
+    if stream_bf16:
+        assert bf16 and S == 8 and not split
+        delta = torch.empty(M // S, NOUT, dtype=torch.float32, device=X.device)
+        nb = lib.pips_mixer_workspace_bytes(M)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
+        with torch.cuda.device(X.device):
+            _lib.check(lib.pips_mixer_fwd_s(_lib.ptr(arena), _lib.ptr(X), M, 8, 2 | 64, _lib.ptr(delta), _lib.ptr(ws), nb, _stream()),
+                       "pips_mixer_fwd_s")
+        return delta
     if S != 8:
         ld = lib.pips_delta_stride(int(S))
         delta = torch.empty(M // S, ld, dtype=torch.float32, device=X.device)
@@ -334,6 +344,10 @@ def gemm_bf16(A, W, bias=None, epi=0, R=None, out_bf16=False):
     M, K = A.shape
     N = W.shape[0]
     Cm = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=A.device)
+    if R is not None and R.dtype == torch.bfloat16:      # a bf16 residual (with a bf16 output): the mixer's bf16 residual stream
+        assert out_bf16 and epi == 2
+        epi = epi | 0x1000
+        R = R.contiguous()
     with torch.cuda.device(A.device):
         _lib.check(lib.pips_gemm_bf16(_lib.ptr(A), int(A.dtype == torch.bfloat16), K, _lib.ptr(W), _lib.ptr(bias), _lib.ptr(Cm),
                                       int(out_bf16), N, M, N, K, epi, _lib.ptr(R), N if R is not None else 0, _stream()),

@@ -74,3 +74,41 @@ def test_config3_geometry_against_bf16_autocast_oracle(weights_tamed):
     d = float((solo - preds[-1][:1]).abs().max())
     print(f"B=8 (assembly GEMMs) vs B=1 (register-staged GEMMs), clip 0: {d:.2e} px")
     assert d < 2e-2
+
+
+def test_config3_geometry_bf16_residual_stream(weights_tamed):
+    """The same geometry with the mixer's residual stream held as bf16 (Pips.mixer_stream_dtype = torch.bfloat16,
+    PIPS_FLAG_BF16_STREAM): what PreNormResidual's `fn(norm(x)) + x` is under autocast (nets/pips.py:93-100).  Same gate as the
+    fp32-stream form against the autocast oracle (2e-2 px), both distances printed; the down-projections must reach the
+    assembly kernel's bf16-stream form."""
+    from oracle import pips_oracle as O
+    from pips_amd import Pips, _lib
+    assert _lib.load().pips_gemm_bf16_route(B * N * S, 512, 2048, 2 | 0x1000, 1, 1) == 3
+    xys, rgbs = _inputs()
+    m = Pips(S=8, stride=8)
+    m.load_state_dict(weights_tamed)
+    m = m.to(DEV).eval()
+    m.mixer_dtype = m.encoder_dtype = torch.bfloat16
+    res = {}
+    for name, dt in (("fp32 stream", torch.float32), ("bf16 stream", torch.bfloat16)):
+        m.mixer_stream_dtype = dt
+        preds, _, vis, _ = m(xys.to(DEV), rgbs.to(DEV), iters=ITERS)
+        res[name] = ([p.cpu() for p in preds], vis.cpu())
+    e = {k: [0.0, 0.0, 0.0] for k in res}
+    for b in range(4):                                                    # four of the eight clips: bounded CPU time
+        xb, rb = xys[b:b + 1], rgbs[b:b + 1]
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ref_bf, _, vis_bf, _ = O.forward(weights_tamed, xb, rb, iters=ITERS, stride=8)
+        ref_32 = O.forward(weights_tamed, xb, rb, iters=ITERS, stride=8)[0] if b < 2 else None
+        for k, (preds, vis) in res.items():
+            for it in range(ITERS):
+                e[k][0] = max(e[k][0], float((preds[it][b:b + 1] - ref_bf[it].float()).abs().max()))
+                if ref_32 is not None:
+                    e[k][1] = max(e[k][1], float((preds[it][b:b + 1] - ref_32[it]).abs().max()))
+            e[k][2] = max(e[k][2], float((vis[b:b + 1] - vis_bf.float()).abs().max()))
+    d = max(float((a - c).abs().max()) for a, c in zip(res["fp32 stream"][0], res["bf16 stream"][0]))
+    for k in res:
+        print(f"config 3 geometry, {k}: vs bf16-autocast oracle {e[k][0]:.2e} px (vis logits {e[k][2]:.2e}), vs fp32 oracle {e[k][1]:.2e} px")
+    print(f"fp32 stream vs bf16 stream: {d:.2e} px")
+    assert e["bf16 stream"][0] < 2e-2 and e["bf16 stream"][1] < 2e-2 and e["bf16 stream"][2] < 0.15
+

@@ -642,6 +642,53 @@ def test_gemm_bf16(M, N, K, epi, out_bf16):
         assert float((out - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 512, 2048), (8192, 512, 2048), (32896, 256, 128), (2048, 512, 2048), (1000, 384, 96)])
+def test_gemm_bf16_residual_stream(M, N, K):
+    """The down-projection with a bf16 residual stream (EPI_RES_BF16: bf16 R, bf16 C -- nets/pips.py:93-100 under autocast): the
+    four-wave assembly kernel's second form (first three shapes) and the register-staged kernel (last two, one with ragged tiles)
+    against fp32 arithmetic on the same bf16 operands, rounded once: within half a bf16 ulp of the fp64 result (+ fp32 sum noise)."""
+    from pips_amd import ops, _lib
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    A = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV).bfloat16()
+    b = torch.randn(N, generator=g).to(DEV)
+    R = (torch.randn(M, N, generator=g) * 3.0).to(DEV).bfloat16()
+    out = ops.gemm_bf16(A, W, b, epi=2, R=R, out_bf16=True)
+    assert out.dtype == torch.bfloat16
+    ref = A.double() @ W.double().t() + b.double() + R.double()
+    err = (out.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -8 + 2e-5).all()), float((err / (ref.abs() + 1e-2)).max())
+    route = _lib.load().pips_gemm_bf16_route(M, N, K, 2 | 0x1000, 1, 1)
+    assert route == (3 if M >= 8192 else 0)
+
+
+@pytest.mark.parametrize("P", [256, 2048])
+def test_mixer_bf16_residual_stream(P, weights_raw, arenas):
+    """PIPS_FLAG_BF16_STREAM: the bf16 mixer with its residual stream stored as bf16 (rounded once per residual add).  Against the
+    oracle's mixer under torch.autocast(bfloat16) -- whose PreNormResidual holds a bf16 stream too -- it must be no further away
+    than the fp32-stream form is, within slack; and it stays at bf16-level distance from the fp32 oracle."""
+    from pips_amd import ops
+    O = _oracle()
+    g = torch.Generator().manual_seed(P + 3)
+    x = torch.randn(min(P, 256), 8, 519, generator=g)
+    if P > 256:
+        x = x.repeat(P // 256, 1, 1) + 0.01 * torch.randn(P, 8, 519, generator=g)
+    ref32 = O.mixer(weights_raw, x)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        refbf = O.mixer(weights_raw, x).float()
+    X = torch.zeros(P * 8, 544)
+    X[:, :519] = x.reshape(P * 8, 519)
+    a = ops.mixer_fwd(arenas["raw"], X.to(DEV), bf16=True).cpu()
+    b = ops.mixer_fwd(arenas["raw"], X.to(DEV), bf16=True, stream_bf16=True).cpu()
+    scale = max(1.0, float(ref32.abs().max()))
+    ref32, refbf = ref32.reshape(a.shape), refbf.reshape(a.shape)
+    e = lambda u, v: float((u - v).abs().max()) / scale
+    print(f"bf16 mixer P={P}: fp32 stream vs autocast oracle {e(a, refbf):.2e}, bf16 stream vs autocast oracle {e(b, refbf):.2e}; "
+          f"vs fp32 oracle {e(a, ref32):.2e} / {e(b, ref32):.2e}; autocast oracle vs fp32 oracle {e(refbf, ref32):.2e}; the two forms {e(a, b):.2e}")
+    assert torch.isfinite(b).all()
+    assert e(b, refbf) < 1.5 * e(a, refbf) + 5e-3 and e(b, ref32) < 3e-2
+
+
 @pytest.mark.parametrize("P", [32, 256, 2048])
 def test_mixer_bf16_operands(P, weights_raw, arenas):
     """bf16 MFMA operands (config 3): against the fp32 oracle at bf16-level tolerance, and much

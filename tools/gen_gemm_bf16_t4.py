@@ -159,7 +159,10 @@ def iteration_single(e):
             frag_read(e, 0, *FRAG_ORDER[f])
 
 
-def body():
+def body(stream_bf16=False):
+    """stream_bf16: the residual R and the output C are bf16 (the mixer's residual stream under autocast) -- the residual tile is
+    loaded as 8-byte pieces into the (still free) fragment registers and widened into the accumulators behind the first barrier;
+    the epilogue rounds to bf16 (v_cvt_pk_bf16_f32, RNE) and stores 8-byte pieces."""
     e = Emit()
     descriptor(e, RS_A, "%[alo]", "%[ahi]")
     descriptor(e, RS_W, "%[wlo]", "%[whi]")
@@ -187,14 +190,31 @@ def body():
     for j in range(8):
         for i in range(4):
             c = acc(i, j)
-            e.vmem("buffer_load_dwordx4 a[%d:%d], %%[voR], s[%d:%d], s%d offen offset:%d" % (c, c + 3, RS_R, RS_R + 3, S_RR + i, 64 * j),
-                   ("res", i, j))
+            if stream_bf16:       # 4 bf16 = 8 bytes -> v[2 t : 2 t + 1], t = i + 4 j (the fragment registers are free until the barrier)
+                t = i + 4 * j
+                e.vmem("buffer_load_dwordx2 v[%d:%d], %%[voR], s[%d:%d], s%d offen offset:%d" % (2 * t, 2 * t + 1, RS_R, RS_R + 3, S_RR + i, 32 * j),
+                       ("res", i, j))
+            else:
+                e.vmem("buffer_load_dwordx4 a[%d:%d], %%[voR], s[%d:%d], s%d offen offset:%d" % (c, c + 3, RS_R, RS_R + 3, S_RR + i, 64 * j),
+                       ("res", i, j))
     for s in range(12):
         store_piece(e, s)
     e.raw("s_min_u32 s%d, 128, s%d" % (S_SO, S_LAST))
     for s in range(12):
         load_piece(e, s, "s%d" % S_SO)
     e.barrier()
+    if stream_bf16:
+        # widen the residual tile into the accumulators before the fragment reads take its registers (bf16 -> fp32 = a shift / a mask)
+        e.need_vm({("res", i, j) for i in range(4) for j in range(8)})
+        for j in range(8):
+            for i in range(4):
+                c, t = acc(i, j), i + 4 * j
+                e.raw("v_lshlrev_b32 v%d, 16, v%d" % (64, 2 * t))
+                e.raw("v_and_b32 v%d, 0xffff0000, v%d" % (65, 2 * t))
+                e.raw("v_lshlrev_b32 v%d, 16, v%d" % (66, 2 * t + 1))
+                e.raw("v_and_b32 v%d, 0xffff0000, v%d" % (67, 2 * t + 1))
+                for q in range(4):
+                    e.raw("v_accvgpr_write_b32 a%d, v%d" % (c + q, 64 + q))
     for which, idx in FRAG_ORDER:
         frag_read(e, 0, which, idx)
     e.need_vm({("res", i, j) for i in range(4) for j in range(8)})
@@ -226,8 +246,14 @@ def body():
                 e.raw("v_accvgpr_read_b32 v%d, a%d" % (r + q, c + q))
             e.raw("v_pk_add_f32 v[%d:%d], v[%d:%d], v[%d:%d]" % (r, r + 1, r, r + 1, 4 * j, 4 * j + 1))
             e.raw("v_pk_add_f32 v[%d:%d], v[%d:%d], v[%d:%d]" % (r + 2, r + 3, r + 2, r + 3, 4 * j + 2, 4 * j + 3))
-            e.vmem("buffer_store_dwordx4 v[%d:%d], %%[voC], s[%d:%d], s%d offen offset:%d" % (r, r + 3, RS_C, RS_C + 3, S_CR + i, 64 * j),
-                   ("out", i, j))
+            if stream_bf16:
+                e.raw("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (r, r, r + 1))
+                e.raw("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (r + 1, r + 2, r + 3))
+                e.vmem("buffer_store_dwordx2 v[%d:%d], %%[voC], s[%d:%d], s%d offen offset:%d" % (r, r + 1, RS_C, RS_C + 3, S_CR + i, 32 * j),
+                       ("out", i, j))
+            else:
+                e.vmem("buffer_store_dwordx4 v[%d:%d], %%[voC], s[%d:%d], s%d offen offset:%d" % (r, r + 3, RS_C, RS_C + 3, S_CR + i, 64 * j),
+                       ("out", i, j))
         if j >= 1:
             e.need_vm({("out", i, j - 1) for i in range(4)})   # the other register set is free again
     e.raw("s_waitcnt vmcnt(0)")
@@ -239,8 +265,8 @@ def main():
            ['"s%d"' % i for i in range(40, 76)]
     with open(OUT, "w") as f:
         f.write("// generated by tools/gen_gemm_bf16_t4.py -- do not edit\n")
-        for name in ("PIPS_T4_TEXT",):
-            lines = body()
+        for name in ("PIPS_T4_TEXT", "PIPS_T4B_TEXT"):
+            lines = body(stream_bf16=name == "PIPS_T4B_TEXT")
             f.write("#define %s \\\n" % name)
             for ln in lines:
                 f.write('    "%s\\n\\t" \\\n' % ln)
