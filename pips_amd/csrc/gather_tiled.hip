@@ -520,7 +520,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
 //     product wave issues no load at all (its stores are never waited for) and a loader wave nothing but loads;
 //   * an item's pixel blocks -- the region of each level cut into blocks of 8 x 4 pixels = the 32 rows of one MFMA -- form ONE
 //     sequence of chunks of four blocks (32 KiB: all 128 channels) over the four levels; in step s the loaders write chunk s + 1
-//     (requested two steps earlier; slots outside the region as zeros) into stage buffer (s + 1) & 1 and request chunk s + 3,
+//     (requested two steps earlier) into stage buffer (s + 1) & 1 and request chunk s + 3,
 //     the product waves work on chunk s out of buffer s & 1; ONE barrier per step.  256-byte rows with the 16-byte chunk index
 //     XORed with (row & 15): fragment reads and staging writes are conflict-free;
 //   * B operand (features): the loaders convert the item's features fp32 -> bf16 (RNE) into LDS once per item; a product wave
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                     }                                                                                                           \
                 }
                 const int ldsA = (ltid >> 4) * 256 + (((ltid & 15) ^ ((ltid >> 4) & 15)) << 4);      // row i (and i + 16: same swizzle), chunk c
-                uint4 preA[GM_PIECES], preB[GM_PIECES], preC[GM_PIECES];   // chunks 3 k, 3 k + 1, 3 k + 2: three requests in flight
+                uint4 preA[GM_PIECES], preB[GM_PIECES];                    // chunks 2 k, 2 k + 1: two requests in flight (a third set of 32 registers spills)
                 GM_REQUEST(0, preA)                                      // (first in the queue: what the first step needs)
                 // (order: everything that depends on nothing but the entry first -- the map chunk above, the records, the six
                 //  feature-row indices -- then the feature rows, which need the indices: two memory round trips, not one per batch)
@@ -694,23 +694,19 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                     }
                 }
                 if (nchunks > 1) GM_REQUEST(1, preB)                     // (after the features: register budget of a 16-wave block)
-                if (nchunks > 2) GM_REQUEST(2, preC)
                 if ((ltid >> 2) >= count) r0 = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);
                 if (((ltid + GM_LTHREADS) >> 2) >= count) r1 = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);
                 rec[ltid] = r0;
                 if (ltid + GM_LTHREADS < GMAX * PIPS_LEVELS) rec[ltid + GM_LTHREADS] = r1;
                 GM_DELIVER(0, preA)
-                if (nchunks > 3) GM_REQUEST(3, preA)
+                if (nchunks > 2) GM_REQUEST(2, preA)
                 lds_barrier();                                           // (A) records, features and chunk 0 are in LDS
-                // step s: deliver chunk s + 1 (requested three steps earlier), request chunk s + 4 into its registers
-                for (int s = 0; s <= nchunks; s += 3) {
-                    if (s + 1 < nchunks) { GM_DELIVER(s + 1, preB) if (s + 4 < nchunks) GM_REQUEST(s + 4, preB) }
+                // step s: deliver chunk s + 1 (requested two steps earlier), request chunk s + 3 into its registers
+                for (int s = 0; s <= nchunks; s += 2) {
+                    if (s + 1 < nchunks) { GM_DELIVER(s + 1, preB) if (s + 3 < nchunks) GM_REQUEST(s + 3, preB) }
                     lds_barrier();
                     if (s + 1 > nchunks) break;
-                    if (s + 2 < nchunks) { GM_DELIVER(s + 2, preC) if (s + 5 < nchunks) GM_REQUEST(s + 5, preC) }
-                    lds_barrier();
-                    if (s + 2 > nchunks) break;
-                    if (s + 3 < nchunks) { GM_DELIVER(s + 3, preA) if (s + 6 < nchunks) GM_REQUEST(s + 6, preA) }
+                    if (s + 2 < nchunks) { GM_DELIVER(s + 2, preA) if (s + 4 < nchunks) GM_REQUEST(s + 4, preA) }
                     lds_barrier();
                 }
 #undef GM_REQUEST

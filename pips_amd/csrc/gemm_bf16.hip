@@ -364,11 +364,11 @@ static int pick_tile(const GemmArgs& a, hipStream_t st) {
     const long b128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const long b64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
     if (a.K % 64 != 0) {                        // K % 32 == 0: the 544-wide input projection, 32-element K blocks
-        if constexpr (!A_BF16 && !OUT_BF16) {
-            if (b128 >= 400) return launch_bf16_tile<128, 128, 2, 2, 1, false, false, 32>(a, st);
-            return launch_bf16_tile<64, 64, 2, 2, 1, false, false, 32>(a, st);
+        if constexpr (!A_BF16) {                // (bf16 C: the input projection of a mixer with a bf16 residual stream)
+            if (b128 >= 400) return launch_bf16_tile<128, 128, 2, 2, 1, false, OUT_BF16, 32>(a, st);
+            return launch_bf16_tile<64, 64, 2, 2, 1, false, OUT_BF16, 32>(a, st);
         } else {
-            set_error("gemm_bf16: K=%d needs fp32 A and fp32 C (32-element K blocks)", a.K);
+            set_error("gemm_bf16: K=%d needs fp32 A (32-element K blocks)", a.K);
             return PIPS_E_ARG;
         }
     }

@@ -79,9 +79,10 @@ class Pips(nn.Module):
         # ``torch.autocast("cuda", dtype=torch.bfloat16)``, the way the reference would be run in bf16.
         self.mixer_dtype = torch.float32
         self.encoder_dtype = torch.float32          # same switch for the encoder's 3x3 / 1x1 convolutions
-        # torch.bfloat16 (with a bf16 mixer, S = 8): the mixer's residual stream is a bf16 tensor, as PreNormResidual's is under
-        # autocast (nets/pips.py:93-100) -- PIPS_FLAG_BF16_STREAM; torch.float32 keeps it fp32 (rounds 1-4)
-        self.mixer_stream_dtype = torch.float32
+        # residual stream of the bf16 mixer (S = 8).  None (default): follows the mixer -- a bf16 mixer holds a bf16 stream, as
+        # PreNormResidual's `fn(norm(x)) + x` does under autocast (nets/pips.py:93-100; PIPS_FLAG_BF16_STREAM; round 5: 1.4e-2 px
+        # against the autocast oracle at BASELINE configs[2], the fp32 stream 1.5e-2).  torch.float32 keeps it fp32 (rounds 1-4).
+        self.mixer_stream_dtype = None
         # "exact": fp32 MFMA (products and sums bitwise an fmaf chain).  "split": the fp32-grade
         # split-bf16 matrix path (PIPS_FLAG_SPLIT_BF16: three exact bf16 terms per fp32 operand, six
         # bf16 products per fp32 product, fp32 accumulation) -- same accuracy class, ~1.2x faster.
@@ -149,7 +150,7 @@ class Pips(nn.Module):
             raise ValueError(f"Pips.matmul must be 'exact' or 'split', not {self.matmul!r}")
         bf = (2 if ac or self.mixer_dtype == torch.bfloat16 else 0) | \
              (4 if ac or self.encoder_dtype == torch.bfloat16 else 0)     # PIPS_FLAG_BF16_MIXER | _ENCODER
-        if (bf & 2) and self.S == 8 and self.mixer_stream_dtype == torch.bfloat16:
+        if (bf & 2) and self.S == 8 and self.mixer_stream_dtype in (None, torch.bfloat16):
             bf |= 64                                                      # PIPS_FLAG_BF16_STREAM
         if bf and self.matmul == "split" and not self._warned_precedence:
             # a bf16 request (autocast or mixer_dtype / encoder_dtype) wins over matmul="split": say so once

@@ -1,0 +1,6 @@
+#!/bin/sh
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
+timeout 600 python -m pytest tests -m gpu -x -q -k "mfma or bf16_matrix" 2>&1 | tail -2
+timeout 300 python -u tools/gather_c4.py 2>&1 | grep -v amdgpu | tee $O/r5c15_gather.txt
+sh tools/gather_pmc.sh gpurun_out/r5c15_gather_mfma_pmc.txt bf16 FETCH_SIZE WRITE_SIZE TCC_HIT_sum:TCC_MISS_sum:TCC_REQ_sum > /dev/null 2>&1
+cat gpurun_out/r5c15_gather_mfma_pmc.txt
