@@ -81,7 +81,7 @@ class Pips(nn.Module):
         self.encoder_dtype = torch.float32          # same switch for the encoder's 3x3 / 1x1 convolutions
         # residual stream of the bf16 mixer (S = 8).  None (default): follows the mixer -- a bf16 mixer holds a bf16 stream, as
         # PreNormResidual's `fn(norm(x)) + x` does under autocast (nets/pips.py:93-100; PIPS_FLAG_BF16_STREAM; round 5: 1.4e-2 px
-        # against the autocast oracle at BASELINE configs[2], the fp32 stream 1.5e-2).  torch.float32 keeps it fp32 (rounds 1-4).
+        # against the reference arithmetic under autocast at BASELINE configs[2], the fp32 stream 1.5e-2).  torch.float32 keeps it fp32 (rounds 1-4).
         self.mixer_stream_dtype = None
         # "exact": fp32 MFMA (products and sums bitwise an fmaf chain).  "split": the fp32-grade
         # split-bf16 matrix path (PIPS_FLAG_SPLIT_BF16: three exact bf16 terms per fp32 operand, six
