@@ -544,16 +544,27 @@ constexpr int GM_WIN_ROW = 65;                    // floats per particle window:
 constexpr int GM_WIN_BYTES = GMAX * GM_WIN_ROW * 4;
 constexpr int GM_WIN_OFF = 2 * GM_STAGE + 128;    // (the scatter's per-lane base may lie up to 108 bytes below a particle's window)
 constexpr int GM_REC_OFF = GM_WIN_OFF + 2 * GM_WIN_BYTES;
-constexpr int GM_FEAT_OFF = GM_REC_OFF + GMAX * PIPS_LEVELS * 16;
+constexpr int GM_FEAT_OFF = GM_REC_OFF + 2 * GMAX * PIPS_LEVELS * 16;      // (two record buffers: item parity)
 constexpr int GM_ENTS = 64;                       // work-item entries looked up at a time
 constexpr int GM_ENT_OFF = GM_FEAT_OFF + GMAX * C * 2;
-constexpr int GM_LDS = GM_ENT_OFF + GM_ENTS * 16;
+constexpr int GM_DUMMY_OFF = GM_ENT_OFF + GM_ENTS * 16;          // 256 bytes: where the scatter's out-of-window values go
+constexpr int GM_LDS = GM_DUMMY_OFF + 256;
 constexpr int GM_TAPS = 49;                       // (2 r + 1)^2 taps per level (PIPS_NCORR = 4 x 49 is a mixer row's whole correlation block)
 constexpr int GM_PIECES = GM_CHUNK * 32 * 16 / GM_LTHREADS;                        // 16-byte pieces per loader thread and chunk (8)
 static_assert(GM_PB * GM_CHUNK == GM_PWAVES && GM_CHUNK * 32 * 16 % GM_LTHREADS == 0, "wave <-> (particle block, block of the chunk)");
 static_assert(GM_LDS <= 160 * 1024 && GM_WIN_OFF % 16 == 0 && GM_REC_OFF % 16 == 0 && GM_FEAT_OFF % 16 == 0, "LDS layout");
 
 typedef __bf16 bf16x8_gm __attribute__((ext_vector_type(8)));
+#ifdef GM_TRACE          // tuning builds (tools/gm_trace.py): time stamps of waves 0 (product) and 12 (loader) of blocks 0 and 1
+__device__ unsigned long long* g_gm_trace;
+constexpr int GM_TRN = 8192;
+#define GM_T(tag_) do { if (trp && tn < GM_TRN) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) trp[tn] = (t_ << 8) | (unsigned)(tag_); ++tn; } } while (0)
+#else
+#define GM_T(tag_) do { } while (0)
+#endif
+#ifndef GM_ROLE
+#define GM_ROLE 0       // compile-time probe of one role's register use: 1 loader only, 2 product only
+#endif
 #ifndef GM_ABLATE
 #define GM_ABLATE 0      // debugging builds only: 1 no map loads, 2 no products / scatter, 4 no stores, 8 no feature loads, 16 items only
 #endif
@@ -569,6 +580,27 @@ __device__ __forceinline__ void gm_level_geom(int l, int tx, int ty, int Wl, int
     const int nbx = (RW + 7) >> 3, nblk = nbx * ((RH + 3) >> 2);
     P = x0 | (y0 << 16);
     Q = RW | (RH << 8) | (nbx << 16) | (nblk << 24);
+}
+
+// per-level geometry of a work item (wave-uniform; named scalars and packed fields, selected by ternaries: an array indexed by the
+// run-time level goes to scratch -- and so does a lambda's closure); a level's blocks fill whole chunks.  f < 0: no item
+struct GmGeo { int first, count, f, P0, P1, P2, P3, Q0, Q1, Q2, Q3, cs1, cs2, cs3, nchunks; };
+__device__ __forceinline__ GmGeo gm_geo(const int4* ent, int it, int tiles_x, int W0, int W1, int W2, int W3, int H0, int H1, int H2, int H3) {
+    GmGeo G;
+    const int4 ev = ent[min(it, GM_ENTS - 1)];
+    const int tile = __builtin_amdgcn_readfirstlane(ev.x);
+    G.first = __builtin_amdgcn_readfirstlane(ev.y); G.count = __builtin_amdgcn_readfirstlane(ev.z);
+    G.f = it < GM_ENTS ? __builtin_amdgcn_readfirstlane(ev.w) : -1;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    gm_level_geom(0, tx, ty, W0, H0, G.P0, G.Q0);
+    gm_level_geom(1, tx, ty, W1, H1, G.P1, G.Q1);
+    gm_level_geom(2, tx, ty, W2, H2, G.P2, G.Q2);
+    gm_level_geom(3, tx, ty, W3, H3, G.P3, G.Q3);
+    G.cs1 = (((unsigned)G.Q0 >> 24) + GM_CHUNK - 1) / GM_CHUNK;                   // first chunk of level 1, 2, 3; number of chunks
+    G.cs2 = G.cs1 + (((unsigned)G.Q1 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    G.cs3 = G.cs2 + (((unsigned)G.Q2 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    G.nchunks = G.cs3 + (((unsigned)G.Q3 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    return G;
 }
 
 __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned short* __restrict__ mirror, TiledLevels lv,
@@ -589,146 +621,208 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
     // the levels' map sizes and offsets as scalars (static indices: a dynamically indexed kernel-argument array goes to scratch)
     const int W0 = lv.W[0], W1 = lv.W[1], W2 = lv.W[2], W3 = lv.W[3], H0 = lv.H[0], H1 = lv.H[1], H2 = lv.H[2], H3 = lv.H[3];
     const size_t o0 = lv.off[0], o1 = lv.off[1], o2 = lv.off[2], o3 = lv.off[3];
+#ifdef GM_TRACE
+    unsigned long long* trp = (g_gm_trace && blockIdx.x < 2 && (wave == 0 || wave == GM_PWAVES)) ? g_gm_trace + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * GM_TRN : nullptr;
+    int tn = 0;
+#endif
 #define GM_SEL4(l_, a0, a1, a2, a3) ((l_) == 0 ? (a0) : ((l_) == 1 ? (a1) : ((l_) == 2 ? (a2) : (a3))))
-    for (int base = 0;; base += GM_ENTS) {
-        // ---- this block's next (up to) 64 work items: item i of the block is entry jb + i J of the XCD's list (frames xcd,
-        //      xcd + 8, ... one after another); lane-parallel look-up, entries {tile, first, count, frame} in LDS
-        lds_barrier();
-        if (wave == 0) {
-            int gi = jb + (base + lane) * J, fr = xcd;
-            int4 e = make_int4(0, 0, 0, -1);
-            for (; fr < F; fr += 8) {
-                const int n = nitems[fr];
-                if (gi < n) break;
-                gi -= n;
+#define geo_of(it_) gm_geo(ent, (it_), tiles_x, W0, W1, W2, W3, H0, H1, H2, H3)
+    typedef GmGeo Geo;
+#define GM_LEVEL_OF(G_, ci_) (((ci_) >= G_.cs1) + ((ci_) >= G_.cs2) + ((ci_) >= G_.cs3))
+    // ---- a batch = this block's next (up to) 64 work items: item i of the block is entry jb + i J of the XCD's list (frames xcd,
+    //      xcd + 8, ... one after another); lane-parallel look-up by wave 0, entries {tile, first, count, frame} in LDS.  Each role
+    //      runs its own loop over the batches (one loop around both roles keeps either role's values alive through the other: spills)
+#define GM_BATCH_HEAD()                                                                                                         \
+        lds_barrier();                                                                                                          \
+        if (wave == 0) {                                                                                                        \
+            int gi = jb + (base + lane) * J, fr = xcd;                                                                          \
+            int4 e = make_int4(0, 0, 0, -1);                                                                                    \
+            for (; fr < F; fr += 8) {                                                                                           \
+                const int n = nitems[fr];                                                                                       \
+                if (gi < n) break;                                                                                              \
+                gi -= n;                                                                                                        \
+            }                                                                                                                   \
+            if (fr < F) { e = items[(size_t)fr * max_items + gi]; e.w = fr; }                                                   \
+            ent[lane] = e;                                                                                                      \
+        }                                                                                                                       \
+        __syncthreads();                                                                                                        \
+        bool more = true;                                                                                                       \
+        if (GM_ABLATE & 16) { if (ent[GM_ENTS - 1].w < 0) break; continue; }
+    if (loader) { if (GM_ROLE == 2) return;
+      for (int base = 0;; base += GM_ENTS) {
+        GM_BATCH_HEAD()
+        {
+            // =================================================================== loader waves: nothing but loads (and LDS writes)
+            // request: thread = (rows i = ltid >> 4 and i + 16 of every block, 16-byte chunk c = ltid & 15); a block's source is a
+            // wave-uniform base (SGPRs) + one of two per-lane offsets.  No mask and no clamp: a slot outside the region holds
+            // whatever lies there in the buffer (a slack behind the mirror keeps the last level's last rows inside it,
+            // pips_pyramid_floats) -- a window pixel that falls on such a slot lies outside the map, and the blend tests that
+#define GM_REQUEST(G_, ci_, pre)                                                                                                \
+            {                                                                                                                   \
+                const int l_ = GM_LEVEL_OF(G_, ci_);                                                                            \
+                const int c0_ = ((ci_) - GM_SEL4(l_, 0, G_.cs1, G_.cs2, G_.cs3)) * GM_CHUNK;                                    \
+                const int P_ = GM_SEL4(l_, G_.P0, G_.P1, G_.P2, G_.P3), Q_ = GM_SEL4(l_, G_.Q0, G_.Q1, G_.Q2, G_.Q3);           \
+                const int x0_ = P_ & 0xffff, y0_ = (unsigned)P_ >> 16, nbx_ = (Q_ >> 16) & 0xff, nblk_ = (unsigned)Q_ >> 24;    \
+                const int Wl_ = GM_SEL4(l_, W0, W1, W2, W3), Hl_ = GM_SEL4(l_, H0, H1, H2, H3);                                 \
+                const size_t ol_ = GM_SEL4(l_, o0, o1, o2, o3);                                                                 \
+                const unsigned inv_ = (65536u + (unsigned)nbx_ - 1u) / (unsigned)nbx_;   /* block -> block row: exact for < 256 blocks */ \
+                const char* mp_ = reinterpret_cast<const char*>(mirror + ol_ + (size_t)G_.f * Hl_ * Wl_ * C);                   \
+                const unsigned offA_ = (unsigned)(((ltid >> 7) * Wl_ + ((ltid >> 4) & 7)) * (C * 2) + (ltid & 15) * 16);        \
+                const unsigned offB_ = offA_ + (unsigned)(2 * Wl_ * C * 2);          /* row i + 16: two image rows further down */ \
+                _Pragma("unroll") for (int b_ = 0; b_ < GM_CHUNK; ++b_) {                                                       \
+                    const int gb = min(c0_ + b_, nblk_ - 1);      /* (a chunk's blocks past the level's last repeat it: never used) */ \
+                    const int byi = (int)(((unsigned)gb * inv_) >> 16), bxi = gb - byi * nbx_;                                  \
+                    const char* sb_ = mp_ + (size_t)((unsigned)((y0_ + byi * 4) * Wl_ + x0_ + bxi * 8) * (unsigned)(C * 2));    \
+                    pre[2 * b_] = (GM_ABLATE & 1) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(sb_ + offA_);  \
+                    pre[2 * b_ + 1] = (GM_ABLATE & 1) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(sb_ + offB_); \
+                }                                                                                                               \
             }
-            if (fr < F) { e = items[(size_t)fr * max_items + gi]; e.w = fr; }
-            ent[lane] = e;
-        }
-        __syncthreads();
-        bool more = true;
-        for (int it = 0; it < GM_ENTS; ++it) {
-            const int4 ev = ent[it];
-            const int tile = __builtin_amdgcn_readfirstlane(ev.x), first = __builtin_amdgcn_readfirstlane(ev.y),
-                      count = __builtin_amdgcn_readfirstlane(ev.z), f = __builtin_amdgcn_readfirstlane(ev.w);
-            if (f < 0) { more = false; break; }
-            if (GM_ABLATE & 16) continue;
-            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-            // ---- per-level geometry of the item (wave-uniform; named scalars and packed fields, selected by ternaries: an array
-            //      indexed by the run-time level goes to scratch); a level's blocks fill whole chunks
-            int P0, P1, P2, P3, Q0, Q1, Q2, Q3;                           // P = x0 | y0 << 16;  Q = RW | RH << 8 | nbx << 16 | nblk << 24
-            gm_level_geom(0, tx, ty, W0, H0, P0, Q0);
-            gm_level_geom(1, tx, ty, W1, H1, P1, Q1);
-            gm_level_geom(2, tx, ty, W2, H2, P2, Q2);
-            gm_level_geom(3, tx, ty, W3, H3, P3, Q3);
-            const int cs1 = (((unsigned)Q0 >> 24) + GM_CHUNK - 1) / GM_CHUNK;                   // first chunk of level 1, 2, 3; number of chunks
-            const int cs2 = cs1 + (((unsigned)Q1 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
-            const int cs3 = cs2 + (((unsigned)Q2 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
-            const int nchunks = cs3 + (((unsigned)Q3 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
-#define GM_LEVEL_OF(ci_) (((ci_) >= cs1) + ((ci_) >= cs2) + ((ci_) >= cs3))
-            if (loader) {
-                // =================================================================== loader waves: nothing but loads (and LDS writes)
-                // request: thread = (rows i = ltid >> 4 and i + 16 of every block, 16-byte chunk c = ltid & 15); a block's source is a
-                // wave-uniform base (SGPRs) + one of two per-lane offsets.  No mask and no clamp: a slot outside the region holds
-                // whatever lies there in the buffer (a slack behind the mirror keeps the last level's last rows inside it,
-                // pips_pyramid_floats) -- a window pixel that falls on such a slot lies outside the map, and the blend tests that
-#define GM_REQUEST(ci_, pre)                                                                                                    \
-                {                                                                                                               \
-                    const int l_ = GM_LEVEL_OF(ci_);                                                                            \
-                    const int c0_ = ((ci_) - GM_SEL4(l_, 0, cs1, cs2, cs3)) * GM_CHUNK;                                         \
-                    const int P_ = GM_SEL4(l_, P0, P1, P2, P3), Q_ = GM_SEL4(l_, Q0, Q1, Q2, Q3);                               \
-                    const int x0_ = P_ & 0xffff, y0_ = (unsigned)P_ >> 16, nbx_ = (Q_ >> 16) & 0xff, nblk_ = (unsigned)Q_ >> 24; \
-                    const int Wl_ = GM_SEL4(l_, W0, W1, W2, W3), Hl_ = GM_SEL4(l_, H0, H1, H2, H3);                             \
-                    const size_t ol_ = GM_SEL4(l_, o0, o1, o2, o3);                                                             \
-                    const unsigned inv_ = (65536u + (unsigned)nbx_ - 1u) / (unsigned)nbx_;   /* block -> block row: exact for < 256 blocks */ \
-                    const char* mp_ = reinterpret_cast<const char*>(mirror + ol_ + (size_t)f * Hl_ * Wl_ * C);                  \
-                    const unsigned offA_ = (unsigned)(((ltid >> 7) * Wl_ + ((ltid >> 4) & 7)) * (C * 2) + (ltid & 15) * 16);    \
-                    const unsigned offB_ = offA_ + (unsigned)(2 * Wl_ * C * 2);          /* row i + 16: two image rows further down */ \
-                    _Pragma("unroll") for (int b_ = 0; b_ < GM_CHUNK; ++b_) {                                                   \
-                        const int gb = min(c0_ + b_, nblk_ - 1);      /* (a chunk's blocks past the level's last repeat it: never used) */ \
-                        const int byi = (int)(((unsigned)gb * inv_) >> 16), bxi = gb - byi * nbx_;                              \
-                        const char* sb_ = mp_ + (size_t)((unsigned)((y0_ + byi * 4) * Wl_ + x0_ + bxi * 8) * (unsigned)(C * 2)); \
-                        pre[2 * b_] = (GM_ABLATE & 1) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(sb_ + offA_); \
-                        pre[2 * b_ + 1] = (GM_ABLATE & 1) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(sb_ + offB_); \
-                    }                                                                                                           \
-                }
 #define GM_DELIVER(ci_, pre)                                                                                                    \
-                {                                                                                                               \
-                    char* st_ = smem + ((ci_) & 1) * GM_STAGE + ldsA;                                                           \
-                    _Pragma("unroll") for (int b_ = 0; b_ < GM_CHUNK; ++b_) {                                                   \
-                        *reinterpret_cast<uint4*>(st_ + b_ * GM_BLK_BYTES) = pre[2 * b_];                                       \
-                        *reinterpret_cast<uint4*>(st_ + b_ * GM_BLK_BYTES + 16 * 256) = pre[2 * b_ + 1];                        \
-                    }                                                                                                           \
-                }
-                const int ldsA = (ltid >> 4) * 256 + (((ltid & 15) ^ ((ltid >> 4) & 15)) << 4);      // row i (and i + 16: same swizzle), chunk c
-                uint4 preA[GM_PIECES], preB[GM_PIECES];                    // chunks 2 k, 2 k + 1: two requests in flight (a third set of 32 registers spills)
-                GM_REQUEST(0, preA)                                      // (first in the queue: what the first step needs)
-                // (order: everything that depends on nothing but the entry first -- the map chunk above, the records, the six
-                //  feature-row indices -- then the feature rows, which need the indices: two memory round trips, not one per batch)
-                int4 r0 = order[((size_t)f * N + first) * PIPS_LEVELS + min(ltid, count * PIPS_LEVELS - 1)];
-                int4 r1 = order[((size_t)f * N + first) * PIPS_LEVELS + min(ltid + GM_LTHREADS, count * PIPS_LEVELS - 1)];
-                {
-                    // thread -> (particle j = k * 16 + (ltid >> 4), chunk c = ltid & 15 of 8 channels), k = 0..5
-                    const int c = ltid & 15;
-                    int mrow[GMAX / 16];
-#pragma unroll
-                    for (int k = 0; k < GMAX / 16; ++k)
-                        mrow[k] = order[((size_t)f * N + first + min(k * 16 + (ltid >> 4), count - 1)) * PIPS_LEVELS].w;
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {                     // (two batches of three rows: register budget)
-                        float4 fa[GMAX / 32], fb[GMAX / 32];
-#pragma unroll
-                        for (int k = 0; k < GMAX / 32; ++k) {
-                            const float* fp = ffeats + (size_t)mrow[hb * (GMAX / 32) + k] * C + c * 8;
-                            fa[k] = *reinterpret_cast<const float4*>(fp);
-                            fb[k] = *reinterpret_cast<const float4*>(fp + 4);
-                        }
-#pragma unroll
-                        for (int k = 0; k < GMAX / 32; ++k) {
-                            const int j = (hb * (GMAX / 32) + k) * 16 + (ltid >> 4);
-                            const unsigned keep = (j < count && !(GM_ABLATE & 8)) ? 0xffffffffu : 0u;
-                            *reinterpret_cast<uint4*>(smem + GM_FEAT_OFF + j * 256 + ((c ^ (j & 15)) << 4)) =
-                                make_uint4(pack2_bf16(fa[k].x, fa[k].y) & keep, pack2_bf16(fa[k].z, fa[k].w) & keep,
-                                           pack2_bf16(fb[k].x, fb[k].y) & keep, pack2_bf16(fb[k].z, fb[k].w) & keep);
-                        }
-                    }
-                }
-                if (nchunks > 1) GM_REQUEST(1, preB)                     // (after the features: register budget of a 16-wave block)
-                if ((ltid >> 2) >= count) r0 = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);
-                if (((ltid + GM_LTHREADS) >> 2) >= count) r1 = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);
-                rec[ltid] = r0;
-                if (ltid + GM_LTHREADS < GMAX * PIPS_LEVELS) rec[ltid + GM_LTHREADS] = r1;
+            {                                                                                                                   \
+                char* st_ = smem + ((ci_) & 1) * GM_STAGE + ldsA;                                                               \
+                _Pragma("unroll") for (int b_ = 0; b_ < GM_CHUNK; ++b_) {                                                       \
+                    *reinterpret_cast<uint4*>(st_ + b_ * GM_BLK_BYTES) = pre[2 * b_];                                           \
+                    *reinterpret_cast<uint4*>(st_ + b_ * GM_BLK_BYTES + 16 * 256) = pre[2 * b_ + 1];                            \
+                }                                                                                                               \
+            }
+            const int ldsA = (ltid >> 4) * 256 + (((ltid & 15) ^ ((ltid >> 4) & 15)) << 4);      // row i (and i + 16: same swizzle), chunk c
+            uint4 preA[GM_PIECES], preB[GM_PIECES];      // even / odd chunks: two requests in flight (a third set of 32 registers spills)
+            Geo G = geo_of(0);
+            if (G.f >= 0) {                               // the batch's first item: its first chunks are requested here, exposed
+                GM_T(1);
+                GM_REQUEST(G, 0, preA)
+                if (G.nchunks > 1) GM_REQUEST(G, 1, preB)
                 GM_DELIVER(0, preA)
-                if (nchunks > 2) GM_REQUEST(2, preA)
-                lds_barrier();                                           // (A) records, features and chunk 0 are in LDS
-                // step s: deliver chunk s + 1 (requested two steps earlier), request chunk s + 3 into its registers
-                for (int s = 0; s <= nchunks; s += 2) {
-                    if (s + 1 < nchunks) { GM_DELIVER(s + 1, preB) if (s + 3 < nchunks) GM_REQUEST(s + 3, preB) }
+                if (G.nchunks > 2) GM_REQUEST(G, 2, preA)
+            }
+            for (int it = 0; it < GM_ENTS; ++it) {
+                if (G.f < 0) { more = false; break; }
+                const Geo Gn = geo_of(it + 1);
+                const bool hasnext = Gn.f >= 0;
+                GM_T(12);
+                lds_barrier();                                           // (A) records, features and chunk 0 of item `it` are in LDS
+                // steps 0 .. nchunks - 2: deliver chunk s + 1 (requested two steps earlier), request chunk s + 3 into its registers
+                for (int s = 0; s + 1 < G.nchunks; ++s) {
+                    GM_T(20);
+                    const int c = s + 1;
+                    if (c & 1) { GM_DELIVER(c, preB) GM_T(21); if (c + 2 < G.nchunks) GM_REQUEST(G, c + 2, preB) }
+                    else { GM_DELIVER(c, preA) GM_T(21); if (c + 2 < G.nchunks) GM_REQUEST(G, c + 2, preA) }
+                    GM_T(22);
                     lds_barrier();
-                    if (s + 1 > nchunks) break;
-                    if (s + 2 < nchunks) { GM_DELIVER(s + 2, preA) if (s + 4 < nchunks) GM_REQUEST(s + 4, preA) }
-                    lds_barrier();
+                    GM_T(23);
                 }
+                // step nchunks - 1 (the products of the last chunk; nothing left to deliver, both register sets idle): the NEXT item's
+                // chunks 0 and 1 requested; step nchunks (blend only, no product wave reads a stage buffer): its chunk 0 delivered,
+                // chunk 2 requested -- the next item starts with its first chunk in LDS
+                GM_T(20);
+                if (hasnext) {
+                    GM_REQUEST(Gn, 0, preA)
+                    if (Gn.nchunks > 1) GM_REQUEST(Gn, 1, preB)
+                }
+                GM_T(22);
+                lds_barrier();
+                GM_T(23);
+                GM_T(20);
+                if (hasnext) {
+                    GM_DELIVER(0, preA)
+                    GM_T(21);
+                    if (Gn.nchunks > 2) GM_REQUEST(Gn, 2, preA)
+                }
+                GM_T(22);
+                lds_barrier();
+                GM_T(23);
+                G = Gn;
+            }
+        }
+        if (!more) break;
+      }
 #undef GM_REQUEST
 #undef GM_DELIVER
-            } else {
-                // =================================================================== product waves: no loads; LDS, MFMA, stores
+    } else { if (GM_ROLE == 1) return;
+      for (int base = 0;; base += GM_ENTS) {
+        GM_BATCH_HEAD()
+        {
+            // =================================================================== product waves: LDS, MFMA, stores -- and the NEXT item's
+            // records and features, fetched under this item's steps (three short stages: a wait for them also waits for the tap stores
+            // issued before, which by then are steps old).  Records: thread t < 384 holds (particle j, level l) = 4 j + l; slots past the
+            // item's particles get a far-away anchor.  Features: thread t -> particle j = t >> 3, channels 16 (t & 7) .. + 15; fp32 -> bf16
+            // RNE into LDS rows of 256 bytes, 16-byte chunk index XORed with row & 15 (the fragment reads are conflict-free)
+#define GM_PRO_LOAD1(G_)                                                                                                        \
+            {   /* (32-bit byte offsets from scalar bases: the launcher checks that records and features stay below 4 GiB) */  \
+                const char* ob_ = reinterpret_cast<const char*>(order + ((size_t)G_.f * N + G_.first) * PIPS_LEVELS);            \
+                prr = *reinterpret_cast<const int4*>(ob_ + (unsigned)min(min(tid, GMAX * PIPS_LEVELS - 1), G_.count * PIPS_LEVELS - 1) * 16u); \
+                prm = *reinterpret_cast<const int*>(ob_ + (unsigned)min(tid >> 3, G_.count - 1) * (unsigned)(PIPS_LEVELS * 16) + 12u); \
+            }
+#define GM_PRO_LOAD2()                                                                                                          \
+            {                                                                                                                   \
+                const char* fp_ = reinterpret_cast<const char*>(ffeats) + ((unsigned)prm * (unsigned)(C * 4) + (unsigned)((tid & 7) * 64)); \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) prf[k] = *reinterpret_cast<const float4*>(fp_ + 16 * k);          \
+            }
+#define GM_PRO_STORE(G_, recp_)                                                                                                 \
+            {                                                                                                                   \
+                const int j_ = tid >> 3, c_ = (tid & 7) * 2;                                                                    \
+                const unsigned keep_ = (j_ < G_.count && !(GM_ABLATE & 8)) ? 0xffffffffu : 0u;                                  \
+                char* fr_ = smem + GM_FEAT_OFF + j_ * 256;                                                                      \
+                *reinterpret_cast<uint4*>(fr_ + ((c_ ^ (j_ & 15)) << 4)) =                                                      \
+                    make_uint4(pack2_bf16(prf[0].x, prf[0].y) & keep_, pack2_bf16(prf[0].z, prf[0].w) & keep_,                  \
+                               pack2_bf16(prf[1].x, prf[1].y) & keep_, pack2_bf16(prf[1].z, prf[1].w) & keep_);                 \
+                *reinterpret_cast<uint4*>(fr_ + (((c_ + 1) ^ (j_ & 15)) << 4)) =                                                \
+                    make_uint4(pack2_bf16(prf[2].x, prf[2].y) & keep_, pack2_bf16(prf[2].z, prf[2].w) & keep_,                  \
+                               pack2_bf16(prf[3].x, prf[3].y) & keep_, pack2_bf16(prf[3].z, prf[3].w) & keep_);                 \
+                if ((tid >> 2) >= G_.count) prr = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);                          \
+                if (tid < GMAX * PIPS_LEVELS) (recp_)[tid] = prr;                                                               \
+            }
+            int4 prr = make_int4(0, 0, 0, 0);
+            int prm = 0;
+            float4 prf[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) prf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            {
+                const Geo G0 = geo_of(0);
+                if (G0.f >= 0) {                         // the batch's first item: exposed
+                    GM_PRO_LOAD1(G0)
+                    GM_PRO_LOAD2()
+                    GM_PRO_STORE(G0, rec)
+                }
+            }
+            for (int it = 0; it < GM_ENTS; ++it) {
+                const Geo G = geo_of(it);
+                if (G.f < 0) { more = false; break; }
+                const Geo Gn = geo_of(it + 1);
+                const bool hasnext = Gn.f >= 0;
+                int pstage = hasnext ? 0 : 3;            // next item's records / features: 0 nothing, 1 records + row index requested, 2 rows requested, 3 in LDS
+                const int count = G.count, nchunks = G.nchunks, cs1 = G.cs1, cs2 = G.cs2, cs3 = G.cs3;
+                const int4* recp = rec + (it & 1) * (GMAX * PIPS_LEVELS);
+                int4* recn = rec + ((it + 1) & 1) * (GMAX * PIPS_LEVELS);
+                GM_T(1);
                 lds_barrier();                                           // (A)
+                GM_T(30);
                 uint4 bfr[8];                                            // B operand: this lane's particle, channels 16 ks + 8 half ... + 8
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
                     bfr[ks] = *reinterpret_cast<const uint4*>(smem + GM_FEAT_OFF + jme * 256 + (((ks * 2 + half) ^ (jme & 15)) << 4));
                 const bool active = pb * 32 < count;                     // (wave-uniform) this wave's particle block holds particles
                 for (int s = 0; s <= nchunks; ++s) {
+                    GM_T(40);
+                    // the next item's prologue (the feature buffer is free behind step 0's barrier, the records go to the other buffer)
+                    if (pstage == 0 && s >= 1) { GM_PRO_LOAD1(Gn) pstage = 1; }
+                    else if (pstage == 1 && s >= 3) { GM_PRO_LOAD2() pstage = 2; }
+                    else if (pstage == 2 && s >= 5) { GM_PRO_STORE(Gn, recn) pstage = 3; }
+                    if (s == nchunks && pstage < 3) {                    // (an item of fewer than six steps: the rest, exposed)
+                        if (pstage < 1) GM_PRO_LOAD1(Gn)
+                        if (pstage < 2) GM_PRO_LOAD2()
+                        GM_PRO_STORE(Gn, recn)
+                        pstage = 3;
+                    }
                     if (s < nchunks && active && !(GM_ABLATE & 2)) {
                         // ---- products of chunk s: this wave's block of the chunk x its particle block, scattered into the windows
-                        const int l = GM_LEVEL_OF(s);
+                        const int l = GM_LEVEL_OF(G, s);
                         const int c0 = (s - GM_SEL4(l, 0, cs1, cs2, cs3)) * GM_CHUNK;
-                        const int P = GM_SEL4(l, P0, P1, P2, P3), Q = GM_SEL4(l, Q0, Q1, Q2, Q3);
+                        const int P = GM_SEL4(l, G.P0, G.P1, G.P2, G.P3), Q = GM_SEL4(l, G.Q0, G.Q1, G.Q2, G.Q3);
                         const int nbx = (Q >> 16) & 0xff, nblk = (unsigned)Q >> 24;
                         const int gb = c0 + bl;
                         if (gb < nblk) {
-                            const int rx_ = rec[jme * PIPS_LEVELS + l].x;            // window anchor in region coordinates
+                            const int rx_ = recp[jme * PIPS_LEVELS + l].x;           // window anchor in region coordinates
                             const int bxr = (int)(short)(rx_ & 0xffff) - (P & 0xffff), byr = (rx_ >> 16) - (int)((unsigned)P >> 16);
                             f32x16 acc;
 #pragma unroll
@@ -740,28 +834,37 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_gm*>(&a),
                                                                               *reinterpret_cast<const bf16x8_gm*>(&bfr[ks]), acc, 0, 0, 0);
                             }
+#ifdef GM_TRACE
+                            { int d_; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(d_) : "v"(acc[15])); asm volatile("" :: "s"(d_)); }
+                            GM_T(41);
+#endif
                             const unsigned inv_nbx = (65536u + (unsigned)nbx - 1u) / (unsigned)nbx;
                             const int byi = (int)(((unsigned)gb * inv_nbx) >> 16), bxi = gb - byi * nbx;
                             const int dx0 = bxi * 8 + 4 * half - bxr, dy0 = byi * 4 - byr;
-                            char* wb = smem + GM_WIN_OFF + (l & 1) * GM_WIN_BYTES + jme * (GM_WIN_ROW * 4) + dy0 * 32 + dx0 * 4;
+                            // branch-free: a value outside its particle's window goes to a per-lane dummy slot instead (16 selects + 16
+                            // unconditional ds_write_b32)
+                            const unsigned wbo = (unsigned)(GM_WIN_OFF + (l & 1) * GM_WIN_BYTES + jme * (GM_WIN_ROW * 4) + dy0 * 32 + dx0 * 4);
+                            const unsigned dmy = (unsigned)(GM_DUMMY_OFF + lane * 4);
 #pragma unroll
                             for (int y = 0; y < 4; ++y)
 #pragma unroll
-                                for (int x = 0; x < 4; ++x)
-                                    if ((unsigned)(dx0 + x) < 8u && (unsigned)(dy0 + y) < 8u)
-                                        *reinterpret_cast<float*>(wb + y * 32 + x * 4) = acc[y * 4 + x];
+                                for (int x = 0; x < 4; ++x) {
+                                    const bool ok = (unsigned)(dx0 + x) < 8u && (unsigned)(dy0 + y) < 8u;
+                                    *reinterpret_cast<float*>(smem + (ok ? wbo + (unsigned)(y * 32 + x * 4) : dmy)) = acc[y * 4 + x];
+                                }
                         }
                     }
+                    GM_T(42);
                     if (s > 0 && (s == cs1 || s == cs2 || s == cs3 || s == nchunks)) {
                         // ---- the step after a level's last chunk: 2x2 blend of its 8x8 correlations to the 49 taps, k = ix*7 + iy
                         //      (transposed, :379-381); neighbours outside the map count as zero (:324)
-                        const int l = GM_LEVEL_OF(s - 1);
+                        const int l = GM_LEVEL_OF(G, s - 1);
                         const int Wl = GM_SEL4(l, W0, W1, W2, W3), Hl = GM_SEL4(l, H0, H1, H2, H3);
                         const float* winf = reinterpret_cast<const float*>(smem + GM_WIN_OFF + (l & 1) * GM_WIN_BYTES);
                         for (int idx = tid; idx < count * GM_TAPS; idx += GM_PTHREADS) {
                             const int j = idx / GM_TAPS, t = idx - j * GM_TAPS;
                             const int ti = t / 7, tj = t - ti * 7;
-                            const int4 r = rec[j * PIPS_LEVELS + l];
+                            const int4 r = recp[j * PIPS_LEVELS + l];
                             const float wx = __int_as_float(r.y), wy = __int_as_float(r.z);
                             const int px = (int)(short)(r.x & 0xffff) + ti, py = (r.x >> 16) + tj;        // map pixel of the tap's north-west neighbour
                             const bool x0in = (unsigned)px < (unsigned)Wl, x1in = (unsigned)(px + 1) < (unsigned)Wl,
@@ -777,15 +880,20 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                             o = fmaf(w1, ne, o); o = fmaf(w2, sw, o); o = fmaf(w3, se, o);
                             if (!(GM_ABLATE & 4)) X[(size_t)r.w * PIPS_KIN_PAD + C + GM_TAPS * l + t] = o;
                         }
+                        GM_T(43);
                     }
                     lds_barrier();
+                    GM_T(44);
                 }
             }
-#undef GM_LEVEL_OF
         }
         if (!more) break;
+      }
     }
+#undef GM_BATCH_HEAD
+#undef GM_LEVEL_OF
 #undef GM_SEL4
+#undef geo_of
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -894,6 +1002,11 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
 
 }  // namespace pips
 
+#ifdef GM_TRACE
+extern "C" int pips_gm_trace(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(pips::g_gm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
 #ifdef PIPS_TILED_TRACE
 extern "C" int pips_tiled_trace(void* buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(pips::g_tiled_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
