@@ -547,7 +547,7 @@ constexpr int GM_REC_OFF = GM_WIN_OFF + 2 * GM_WIN_BYTES;
 constexpr int GM_FEAT_OFF = GM_REC_OFF + 2 * GMAX * PIPS_LEVELS * 16;      // (two record buffers: item parity)
 constexpr int GM_ENTS = 64;                       // work-item entries looked up at a time
 constexpr int GM_ENT_OFF = GM_FEAT_OFF + GMAX * C * 2;
-constexpr int GM_DUMMY_OFF = GM_ENT_OFF + GM_ENTS * 16;          // 256 bytes: where the scatter's out-of-window values go
+constexpr int GM_DUMMY_OFF = GM_ENT_OFF + GM_ENTS * 64;          // 256 bytes: where the scatter's out-of-window values go
 constexpr int GM_LDS = GM_DUMMY_OFF + 256;
 constexpr int GM_TAPS = 49;                       // (2 r + 1)^2 taps per level (PIPS_NCORR = 4 x 49 is a mixer row's whole correlation block)
 constexpr int GM_PIECES = GM_CHUNK * 32 * 16 / GM_LTHREADS;                        // 16-byte pieces per loader thread and chunk (8)
@@ -564,6 +564,9 @@ constexpr int GM_TRN = 8192;
 #endif
 #ifndef GM_ROLE
 #define GM_ROLE 0       // compile-time probe of one role's register use: 1 loader only, 2 product only
+#endif
+#ifndef GM_BU
+#define GM_BU 2          // taps per thread and pass of the blend (3: same time, 8 more registers; 4 spills)
 #endif
 #ifndef GM_ABLATE
 #define GM_ABLATE 0      // debugging builds only: 1 no map loads, 2 no products / scatter, 4 no stores, 8 no feature loads, 16 items only
@@ -585,21 +588,35 @@ __device__ __forceinline__ void gm_level_geom(int l, int tx, int ty, int Wl, int
 // per-level geometry of a work item (wave-uniform; named scalars and packed fields, selected by ternaries: an array indexed by the
 // run-time level goes to scratch -- and so does a lambda's closure); a level's blocks fill whole chunks.  f < 0: no item
 struct GmGeo { int first, count, f, P0, P1, P2, P3, Q0, Q1, Q2, Q3, cs1, cs2, cs3, nchunks; };
-__device__ __forceinline__ GmGeo gm_geo(const int4* ent, int it, int tiles_x, int W0, int W1, int W2, int W3, int H0, int H1, int H2, int H3) {
+// one lane's entry {tile, first, count, frame} -> the item's geometry, as 4 x int4 (the batch head: lane i works out item i once;
+// worked out per item by every wave instead, the scalar code sat on the loaders' path, tools/gm_trace.py)
+__device__ __forceinline__ void gm_geo_store(int4* geo, int4 ev, int tiles_x, int W0, int W1, int W2, int W3, int H0, int H1, int H2, int H3) {
+    const int ty = ev.x / tiles_x, tx = ev.x - ty * tiles_x;
+    int P0, P1, P2, P3, Q0, Q1, Q2, Q3;
+    gm_level_geom(0, tx, ty, W0, H0, P0, Q0);
+    gm_level_geom(1, tx, ty, W1, H1, P1, Q1);
+    gm_level_geom(2, tx, ty, W2, H2, P2, Q2);
+    gm_level_geom(3, tx, ty, W3, H3, P3, Q3);
+    const int cs1 = (((unsigned)Q0 >> 24) + GM_CHUNK - 1) / GM_CHUNK;                 // first chunk of level 1, 2, 3; number of chunks
+    const int cs2 = cs1 + (((unsigned)Q1 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    const int cs3 = cs2 + (((unsigned)Q2 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    const int nchunks = cs3 + (((unsigned)Q3 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    geo[0] = make_int4(ev.y, ev.z, ev.w, nchunks);
+    geo[1] = make_int4(P0, P1, P2, P3);
+    geo[2] = make_int4(Q0, Q1, Q2, Q3);
+    geo[3] = make_int4(cs1, cs2, cs3, 0);
+}
+// item `it` of the batch, wave-uniform (scalars)
+__device__ __forceinline__ GmGeo gm_geo(const int4* geo, int it) {
     GmGeo G;
-    const int4 ev = ent[min(it, GM_ENTS - 1)];
-    const int tile = __builtin_amdgcn_readfirstlane(ev.x);
-    G.first = __builtin_amdgcn_readfirstlane(ev.y); G.count = __builtin_amdgcn_readfirstlane(ev.z);
-    G.f = it < GM_ENTS ? __builtin_amdgcn_readfirstlane(ev.w) : -1;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    gm_level_geom(0, tx, ty, W0, H0, G.P0, G.Q0);
-    gm_level_geom(1, tx, ty, W1, H1, G.P1, G.Q1);
-    gm_level_geom(2, tx, ty, W2, H2, G.P2, G.Q2);
-    gm_level_geom(3, tx, ty, W3, H3, G.P3, G.Q3);
-    G.cs1 = (((unsigned)G.Q0 >> 24) + GM_CHUNK - 1) / GM_CHUNK;                   // first chunk of level 1, 2, 3; number of chunks
-    G.cs2 = G.cs1 + (((unsigned)G.Q1 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
-    G.cs3 = G.cs2 + (((unsigned)G.Q2 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
-    G.nchunks = G.cs3 + (((unsigned)G.Q3 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    const int4* gp = geo + 4 * min(it, GM_ENTS - 1);
+    const int4 a = gp[0], b = gp[1], c = gp[2], d = gp[3];
+#define GM_RFL(x_) __builtin_amdgcn_readfirstlane(x_)
+    G.first = GM_RFL(a.x); G.count = GM_RFL(a.y); G.f = it < GM_ENTS ? GM_RFL(a.z) : -1; G.nchunks = GM_RFL(a.w);
+    G.P0 = GM_RFL(b.x); G.P1 = GM_RFL(b.y); G.P2 = GM_RFL(b.z); G.P3 = GM_RFL(b.w);
+    G.Q0 = GM_RFL(c.x); G.Q1 = GM_RFL(c.y); G.Q2 = GM_RFL(c.z); G.Q3 = GM_RFL(c.w);
+    G.cs1 = GM_RFL(d.x); G.cs2 = GM_RFL(d.y); G.cs3 = GM_RFL(d.z);
+#undef GM_RFL
     return G;
 }
 
@@ -626,11 +643,11 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
     int tn = 0;
 #endif
 #define GM_SEL4(l_, a0, a1, a2, a3) ((l_) == 0 ? (a0) : ((l_) == 1 ? (a1) : ((l_) == 2 ? (a2) : (a3))))
-#define geo_of(it_) gm_geo(ent, (it_), tiles_x, W0, W1, W2, W3, H0, H1, H2, H3)
+#define geo_of(it_) gm_geo(ent, (it_))
     typedef GmGeo Geo;
 #define GM_LEVEL_OF(G_, ci_) (((ci_) >= G_.cs1) + ((ci_) >= G_.cs2) + ((ci_) >= G_.cs3))
     // ---- a batch = this block's next (up to) 64 work items: item i of the block is entry jb + i J of the XCD's list (frames xcd,
-    //      xcd + 8, ... one after another); lane-parallel look-up by wave 0, entries {tile, first, count, frame} in LDS.  Each role
+    //      xcd + 8, ... one after another); lane-parallel look-up by wave 0, the items' geometry (gm_geo_store) in LDS.  Each role
     //      runs its own loop over the batches (one loop around both roles keeps either role's values alive through the other: spills)
 #define GM_BATCH_HEAD()                                                                                                         \
         lds_barrier();                                                                                                          \
@@ -643,11 +660,11 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                 gi -= n;                                                                                                        \
             }                                                                                                                   \
             if (fr < F) { e = items[(size_t)fr * max_items + gi]; e.w = fr; }                                                   \
-            ent[lane] = e;                                                                                                      \
+            gm_geo_store(ent + 4 * lane, e, tiles_x, W0, W1, W2, W3, H0, H1, H2, H3);                                           \
         }                                                                                                                       \
         __syncthreads();                                                                                                        \
         bool more = true;                                                                                                       \
-        if (GM_ABLATE & 16) { if (ent[GM_ENTS - 1].w < 0) break; continue; }
+        if (GM_ABLATE & 16) { if (ent[4 * (GM_ENTS - 1)].z < 0) break; continue; }
     if (loader) { if (GM_ROLE == 2) return;
       for (int base = 0;; base += GM_ENTS) {
         GM_BATCH_HEAD()
@@ -687,52 +704,54 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
             }
             const int ldsA = (ltid >> 4) * 256 + (((ltid & 15) ^ ((ltid >> 4) & 15)) << 4);      // row i (and i + 16: same swizzle), chunk c
             uint4 preA[GM_PIECES], preB[GM_PIECES];      // even / odd chunks: two requests in flight (a third set of 32 registers spills)
-            Geo G = geo_of(0);
-            if (G.f >= 0) {                               // the batch's first item: its first chunks are requested here, exposed
+            // The chunks of a batch's items form ONE stream q = 0, 1, 2 ...: chunk q goes through register set q & 1 into stage
+            // buffer q & 1; in the step whose products read chunk q, chunk q + 1 is delivered and chunk q + 3 requested -- across
+            // item boundaries (every item has >= 4 chunks, one per level at least: three chunks ahead is this item or the next)
+            // Requests and deliveries are UNCONDITIONAL and the two register sets alternate in straight-line code (two steps per loop
+            // iteration): behind a conditional request, or a run-time choice of the set, the compiler's wait-count pass must assume the
+            // set being delivered was requested last and waits for vmcnt(0) -- i.e. for the request issued one step ago as well,
+            // which makes the pipeline one step deep instead of two.  Past the batch's last chunk the stream repeats a valid chunk
+            // (never read)
+            Geo G = geo_of(0), Gn = geo_of(1);
+            int it = 0, s = 0;
+#define GM_LSTEP(par_, pre)                                                                                                     \
+            {   /* the products read chunk s of item G: chunk s + 1 of the stream delivered, chunk s + 3 requested */          \
+                GM_T(20);                                                                                                       \
+                const bool hasnext = Gn.f >= 0, rnext = s + 3 >= G.nchunks;                                                     \
+                const Geo Gr = (rnext && hasnext) ? Gn : G;                                                                     \
+                const int cr = rnext ? (hasnext ? s + 3 - G.nchunks : 0) : s + 3;                                               \
+                GM_DELIVER(par_, pre)                                                                                           \
+                GM_T(21);                                                                                                       \
+                GM_REQUEST(Gr, cr, pre)                                                                                         \
+                GM_T(22);                                                                                                       \
+                if (!done) {     /* (the loop is left at its end only: an exit between the two steps merges their wait states) */ \
+                    lds_barrier();                                                                                              \
+                    GM_T(23);                                                                                                   \
+                    if (++s == G.nchunks) {                                                                                     \
+                        if (!hasnext) done = true;                                                                              \
+                        else { G = Gn; ++it; Gn = geo_of(it + 1); s = 0; GM_T(12); }                                            \
+                    }                                                                                                           \
+                }                                                                                                               \
+            }
+            if (G.f < 0) {
+                lds_barrier();                                           // (A)
+                more = false;
+            } else {
                 GM_T(1);
-                GM_REQUEST(G, 0, preA)
-                if (G.nchunks > 1) GM_REQUEST(G, 1, preB)
+                GM_REQUEST(G, 0, preA)                                   // the batch's first item: its first chunks, exposed
+                GM_REQUEST(G, 1, preB)
                 GM_DELIVER(0, preA)
-                if (G.nchunks > 2) GM_REQUEST(G, 2, preA)
+                GM_REQUEST(G, 2, preA)
+                lds_barrier();                                           // (A) records, features and chunk 0 of the first item are in LDS
+                bool done = false;
+                do {
+                    GM_LSTEP(1, preB)
+                    GM_LSTEP(0, preA)
+                } while (!done);
+                lds_barrier();                                           // (the product waves' last blend)
+                more = it + 1 >= GM_ENTS;
             }
-            for (int it = 0; it < GM_ENTS; ++it) {
-                if (G.f < 0) { more = false; break; }
-                const Geo Gn = geo_of(it + 1);
-                const bool hasnext = Gn.f >= 0;
-                GM_T(12);
-                lds_barrier();                                           // (A) records, features and chunk 0 of item `it` are in LDS
-                // steps 0 .. nchunks - 2: deliver chunk s + 1 (requested two steps earlier), request chunk s + 3 into its registers
-                for (int s = 0; s + 1 < G.nchunks; ++s) {
-                    GM_T(20);
-                    const int c = s + 1;
-                    if (c & 1) { GM_DELIVER(c, preB) GM_T(21); if (c + 2 < G.nchunks) GM_REQUEST(G, c + 2, preB) }
-                    else { GM_DELIVER(c, preA) GM_T(21); if (c + 2 < G.nchunks) GM_REQUEST(G, c + 2, preA) }
-                    GM_T(22);
-                    lds_barrier();
-                    GM_T(23);
-                }
-                // step nchunks - 1 (the products of the last chunk; nothing left to deliver, both register sets idle): the NEXT item's
-                // chunks 0 and 1 requested; step nchunks (blend only, no product wave reads a stage buffer): its chunk 0 delivered,
-                // chunk 2 requested -- the next item starts with its first chunk in LDS
-                GM_T(20);
-                if (hasnext) {
-                    GM_REQUEST(Gn, 0, preA)
-                    if (Gn.nchunks > 1) GM_REQUEST(Gn, 1, preB)
-                }
-                GM_T(22);
-                lds_barrier();
-                GM_T(23);
-                GM_T(20);
-                if (hasnext) {
-                    GM_DELIVER(0, preA)
-                    GM_T(21);
-                    if (Gn.nchunks > 2) GM_REQUEST(Gn, 2, preA)
-                }
-                GM_T(22);
-                lds_barrier();
-                GM_T(23);
-                G = Gn;
-            }
+#undef GM_LSTEP
         }
         if (!more) break;
       }
@@ -772,6 +791,46 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                 if ((tid >> 2) >= G_.count) prr = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);                          \
                 if (tid < GMAX * PIPS_LEVELS) (recp_)[tid] = prr;                                                               \
             }
+            // the step after a level's last chunk: 2x2 blend of its 8x8 correlations to the 49 taps, k = ix*7 + iy (transposed, :379-381);
+            // neighbours outside the map count as zero (:324).  The last level's blend runs in the NEXT item's step 0 (its records are in
+            // the other record buffer, its windows in the buffer level 0 does not use)
+#define GM_BLEND(l_, recb_, cnt_)                                                                                               \
+            {   /* GM_BU taps per thread and pass: their LDS reads issued together (clamped index, nothing conditional), then the  \
+                   arithmetic; a window value outside the map is whatever the buffer holds and is replaced by zero */             \
+                const int Wl = GM_SEL4(l_, W0, W1, W2, W3), Hl = GM_SEL4(l_, H0, H1, H2, H3);                                   \
+                const float* winf = reinterpret_cast<const float*>(smem + GM_WIN_OFF + ((l_) & 1) * GM_WIN_BYTES);              \
+                const int total_ = (cnt_) * GM_TAPS;                                                                            \
+                for (int k0 = tid; k0 < total_; k0 += GM_BU * GM_PTHREADS) {                                                        \
+                    int4 r_[GM_BU]; int t_[GM_BU]; float nw_[GM_BU], ne_[GM_BU], sw_[GM_BU], se_[GM_BU];                                                \
+                    _Pragma("unroll") for (int u = 0; u < GM_BU; ++u) {                                                           \
+                        const int idx = min(k0 + u * GM_PTHREADS, total_ - 1);                                                  \
+                        const int j = idx / GM_TAPS, t = idx - j * GM_TAPS;                                                     \
+                        const int ti = t / 7, tj = t - ti * 7;                                                                  \
+                        const float* wv = winf + j * GM_WIN_ROW + tj * 8 + ti;                                                  \
+                        r_[u] = (recb_)[j * PIPS_LEVELS + (l_)];                                                                \
+                        t_[u] = t;                                                                                              \
+                        nw_[u] = wv[0]; ne_[u] = wv[1]; sw_[u] = wv[8]; se_[u] = wv[9];                                         \
+                    }                                                                                                           \
+                    _Pragma("unroll") for (int u = 0; u < GM_BU; ++u) {                                                           \
+                        const int4 r = r_[u];                                                                                   \
+                        const int t = t_[u], ti = t / 7, tj = t - ti * 7;                                                       \
+                        const float wx = __int_as_float(r.y), wy = __int_as_float(r.z);                                         \
+                        const int px = (int)(short)(r.x & 0xffff) + ti, py = (r.x >> 16) + tj;   /* map pixel of the tap's north-west neighbour */ \
+                        const bool x0in = (unsigned)px < (unsigned)Wl, x1in = (unsigned)(px + 1) < (unsigned)Wl,                \
+                                   y0in = (unsigned)py < (unsigned)Hl, y1in = (unsigned)(py + 1) < (unsigned)Hl;                \
+                        const float nw = (x0in && y0in) ? nw_[u] : 0.f, ne = (x1in && y0in) ? ne_[u] : 0.f,                     \
+                                    sw = (x0in && y1in) ? sw_[u] : 0.f, se = (x1in && y1in) ? se_[u] : 0.f;                     \
+                        const float e = 1.0f - wx, so = 1.0f - wy;                                                              \
+                        const float k128 = 0.08838834764831845f;              /* the 1/sqrt(128) of :397 rides on the weights */ \
+                        const float w0 = __fmul_rn(__fmul_rn(so, e), k128), w1 = __fmul_rn(__fmul_rn(so, wx), k128),            \
+                                    w2 = __fmul_rn(__fmul_rn(wy, e), k128), w3 = __fmul_rn(__fmul_rn(wy, wx), k128);            \
+                        float o = __fmul_rn(w0, nw);                                                                            \
+                        o = fmaf(w1, ne, o); o = fmaf(w2, sw, o); o = fmaf(w3, se, o);                                          \
+                        if (k0 + u * GM_PTHREADS < total_ && !(GM_ABLATE & 4))                                                  \
+                            X[(size_t)r.w * PIPS_KIN_PAD + C + GM_TAPS * (l_) + t] = o;                                         \
+                    }                                                                                                           \
+                }                                                                                                               \
+            }
             int4 prr = make_int4(0, 0, 0, 0);
             int prm = 0;
             float4 prf[4];
@@ -785,6 +844,9 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                     GM_PRO_STORE(G0, rec)
                 }
             }
+            GM_T(1);
+            lds_barrier();                                               // (A)
+            int g = 0, countp = 0;                                       // stream index of the item's chunk 0; the previous item's particles
             for (int it = 0; it < GM_ENTS; ++it) {
                 const Geo G = geo_of(it);
                 if (G.f < 0) { more = false; break; }
@@ -793,28 +855,27 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                 int pstage = hasnext ? 0 : 3;            // next item's records / features: 0 nothing, 1 records + row index requested, 2 rows requested, 3 in LDS
                 const int count = G.count, nchunks = G.nchunks, cs1 = G.cs1, cs2 = G.cs2, cs3 = G.cs3;
                 const int4* recp = rec + (it & 1) * (GMAX * PIPS_LEVELS);
-                int4* recn = rec + ((it + 1) & 1) * (GMAX * PIPS_LEVELS);
-                GM_T(1);
-                lds_barrier();                                           // (A)
+                int4* recn = rec + ((it + 1) & 1) * (GMAX * PIPS_LEVELS);        // the next item's = the previous item's buffer
                 GM_T(30);
                 uint4 bfr[8];                                            // B operand: this lane's particle, channels 16 ks + 8 half ... + 8
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
                     bfr[ks] = *reinterpret_cast<const uint4*>(smem + GM_FEAT_OFF + jme * 256 + (((ks * 2 + half) ^ (jme & 15)) << 4));
                 const bool active = pb * 32 < count;                     // (wave-uniform) this wave's particle block holds particles
-                for (int s = 0; s <= nchunks; ++s) {
+                for (int s = 0; s < nchunks; ++s) {
                     GM_T(40);
-                    // the next item's prologue (the feature buffer is free behind step 0's barrier, the records go to the other buffer)
+                    // the next item's prologue (the feature buffer is free behind step 0's barrier, the other record buffer behind the
+                    // previous item's last blend in step 0)
                     if (pstage == 0 && s >= 1) { GM_PRO_LOAD1(Gn) pstage = 1; }
                     else if (pstage == 1 && s >= 3) { GM_PRO_LOAD2() pstage = 2; }
                     else if (pstage == 2 && s >= 5) { GM_PRO_STORE(Gn, recn) pstage = 3; }
-                    if (s == nchunks && pstage < 3) {                    // (an item of fewer than six steps: the rest, exposed)
+                    if (s == nchunks - 1 && pstage < 3) {                // (an item of fewer than six chunks: the rest, exposed)
                         if (pstage < 1) GM_PRO_LOAD1(Gn)
                         if (pstage < 2) GM_PRO_LOAD2()
                         GM_PRO_STORE(Gn, recn)
                         pstage = 3;
                     }
-                    if (s < nchunks && active && !(GM_ABLATE & 2)) {
+                    if (active && !(GM_ABLATE & 2)) {
                         // ---- products of chunk s: this wave's block of the chunk x its particle block, scattered into the windows
                         const int l = GM_LEVEL_OF(G, s);
                         const int c0 = (s - GM_SEL4(l, 0, cs1, cs2, cs3)) * GM_CHUNK;
@@ -827,7 +888,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                             f32x16 acc;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                            const char* ap = smem + (s & 1) * GM_STAGE + bl * GM_BLK_BYTES + l31 * 256;
+                            const char* ap = smem + ((g + s) & 1) * GM_STAGE + bl * GM_BLK_BYTES + l31 * 256;
 #pragma unroll
                             for (int ks = 0; ks < 8; ++ks) {
                                 const uint4 a = *reinterpret_cast<const uint4*>(ap + (((ks * 2 + half) ^ (l31 & 15)) << 4));
@@ -855,37 +916,24 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                         }
                     }
                     GM_T(42);
-                    if (s > 0 && (s == cs1 || s == cs2 || s == cs3 || s == nchunks)) {
-                        // ---- the step after a level's last chunk: 2x2 blend of its 8x8 correlations to the 49 taps, k = ix*7 + iy
-                        //      (transposed, :379-381); neighbours outside the map count as zero (:324)
+                    if (s == 0) {
+                        if (it > 0) { GM_BLEND(3, recn, countp) GM_T(43); }
+                    } else if (s == cs1 || s == cs2 || s == cs3) {
                         const int l = GM_LEVEL_OF(G, s - 1);
-                        const int Wl = GM_SEL4(l, W0, W1, W2, W3), Hl = GM_SEL4(l, H0, H1, H2, H3);
-                        const float* winf = reinterpret_cast<const float*>(smem + GM_WIN_OFF + (l & 1) * GM_WIN_BYTES);
-                        for (int idx = tid; idx < count * GM_TAPS; idx += GM_PTHREADS) {
-                            const int j = idx / GM_TAPS, t = idx - j * GM_TAPS;
-                            const int ti = t / 7, tj = t - ti * 7;
-                            const int4 r = recp[j * PIPS_LEVELS + l];
-                            const float wx = __int_as_float(r.y), wy = __int_as_float(r.z);
-                            const int px = (int)(short)(r.x & 0xffff) + ti, py = (r.x >> 16) + tj;        // map pixel of the tap's north-west neighbour
-                            const bool x0in = (unsigned)px < (unsigned)Wl, x1in = (unsigned)(px + 1) < (unsigned)Wl,
-                                       y0in = (unsigned)py < (unsigned)Hl, y1in = (unsigned)(py + 1) < (unsigned)Hl;
-                            const float* wv = winf + j * GM_WIN_ROW + tj * 8 + ti;
-                            const float nw = (x0in && y0in) ? wv[0] : 0.f, ne = (x1in && y0in) ? wv[1] : 0.f,
-                                        sw = (x0in && y1in) ? wv[8] : 0.f, se = (x1in && y1in) ? wv[9] : 0.f;
-                            const float e = 1.0f - wx, so = 1.0f - wy;
-                            const float k128 = 0.08838834764831845f;                              // the 1/sqrt(128) of :397 rides on the weights
-                            const float w0 = __fmul_rn(__fmul_rn(so, e), k128), w1 = __fmul_rn(__fmul_rn(so, wx), k128),
-                                        w2 = __fmul_rn(__fmul_rn(wy, e), k128), w3 = __fmul_rn(__fmul_rn(wy, wx), k128);
-                            float o = __fmul_rn(w0, nw);
-                            o = fmaf(w1, ne, o); o = fmaf(w2, sw, o); o = fmaf(w3, se, o);
-                            if (!(GM_ABLATE & 4)) X[(size_t)r.w * PIPS_KIN_PAD + C + GM_TAPS * l + t] = o;
-                        }
+                        GM_BLEND(l, recp, count)
                         GM_T(43);
                     }
                     lds_barrier();
                     GM_T(44);
                 }
+                if (!hasnext) {                                          // the batch's last item: its last level, exposed
+                    GM_BLEND(3, recp, count)
+                    lds_barrier();
+                }
+                g += nchunks;
+                countp = count;
             }
+#undef GM_BLEND
         }
         if (!more) break;
       }
