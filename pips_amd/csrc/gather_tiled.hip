@@ -568,6 +568,9 @@ constexpr int GM_TRN = 8192;
 #ifndef GM_BU
 #define GM_BU 2          // taps per thread and pass of the blend (3: same time, 8 more registers; 4 spills)
 #endif
+#ifndef GM_NOSKIP
+#define GM_NOSKIP 0     // 1: no skipping of (pixel block, particle block) pairs without a window (probe)
+#endif
 #ifndef GM_ABLATE
 #define GM_ABLATE 0      // debugging builds only: 1 no map loads, 2 no products / scatter, 4 no stores, 8 no feature loads, 16 items only
 #endif
@@ -885,6 +888,13 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                         if (gb < nblk) {
                             const int rx_ = recp[jme * PIPS_LEVELS + l].x;           // window anchor in region coordinates
                             const int bxr = (int)(short)(rx_ & 0xffff) - (P & 0xffff), byr = (rx_ >> 16) - (int)((unsigned)P >> 16);
+                            const unsigned inv_nbx = (65536u + (unsigned)nbx - 1u) / (unsigned)nbx;
+                            const int byi = (int)(((unsigned)gb * inv_nbx) >> 16), bxi = gb - byi * nbx;
+                            const int dx0 = bxi * 8 + 4 * half - bxr, dy0 = byi * 4 - byr;
+                            // a lane's 4 x 4 pixels touch its particle's window iff dx0, dy0 in [-3, 7]; particles are binned by 4 x 4
+                            // cell, a block of 32 consecutive ones covers part of the tile: a pixel block none of them reaches is skipped
+                            const bool hit = (unsigned)(dx0 + 3) < 11u && (unsigned)(dy0 + 3) < 11u;
+                            if (__builtin_amdgcn_ballot_w64(hit) != 0ull || (GM_NOSKIP)) {
                             f32x16 acc;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -899,9 +909,6 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                             { int d_; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(d_) : "v"(acc[15])); asm volatile("" :: "s"(d_)); }
                             GM_T(41);
 #endif
-                            const unsigned inv_nbx = (65536u + (unsigned)nbx - 1u) / (unsigned)nbx;
-                            const int byi = (int)(((unsigned)gb * inv_nbx) >> 16), bxi = gb - byi * nbx;
-                            const int dx0 = bxi * 8 + 4 * half - bxr, dy0 = byi * 4 - byr;
                             // branch-free: a value outside its particle's window goes to a per-lane dummy slot instead (16 selects + 16
                             // unconditional ds_write_b32)
                             const unsigned wbo = (unsigned)(GM_WIN_OFF + (l & 1) * GM_WIN_BYTES + jme * (GM_WIN_ROW * 4) + dy0 * 32 + dx0 * 4);
@@ -913,6 +920,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                                     const bool ok = (unsigned)(dx0 + x) < 8u && (unsigned)(dy0 + y) < 8u;
                                     *reinterpret_cast<float*>(smem + (ok ? wbo + (unsigned)(y * 32 + x * 4) : dmy)) = acc[y * 4 + x];
                                 }
+                            }
                         }
                     }
                     GM_T(42);
