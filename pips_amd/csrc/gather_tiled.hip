@@ -1150,15 +1150,16 @@ __global__ __launch_bounds__(GW_THREADS) void gather_wave_kernel(const unsigned 
                 if (l3 < PIPS_LEVELS && !(GW_ABLATE & 4)) GW_LOAD(D, l3, b3)                                                                        \
             }                                                                                                                   \
             if (!(GW_ABLATE & 2)) GW_COMPUTE(l0, b0)                                                                            \
-            if (l1 != l0 && !(GW_ABLATE & 1)) {                      /* the level's last block (of this wave): its taps */                          \
+            if (l1 != l0 && !(GW_ABLATE & 1)) {  /* the level's last block (of this wave): its taps -- and those of the levels before it   \
+                                                    that no window of this wave reached (all outside the map: zeros) */          \
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
-                GW_BLEND(l0)                                                                                                    \
+                for (; lb <= l0; ++lb) GW_BLEND(lb)                                                                             \
             }                                                                                                                   \
             l0 = l1; b0 = b1; l1 = l2; b1 = b2; l2 = l3; b2 = b3;                                                               \
         }
         u32x4_gw opA0, opA1, opA2, opA3, opA4, opA5, opA6, opA7, opB0, opB1, opB2, opB3, opB4, opB5, opB6, opB7,
                  opC0, opC1, opC2, opC3, opC4, opC5, opC6, opC7;
-        int l0 = 0, b0 = -1;
+        int l0 = 0, b0 = -1, lb = 0;                                   // lb: the next level to blend
         GW_ADVANCE(l0, b0)
         int l1 = l0, b1 = b0;
         if (l1 < PIPS_LEVELS) GW_ADVANCE(l1, b1)
@@ -1174,6 +1175,8 @@ __global__ __launch_bounds__(GW_THREADS) void gather_wave_kernel(const unsigned 
             if (l0 >= PIPS_LEVELS) break;
             GW_STEP(C)
         }
+        if (!(GW_ABLATE & 1))
+            for (; lb < PIPS_LEVELS; ++lb) GW_BLEND(lb)                // (levels behind the last block reached)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (the last blend has read this unit's records and windows)
 #undef GW_STEP
 #undef GW_BLEND
