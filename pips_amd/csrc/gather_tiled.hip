@@ -545,14 +545,15 @@ constexpr int GM_WIN_BYTES = GMAX * GM_WIN_ROW * 4;
 constexpr int GM_WIN_OFF = 2 * GM_STAGE + 128;    // (the scatter's per-lane base may lie up to 108 bytes below a particle's window)
 constexpr int GM_REC_OFF = GM_WIN_OFF + 2 * GM_WIN_BYTES;
 constexpr int GM_FEAT_OFF = GM_REC_OFF + 2 * GMAX * PIPS_LEVELS * 16;      // (two record buffers: item parity)
-constexpr int GM_ENTS = 64;                       // work-item entries looked up at a time
+constexpr int GM_ENTS = 16;                       // work items looked up at a time (a batch; BASELINE configs[3] has 8 per block: tests/test_kernels_gpu.py
+                                                  // ::test_gather_mfma_batches covers blocks that walk several batches)
 constexpr int GM_ENT_OFF = GM_FEAT_OFF + GMAX * C * 2;
 constexpr int GM_DUMMY_OFF = GM_ENT_OFF + GM_ENTS * 64;          // 256 bytes: where the scatter's out-of-window values go
 constexpr int GM_LDS = GM_DUMMY_OFF + 256;
 constexpr int GM_TAPS = 49;                       // (2 r + 1)^2 taps per level (PIPS_NCORR = 4 x 49 is a mixer row's whole correlation block)
 constexpr int GM_PIECES = GM_CHUNK * 32 * 16 / GM_LTHREADS;                        // 16-byte pieces per loader thread and chunk (8)
 static_assert(GM_PB * GM_CHUNK == GM_PWAVES && GM_CHUNK * 32 * 16 % GM_LTHREADS == 0, "wave <-> (particle block, block of the chunk)");
-static_assert(GM_LDS <= 160 * 1024 && GM_WIN_OFF % 16 == 0 && GM_REC_OFF % 16 == 0 && GM_FEAT_OFF % 16 == 0, "LDS layout");
+static_assert(GM_ENTS <= 64 && GM_LDS <= 160 * 1024 && GM_WIN_OFF % 16 == 0 && GM_REC_OFF % 16 == 0 && GM_FEAT_OFF % 16 == 0, "LDS layout");
 
 typedef __bf16 bf16x8_gm __attribute__((ext_vector_type(8)));
 #ifdef GM_TRACE          // tuning builds (tools/gm_trace.py): time stamps of waves 0 (product) and 12 (loader) of blocks 0 and 1
@@ -649,12 +650,12 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
 #define geo_of(it_) gm_geo(ent, (it_))
     typedef GmGeo Geo;
 #define GM_LEVEL_OF(G_, ci_) (((ci_) >= G_.cs1) + ((ci_) >= G_.cs2) + ((ci_) >= G_.cs3))
-    // ---- a batch = this block's next (up to) 64 work items: item i of the block is entry jb + i J of the XCD's list (frames xcd,
+    // ---- a batch = this block's next (up to) GM_ENTS work items: item i of the block is entry jb + i J of the XCD's list (frames xcd,
     //      xcd + 8, ... one after another); lane-parallel look-up by wave 0, the items' geometry (gm_geo_store) in LDS.  Each role
     //      runs its own loop over the batches (one loop around both roles keeps either role's values alive through the other: spills)
 #define GM_BATCH_HEAD()                                                                                                         \
         lds_barrier();                                                                                                          \
-        if (wave == 0) {                                                                                                        \
+        if (wave == 0 && lane < GM_ENTS) {                                                                                      \
             int gi = jb + (base + lane) * J, fr = xcd;                                                                          \
             int4 e = make_int4(0, 0, 0, -1);                                                                                    \
             for (; fr < F; fr += 8) {                                                                                           \
@@ -946,250 +947,6 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
 #undef geo_of
 }
 
-// ---------------------------------------------------------------------------- the same products without a block: gather_wave_kernel
-// gather_mfma_kernel's 16 waves walk an item in lock-step (one barrier per chunk), and the trace (tools/gm_trace.py) shows what that
-// costs: every step lasts as long as its slowest wave and nothing overlaps inside a wave.  Here a WAVE is the unit: it owns up to 32
-// particles of one tile (an item's particle block) and does everything for them -- no loader waves, no barrier:
-//   * the pixel blocks (8 x 4 pixels x 128 channels bf16 = 8 KiB) that a window of its particles reaches, of all four levels, form ONE
-//     sequence; three blocks are in flight in three register sets (coalesced: an instruction = four whole pixels, 16 lanes x 16 bytes
-//     each; inline-assembly loads and explicit wait counts -- the compiler's counter pass waits for everything behind a conditional
-//     load);
-//   * an arrived block goes through the wave's own 8 KiB of LDS into the MFMA operand layout (lane-linear ds_write_b128; the source
-//     chunk index is XORed with the pixel index on the GLOBAL side, so the fragment reads are conflict-free) -- a wave's LDS
-//     operations execute in order, a wait on lgkmcnt is all the synchronisation there is;
-//   * products, window scatter, blend and tap stores as in gather_mfma_kernel (same arithmetic, K order and results), the windows in
-//     the wave's own buffer.
-// Eight independent waves per compute unit (18.3 KiB of LDS each, <= 256 registers) hide one another's latencies.
-typedef unsigned u32x4_gw __attribute__((ext_vector_type(4)));
-#ifndef GW_DEFAULT
-#define GW_DEFAULT 0
-#endif
-#ifndef GW_ABLATE
-#define GW_ABLATE 0      // debugging builds: 1 no blend / tap stores, 2 no products / scatter, 4 no block loads, 8 no stage writes
-#endif
-constexpr int GW_WAVES = 8, GW_THREADS = GW_WAVES * 64;
-constexpr int GW_WIN_BYTES = 32 * GM_WIN_ROW * 4;                  // one wave's windows: 32 particles x (64 + 1) floats
-constexpr int GW_REC_BYTES = 32 * PIPS_LEVELS * 16;                // its records
-constexpr int GW_WIN_OFF = GM_BLK_BYTES + 128;                     // (stage buffer first; the scatter's base may lie 108 bytes below a window)
-constexpr int GW_REC_OFF = GW_WIN_OFF + GW_WIN_BYTES;
-constexpr int GW_WAVE_LDS = (GW_REC_OFF + GW_REC_BYTES + 255) / 256 * 256;
-constexpr int GW_LDS = GW_WAVES * GW_WAVE_LDS;
-static_assert(GW_LDS <= 160 * 1024 && GW_WIN_OFF % 16 == 0 && GW_REC_OFF % 16 == 0, "LDS layout");
-
-__global__ __launch_bounds__(GW_THREADS) void gather_wave_kernel(const unsigned short* __restrict__ mirror, TiledLevels lv,
-                                                                const float* __restrict__ ffeats, int N, int max_items, int F,
-                                                                const int4* __restrict__ order, const int4* __restrict__ items,
-                                                                const int* __restrict__ nitems, int tiles_x, float* __restrict__ X) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xcd = blockIdx.x & 7, J = (gridDim.x >> 3) * GW_WAVES, jw = (blockIdx.x >> 3) * GW_WAVES + wave;
-    char* wbase = smem + wave * GW_WAVE_LDS;
-    float* winf = reinterpret_cast<float*>(wbase + GW_WIN_OFF);
-    int4* recw = reinterpret_cast<int4*>(wbase + GW_REC_OFF);
-    const int W0 = lv.W[0], W1 = lv.W[1], W2 = lv.W[2], W3 = lv.W[3], H0 = lv.H[0], H1 = lv.H[1], H2 = lv.H[2], H3 = lv.H[3];
-    const size_t o0 = lv.off[0], o1 = lv.off[1], o2 = lv.off[2], o3 = lv.off[3];
-    // loads: lane t = (pixel q = t >> 4 of the instruction's four, chunk slot c = t & 15); instruction n = 2 r + e covers pixels
-    // 4 n + q = row r, x = 4 e + q of the block and fetches chunk (c ^ q) ^ 4 (n & 3) into LDS slot c of its pixel
-    const unsigned cq = (unsigned)((lane & 15) ^ (lane >> 4));
-    const unsigned cp0 = (unsigned)(lane >> 4) * 256u + ((cq ^ 0u) << 4), cp1 = (unsigned)(lane >> 4) * 256u + ((cq ^ 4u) << 4),
-                   cp2 = (unsigned)(lane >> 4) * 256u + ((cq ^ 8u) << 4), cp3 = (unsigned)(lane >> 4) * 256u + ((cq ^ 12u) << 4);
-    char* stw = wbase + lane * 16;                                                        // this lane's slot of a pixel quad
-    const char* strd = wbase + l31 * 256;                                                 // this lane's pixel row (MFMA row l31)
-#define GM_SEL4(l_, a0, a1, a2, a3) ((l_) == 0 ? (a0) : ((l_) == 1 ? (a1) : ((l_) == 2 ? (a2) : (a3))))
-    for (int k = 0;; ++k) {
-        // ---- this wave's k-th unit = (item, particle block): unit jw + k J of the XCD's list (frames xcd, xcd + 8, ... one after another)
-        const int u = jw + k * J;
-        int gi = u / GM_PB, fr = xcd;
-        const int pb = u - gi * GM_PB;
-        for (; fr < F; fr += 8) {
-            const int n = nitems[fr];
-            if (gi < n) break;
-            gi -= n;
-        }
-        if (fr >= F) break;
-        const int4 ev = items[(size_t)fr * max_items + gi];
-        const int tile = __builtin_amdgcn_readfirstlane(ev.x), first = __builtin_amdgcn_readfirstlane(ev.y) + pb * 32;
-        const int cnt = min(__builtin_amdgcn_readfirstlane(ev.z) - pb * 32, 32);
-        if (cnt <= 0) continue;
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        int P0, P1, P2, P3, Q0, Q1, Q2, Q3;
-        gm_level_geom(0, tx, ty, W0, H0, P0, Q0);
-        gm_level_geom(1, tx, ty, W1, H1, P1, Q1);
-        gm_level_geom(2, tx, ty, W2, H2, P2, Q2);
-        gm_level_geom(3, tx, ty, W3, H3, P3, Q3);
-        // ---- records -> LDS (lane, lane + 64 = (particle, level) 4 j + l; slots past the wave's particles get a far-away anchor)
-        {
-            const int4* ob = order + ((size_t)fr * N + first) * PIPS_LEVELS;
-            int4 r0 = ob[min(lane, cnt * PIPS_LEVELS - 1)], r1 = ob[min(lane + 64, cnt * PIPS_LEVELS - 1)];
-            if ((lane >> 2) >= cnt) r0 = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);
-            if (((lane + 64) >> 2) >= cnt) r1 = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);
-            recw[lane] = r0;
-            recw[lane + 64] = r1;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        // ---- this lane's particle: anchors of the four levels, feature row -> B operand (bf16 RNE, channels 16 ks + 8 half ... + 8)
-        const int a0 = recw[l31 * PIPS_LEVELS + 0].x, a1 = recw[l31 * PIPS_LEVELS + 1].x, a2 = recw[l31 * PIPS_LEVELS + 2].x,
-                  a3 = recw[l31 * PIPS_LEVELS + 3].x;
-        uint4 bfr[8];
-        {
-            const int mrow = recw[min(l31, cnt - 1) * PIPS_LEVELS].w;
-            const float4* fp = reinterpret_cast<const float4*>(ffeats + (size_t)mrow * C + 8 * half);
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const float4 u0 = fp[4 * ks], u1 = fp[4 * ks + 1];
-                bfr[ks] = make_uint4(pack2_bf16(u0.x, u0.y), pack2_bf16(u0.z, u0.w), pack2_bf16(u1.x, u1.y), pack2_bf16(u1.z, u1.w));
-            }
-        }
-        // a level's scalars (wave-uniform) and this lane's window anchor in the level's region coordinates
-#define GW_LEVEL(l_)                                                                                                            \
-        const int P_ = GM_SEL4(l_, P0, P1, P2, P3), Q_ = GM_SEL4(l_, Q0, Q1, Q2, Q3);                                           \
-        const int x0_ = P_ & 0xffff, y0_ = (unsigned)P_ >> 16, nbx_ = (Q_ >> 16) & 0xff, nblk_ = (unsigned)Q_ >> 24;            \
-        const unsigned inv_ = (65536u + (unsigned)nbx_ - 1u) / (unsigned)nbx_;       /* block -> block row: exact for < 256 blocks */ \
-        const int an_ = GM_SEL4(l_, a0, a1, a2, a3);                                                                            \
-        const int ax_ = (int)(short)(an_ & 0xffff) - x0_, ay_ = (an_ >> 16) - y0_;
-        // (ql, qb) -> the next (level, block) behind it that a window of this wave reaches (a lane's 4 x 4 pixels touch its window iff
-        // dx0, dy0 in [-3, 7]); ql = PIPS_LEVELS: none.  Particles are binned by 4 x 4 cell: 32 consecutive ones cover part of the tile
-#define GW_ADVANCE(ql, qb)                                                                                                      \
-        for (;;) {                                                                                                              \
-            ++qb;                                                                                                               \
-            GW_LEVEL(ql)                                                                                                        \
-            if (qb >= nblk_) { qb = -1; if (++ql >= PIPS_LEVELS) break; continue; }                                             \
-            const int byi_ = (int)(((unsigned)qb * inv_) >> 16), bxi_ = qb - byi_ * nbx_;                                       \
-            const int dx_ = bxi_ * 8 + 4 * half - ax_, dy_ = byi_ * 4 - ay_;                                                    \
-            if (__builtin_amdgcn_ballot_w64((unsigned)(dx_ + 3) < 11u && (unsigned)(dy_ + 3) < 11u) != 0ull) break;             \
-        }
-        // block (ql, qb) requested into register set D: no mask and no clamp, as gather_mfma_kernel's loaders (the slack behind the mirror)
-#define GW_LOAD(D, ql, qb)                                                                                                      \
-        {                                                                                                                       \
-            GW_LEVEL(ql)                                                                                                        \
-            const int Wl_ = GM_SEL4(ql, W0, W1, W2, W3), Hl_ = GM_SEL4(ql, H0, H1, H2, H3);                                     \
-            const size_t ol_ = GM_SEL4(ql, o0, o1, o2, o3);                                                                     \
-            const int byi_ = (int)(((unsigned)(qb) * inv_) >> 16), bxi_ = (qb) - byi_ * nbx_;                                   \
-            const char* sb0_ = reinterpret_cast<const char*>(mirror + ol_ + (size_t)fr * Hl_ * Wl_ * C) +                       \
-                               (size_t)((unsigned)((y0_ + byi_ * 4) * Wl_ + x0_ + bxi_ * 8) * (unsigned)(C * 2));               \
-            const char* sb1_ = sb0_ + (size_t)Wl_ * (C * 2); const char* sb2_ = sb1_ + (size_t)Wl_ * (C * 2);                   \
-            const char* sb3_ = sb2_ + (size_t)Wl_ * (C * 2);                                                                    \
-            (void)ax_; (void)ay_; (void)nblk_;                                                                                  \
-            asm volatile("global_load_dwordx4 %0, %8, %12\n\tglobal_load_dwordx4 %1, %9, %12 offset:1024\n\t"                   \
-                         "global_load_dwordx4 %2, %10, %13\n\tglobal_load_dwordx4 %3, %11, %13 offset:1024\n\t"                 \
-                         "global_load_dwordx4 %4, %8, %14\n\tglobal_load_dwordx4 %5, %9, %14 offset:1024\n\t"                   \
-                         "global_load_dwordx4 %6, %10, %15\n\tglobal_load_dwordx4 %7, %11, %15 offset:1024"                     \
-                         : "=&v"(op##D##0), "=&v"(op##D##1), "=&v"(op##D##2), "=&v"(op##D##3), "=&v"(op##D##4),                 \
-                           "=&v"(op##D##5), "=&v"(op##D##6), "=&v"(op##D##7)                                                    \
-                         : "v"(cp0), "v"(cp1), "v"(cp2), "v"(cp3), "s"(sb0_), "s"(sb1_), "s"(sb2_), "s"(sb3_) : "memory");      \
-        }
-#define GW_WAIT(n_, D)                                                                                                          \
-        asm volatile("s_waitcnt vmcnt(" #n_ ")" : "+v"(op##D##0), "+v"(op##D##1), "+v"(op##D##2), "+v"(op##D##3),               \
-                     "+v"(op##D##4), "+v"(op##D##5), "+v"(op##D##6), "+v"(op##D##7) :: "memory");
-        // set D -> the stage buffer (lane-linear: pixel 4 n + q at 256 (4 n + q), slot c)
-#define GW_STAGE(D)                                                                                                             \
-        *reinterpret_cast<u32x4_gw*>(stw) = op##D##0;        *reinterpret_cast<u32x4_gw*>(stw + 1024) = op##D##1;               \
-        *reinterpret_cast<u32x4_gw*>(stw + 2048) = op##D##2; *reinterpret_cast<u32x4_gw*>(stw + 3072) = op##D##3;               \
-        *reinterpret_cast<u32x4_gw*>(stw + 4096) = op##D##4; *reinterpret_cast<u32x4_gw*>(stw + 5120) = op##D##5;               \
-        *reinterpret_cast<u32x4_gw*>(stw + 6144) = op##D##6; *reinterpret_cast<u32x4_gw*>(stw + 7168) = op##D##7;
-        // products of the staged block (cl, cb) x this wave's particles, scattered into its windows
-#define GW_COMPUTE(cl, cb)                                                                                                      \
-        {                                                                                                                       \
-            GW_LEVEL(cl)                                                                                                        \
-            (void)nblk_;                                                                                                        \
-            f32x16 acc;                                                                                                         \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                                        \
-            _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                                  \
-                const uint4 a = *reinterpret_cast<const uint4*>(strd + (((ks * 2 + half) ^ (l31 & 15)) << 4));                  \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_gm*>(&a),                          \
-                                                              *reinterpret_cast<const bf16x8_gm*>(&bfr[ks]), acc, 0, 0, 0);     \
-            }                                                                                                                   \
-            const int byi_ = (int)(((unsigned)(cb) * inv_) >> 16), bxi_ = (cb) - byi_ * nbx_;                                   \
-            const int dx0 = bxi_ * 8 + 4 * half - ax_, dy0 = byi_ * 4 - ay_;                                                    \
-            float* wp = winf + l31 * GM_WIN_ROW + dy0 * 8 + dx0;                                                                \
-            _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                                       \
-                _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                   \
-                    if ((unsigned)(dx0 + x) < 8u && (unsigned)(dy0 + y) < 8u) wp[y * 8 + x] = acc[y * 4 + x];                   \
-        }
-        // 2x2 blend of a level's 8x8 correlations to the 49 taps, k = ix*7 + iy (transposed, :379-381); neighbours outside the map count
-        // as zero (:324): the weights, scaling and operation order of gather_mfma_kernel's blend
-#define GW_BLEND(bl_)                                                                                                           \
-        {   /* a lane = one (particle, iy) row of 7 taps, as gather_mfma_kernel's blend */                                      \
-            const int Wl = GM_SEL4(bl_, W0, W1, W2, W3), Hl = GM_SEL4(bl_, H0, H1, H2, H3);                                     \
-            for (int idx = lane; idx < cnt * 7; idx += 64) {                                                                    \
-                const int j = idx / 7, tj = idx - j * 7;                                                                        \
-                const int4 r = recw[j * PIPS_LEVELS + (bl_)];                                                                   \
-                const float* wv = winf + j * GM_WIN_ROW + tj * 8;                                                               \
-                float z0[8], z1[8];                                                                                             \
-                _Pragma("unroll") for (int c = 0; c < 8; ++c) { z0[c] = wv[c]; z1[c] = wv[8 + c]; }                             \
-                const int px = (int)(short)(r.x & 0xffff), py = (r.x >> 16) + tj;                                               \
-                const bool y0in = (unsigned)py < (unsigned)Hl, y1in = (unsigned)(py + 1) < (unsigned)Hl;                        \
-                _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                 \
-                    const bool xin = (unsigned)(px + c) < (unsigned)Wl;                                                         \
-                    z0[c] = (xin && y0in) ? z0[c] : 0.f;                                                                        \
-                    z1[c] = (xin && y1in) ? z1[c] : 0.f;                                                                        \
-                }                                                                                                               \
-                const float wx = __int_as_float(r.y), wy = __int_as_float(r.z);                                                 \
-                const float e = 1.0f - wx, so = 1.0f - wy;                                                                      \
-                const float k128 = 0.08838834764831845f;                                                                        \
-                const float w0 = __fmul_rn(__fmul_rn(so, e), k128), w1 = __fmul_rn(__fmul_rn(so, wx), k128),                    \
-                            w2 = __fmul_rn(__fmul_rn(wy, e), k128), w3 = __fmul_rn(__fmul_rn(wy, wx), k128);                    \
-                float* xo = X + ((size_t)r.w * PIPS_KIN_PAD + C + GM_TAPS * (bl_) + tj);                                        \
-                _Pragma("unroll") for (int ti = 0; ti < 7; ++ti) {                                                              \
-                    float o = __fmul_rn(w0, z0[ti]);                                                                            \
-                    o = fmaf(w1, z0[ti + 1], o); o = fmaf(w2, z1[ti], o); o = fmaf(w3, z1[ti + 1], o);                          \
-                    xo[ti * 7] = o;                                                                                             \
-                }                                                                                                               \
-            }                                                                                                                   \
-        }
-        // one block of the sequence: queue (l0, b0) in set D (current), (l1, b1), (l2, b2) in the two other sets; the block behind them is
-        // requested into D once D is staged.  vmcnt counts in order: <= 16 / 8 / 0 outstanding = everything but the younger sets' loads
-#define GW_STEP(D)                                                                                                              \
-        {                                                                                                                       \
-            if (l2 < PIPS_LEVELS) { GW_WAIT(16, D) } else if (l1 < PIPS_LEVELS) { GW_WAIT(8, D) } else { GW_WAIT(0, D) }        \
-            if (!(GW_ABLATE & 8)) { GW_STAGE(D) }                                                                               \
-            int l3 = l2, b3 = b2;                                                                                               \
-            if (l3 < PIPS_LEVELS) {                                                                                             \
-                GW_ADVANCE(l3, b3)                                                                                              \
-                if (l3 < PIPS_LEVELS && !(GW_ABLATE & 4)) GW_LOAD(D, l3, b3)                                                                        \
-            }                                                                                                                   \
-            if (!(GW_ABLATE & 2)) GW_COMPUTE(l0, b0)                                                                            \
-            if (l1 != l0 && !(GW_ABLATE & 1)) {  /* the level's last block (of this wave): its taps -- and those of the levels before it   \
-                                                    that no window of this wave reached (all outside the map: zeros) */          \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
-                for (; lb <= l0; ++lb) GW_BLEND(lb)                                                                             \
-            }                                                                                                                   \
-            l0 = l1; b0 = b1; l1 = l2; b1 = b2; l2 = l3; b2 = b3;                                                               \
-        }
-        u32x4_gw opA0, opA1, opA2, opA3, opA4, opA5, opA6, opA7, opB0, opB1, opB2, opB3, opB4, opB5, opB6, opB7,
-                 opC0, opC1, opC2, opC3, opC4, opC5, opC6, opC7;
-        int l0 = 0, b0 = -1, lb = 0;                                   // lb: the next level to blend
-        GW_ADVANCE(l0, b0)
-        int l1 = l0, b1 = b0;
-        if (l1 < PIPS_LEVELS) GW_ADVANCE(l1, b1)
-        int l2 = l1, b2 = b1;
-        if (l2 < PIPS_LEVELS) GW_ADVANCE(l2, b2)
-        if (l0 < PIPS_LEVELS && !(GW_ABLATE & 4)) GW_LOAD(A, l0, b0)
-        if (l1 < PIPS_LEVELS && !(GW_ABLATE & 4)) GW_LOAD(B, l1, b1)
-        if (l2 < PIPS_LEVELS && !(GW_ABLATE & 4)) GW_LOAD(C, l2, b2)
-        while (l0 < PIPS_LEVELS) {
-            GW_STEP(A)
-            if (l0 >= PIPS_LEVELS) break;
-            GW_STEP(B)
-            if (l0 >= PIPS_LEVELS) break;
-            GW_STEP(C)
-        }
-        if (!(GW_ABLATE & 1))
-            for (; lb < PIPS_LEVELS; ++lb) GW_BLEND(lb)                // (levels behind the last block reached)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (the last blend has read this unit's records and windows)
-#undef GW_STEP
-#undef GW_BLEND
-#undef GW_COMPUTE
-#undef GW_STAGE
-#undef GW_WAIT
-#undef GW_LOAD
-#undef GW_ADVANCE
-#undef GW_LEVEL
-    }
-#undef GM_SEL4
-}
-
 // ---------------------------------------------------------------------------- host side
 static int tiled_max_items(int N, int H8, int W8) { return cdiv(W8, TS) * cdiv(H8, TS) + N / GMAX + 1; }
 
@@ -1278,16 +1035,6 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     const int grid = max(cus / 8, 1) * 8;
     if (ev) (void)hipEventRecord(ev[2], st);
     if (mirror != nullptr) {                     // one persistent block of 12 product + 4 loader waves per compute unit
-        if (PIPS_TUNE("PIPS_GATHER_WAVE", GW_DEFAULT)) {      // tuning hook: the block-free form (gather_wave_kernel)
-            static std::atomic<unsigned long long> raised_gw{0};
-            const int rcw = ensure_dynamic_lds(raised_gw, (const void*)gather_wave_kernel, GW_LDS);
-            if (rcw != PIPS_OK) return rcw;
-            hipLaunchKernelGGL(gather_wave_kernel, dim3(grid), dim3(GW_THREADS), GW_LDS, st, mirror, lv, ffeats, N, max_items, F,
-                               order, items, nitems, tiles_x, X);
-            if (ev) (void)hipEventRecord(ev[3], st);
-            PIPS_CHECK_LAUNCH("gather_wave_kernel");
-            return PIPS_OK;
-        }
         static std::atomic<unsigned long long> raised_gm{0};
         const int rc = ensure_dynamic_lds(raised_gm, (const void*)gather_mfma_kernel, GM_LDS);
         if (rc != PIPS_OK) return rc;

@@ -836,3 +836,35 @@ def test_fixed_window_entry_points_equal_the_general_ones(weights_raw):
         outs.append((trajs, vis, ff))
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+def test_gather_mfma_batches():
+    """gather_mfma_kernel's blocks walk their work items in batches (GM_ENTS = 16 per look-up; BASELINE configs[3] gives a block 8): with
+    192 tiles per frame and four frames per XCD a block gets 24+ items, i.e. a second batch whose first item starts from a drained
+    pipeline.  A clip's rows depend on nothing but that clip, so the four clips gathered in ONE launch (several batches per block)
+    must equal, bit for bit, each clip gathered alone (a single batch per block)."""
+    from pips_amd import ops, _lib
+    lib = _lib.load()
+    B, H8, W8, N = 4, 192, 256, 4096
+    F, M = B * 8, B * N * 8
+    g = torch.Generator(device=DEV).manual_seed(5)
+    per = lib.pips_pyramid_floats(8, H8 * 8, W8 * 8, 8)
+    ff = torch.randn(M, 128, generator=g, device=DEV)
+    co = torch.rand(M, 2, generator=g, device=DEV) * torch.tensor([W8 + 6.0, H8 + 6.0], device=DEV) - 3.0
+    assert lib.pips_gather_route(B, N, H8, W8, 32) == 2 and lib.pips_gather_route(1, N, H8, W8, 32) == 2
+    clips, outs = [], []
+    for b in range(B):                                   # one clip at a time: 6 items per block
+        pyr1 = ops.pyramid_mirror(torch.randn(per, generator=g, device=DEV), 8, H8 * 8, W8 * 8, 8)
+        sl = slice(b * N * 8, (b + 1) * N * 8)
+        outs.append(ops.mixer_input_build_tiled(pyr1, 1, H8, W8, ff[sl].contiguous(), co[sl].contiguous(), bf16_maps=True).clone())
+        clips.append(pyr1)
+    # the same maps as ONE four-clip buffer (level-major: every level holds the frames of all clips)
+    pyr4 = torch.empty(lib.pips_pyramid_floats(F, H8 * 8, W8 * 8, 8), device=DEV)
+    for dst, srcs in zip(ops.pyramid_levels(pyr4, F, H8 * 8, W8 * 8, 8),
+                         zip(*[ops.pyramid_levels(p, 8, H8 * 8, W8 * 8, 8) for p in clips])):
+        dst.copy_(torch.cat(list(srcs), 0))
+    ops.pyramid_mirror(pyr4, F, H8 * 8, W8 * 8, 8)
+    X4 = ops.mixer_input_build_tiled(pyr4, B, H8, W8, ff, co, bf16_maps=True)
+    X1 = torch.cat(outs, 0)
+    assert torch.isfinite(X4).all()
+    assert torch.equal(X4, X1)
