@@ -548,8 +548,9 @@ constexpr int GM_FEAT_OFF = GM_REC_OFF + 2 * GMAX * PIPS_LEVELS * 16;      // (t
 constexpr int GM_ENTS = 16;                       // work items looked up at a time (a batch; BASELINE configs[3] has 8 per block: tests/test_kernels_gpu.py
                                                   // ::test_gather_mfma_batches covers blocks that walk several batches)
 constexpr int GM_ENT_OFF = GM_FEAT_OFF + GMAX * C * 2;
-constexpr int GM_DUMMY_OFF = GM_ENT_OFF + GM_ENTS * 64;          // 256 bytes: where the scatter's out-of-window values go
-constexpr int GM_LDS = GM_DUMMY_OFF + 256;
+constexpr int GM_CHUNKS_MAX = 16;                 // chunks per item (TS = 16: 5 + 4 + 2 + 2 at most)
+constexpr int GM_CT_OFF = GM_ENT_OFF + GM_ENTS * 64;             // per item and chunk: the four blocks' byte offsets in the mirror
+constexpr int GM_LDS = GM_CT_OFF + GM_ENTS * GM_CHUNKS_MAX * 16;
 constexpr int GM_TAPS = 49;                       // (2 r + 1)^2 taps per level (PIPS_NCORR = 4 x 49 is a mixer row's whole correlation block)
 constexpr int GM_PIECES = GM_CHUNK * 32 * 16 / GM_LTHREADS;                        // 16-byte pieces per loader thread and chunk (8)
 static_assert(GM_PB * GM_CHUNK == GM_PWAVES && GM_CHUNK * 32 * 16 % GM_LTHREADS == 0, "wave <-> (particle block, block of the chunk)");
@@ -594,7 +595,8 @@ __device__ __forceinline__ void gm_level_geom(int l, int tx, int ty, int Wl, int
 struct GmGeo { int first, count, f, P0, P1, P2, P3, Q0, Q1, Q2, Q3, cs1, cs2, cs3, nchunks; };
 // one lane's entry {tile, first, count, frame} -> the item's geometry, as 4 x int4 (the batch head: lane i works out item i once;
 // worked out per item by every wave instead, the scalar code sat on the loaders' path, tools/gm_trace.py)
-__device__ __forceinline__ void gm_geo_store(int4* geo, int4 ev, int tiles_x, int W0, int W1, int W2, int W3, int H0, int H1, int H2, int H3) {
+__device__ __forceinline__ void gm_geo_store(int4* geo, uint4* ct, int4 ev, int tiles_x, int W0, int W1, int W2, int W3, int H0, int H1, int H2,
+                                             int H3, unsigned ob0, unsigned ob1, unsigned ob2, unsigned ob3) {
     const int ty = ev.x / tiles_x, tx = ev.x - ty * tiles_x;
     int P0, P1, P2, P3, Q0, Q1, Q2, Q3;
     gm_level_geom(0, tx, ty, W0, H0, P0, Q0);
@@ -604,11 +606,32 @@ __device__ __forceinline__ void gm_geo_store(int4* geo, int4 ev, int tiles_x, in
     const int cs1 = (((unsigned)Q0 >> 24) + GM_CHUNK - 1) / GM_CHUNK;                 // first chunk of level 1, 2, 3; number of chunks
     const int cs2 = cs1 + (((unsigned)Q1 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
     const int cs3 = cs2 + (((unsigned)Q2 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
-    const int nchunks = cs3 + (((unsigned)Q3 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    const int nchunks = min(cs3 + (int)((((unsigned)Q3 >> 24) + GM_CHUNK - 1) / GM_CHUNK), GM_CHUNKS_MAX);
     geo[0] = make_int4(ev.y, ev.z, ev.w, nchunks);
     geo[1] = make_int4(P0, P1, P2, P3);
     geo[2] = make_int4(Q0, Q1, Q2, Q3);
     geo[3] = make_int4(cs1, cs2, cs3, 0);
+    // the loaders' table: chunk ci -> the byte offsets in the mirror of its four pixel blocks (multiples of 128: the level rides in
+    // the low bits of the first); a chunk's blocks past the level's last repeat it (never used).  Worked out here once per item --
+    // per chunk in the loaders it was 1.4 k clocks of scalar code on their path (tools/gm_trace.py)
+    if (ev.w < 0) return;
+    int ci = 0;
+#pragma unroll
+    for (int l = 0; l < PIPS_LEVELS; ++l) {
+        const int P = l == 0 ? P0 : (l == 1 ? P1 : (l == 2 ? P2 : P3)), Q = l == 0 ? Q0 : (l == 1 ? Q1 : (l == 2 ? Q2 : Q3));
+        const int Wl = l == 0 ? W0 : (l == 1 ? W1 : (l == 2 ? W2 : W3)), Hl = l == 0 ? H0 : (l == 1 ? H1 : (l == 2 ? H2 : H3));
+        const unsigned ob = l == 0 ? ob0 : (l == 1 ? ob1 : (l == 2 ? ob2 : ob3));
+        const int x0 = P & 0xffff, y0 = (unsigned)P >> 16, nbx = (Q >> 16) & 0xff, nblk = (unsigned)Q >> 24;
+        for (int c0 = 0; c0 < nblk && ci < GM_CHUNKS_MAX; c0 += GM_CHUNK, ++ci) {
+            unsigned d[GM_CHUNK];
+#pragma unroll
+            for (int b = 0; b < GM_CHUNK; ++b) {
+                const int gb = min(c0 + b, nblk - 1), byi = gb / nbx, bxi = gb - byi * nbx;
+                d[b] = ob + (unsigned)((ev.w * Hl + y0 + byi * 4) * Wl + x0 + bxi * 8) * (unsigned)(C * 2);
+            }
+            ct[ci] = make_uint4(d[0] | (unsigned)l, d[1], d[2], d[3]);
+        }
+    }
 }
 // item `it` of the batch, wave-uniform (scalars)
 __device__ __forceinline__ GmGeo gm_geo(const int4* geo, int it) {
@@ -638,7 +661,9 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
     const int xcd = blockIdx.x & 7, J = gridDim.x >> 3, jb = blockIdx.x >> 3;
     int4* rec = reinterpret_cast<int4*>(smem + GM_REC_OFF);
     int4* ent = reinterpret_cast<int4*>(smem + GM_ENT_OFF);
+    uint4* ctab = reinterpret_cast<uint4*>(smem + GM_CT_OFF);
     const int jme = pb * 32 + l31;                                   // a product lane's particle (MFMA column) within the item
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);      // (for ds_write in assembly)
     // the levels' map sizes and offsets as scalars (static indices: a dynamically indexed kernel-argument array goes to scratch)
     const int W0 = lv.W[0], W1 = lv.W[1], W2 = lv.W[2], W3 = lv.W[3], H0 = lv.H[0], H1 = lv.H[1], H2 = lv.H[2], H3 = lv.H[3];
     const size_t o0 = lv.off[0], o1 = lv.off[1], o2 = lv.off[2], o3 = lv.off[3];
@@ -651,11 +676,11 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
     typedef GmGeo Geo;
 #define GM_LEVEL_OF(G_, ci_) (((ci_) >= G_.cs1) + ((ci_) >= G_.cs2) + ((ci_) >= G_.cs3))
     // ---- a batch = this block's next (up to) GM_ENTS work items: item i of the block is entry jb + i J of the XCD's list (frames xcd,
-    //      xcd + 8, ... one after another); lane-parallel look-up by wave 0, the items' geometry (gm_geo_store) in LDS.  Each role
+    //      xcd + 8, ... one after another); lane-parallel look-up by wave 0, the items' geometry and chunk table (gm_geo_store) in LDS.  Each role
     //      runs its own loop over the batches (one loop around both roles keeps either role's values alive through the other: spills)
-#define GM_BATCH_HEAD()                                                                                                         \
+#define GM_BATCH_HEAD(LOOKUP_)                                                                                                      \
         lds_barrier();                                                                                                          \
-        if (wave == 0 && lane < GM_ENTS) {                                                                                      \
+        if ((LOOKUP_) && lane < GM_ENTS) {                                                                                      \
             int gi = jb + (base + lane) * J, fr = xcd;                                                                          \
             int4 e = make_int4(0, 0, 0, -1);                                                                                    \
             for (; fr < F; fr += 8) {                                                                                           \
@@ -664,36 +689,31 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                 gi -= n;                                                                                                        \
             }                                                                                                                   \
             if (fr < F) { e = items[(size_t)fr * max_items + gi]; e.w = fr; }                                                   \
-            gm_geo_store(ent + 4 * lane, e, tiles_x, W0, W1, W2, W3, H0, H1, H2, H3);                                           \
+            gm_geo_store(ent + 4 * lane, ctab + GM_CHUNKS_MAX * lane, e, tiles_x, W0, W1, W2, W3, H0, H1, H2, H3,               \
+                         (unsigned)(o0 * 2), (unsigned)(o1 * 2), (unsigned)(o2 * 2), (unsigned)(o3 * 2));                        \
         }                                                                                                                       \
         __syncthreads();                                                                                                        \
         bool more = true;                                                                                                       \
         if (GM_ABLATE & 16) { if (ent[4 * (GM_ENTS - 1)].z < 0) break; continue; }
     if (loader) { if (GM_ROLE == 2) return;
       for (int base = 0;; base += GM_ENTS) {
-        GM_BATCH_HEAD()
+        GM_BATCH_HEAD(false)
         {
             // =================================================================== loader waves: nothing but loads (and LDS writes)
             // request: thread = (rows i = ltid >> 4 and i + 16 of every block, 16-byte chunk c = ltid & 15); a block's source is a
-            // wave-uniform base (SGPRs) + one of two per-lane offsets.  No mask and no clamp: a slot outside the region holds
+            // wave-uniform base (the batch head's chunk table) + one of two per-lane offsets (per level, below).  No mask and no clamp: a slot outside the region holds
             // whatever lies there in the buffer (a slack behind the mirror keeps the last level's last rows inside it,
             // pips_pyramid_floats) -- a window pixel that falls on such a slot lies outside the map, and the blend tests that
-#define GM_REQUEST(G_, ci_, pre)                                                                                                \
+#define GM_REQUEST(itx_, ci_, pre)                                                                                              \
             {                                                                                                                   \
-                const int l_ = GM_LEVEL_OF(G_, ci_);                                                                            \
-                const int c0_ = ((ci_) - GM_SEL4(l_, 0, G_.cs1, G_.cs2, G_.cs3)) * GM_CHUNK;                                    \
-                const int P_ = GM_SEL4(l_, G_.P0, G_.P1, G_.P2, G_.P3), Q_ = GM_SEL4(l_, G_.Q0, G_.Q1, G_.Q2, G_.Q3);           \
-                const int x0_ = P_ & 0xffff, y0_ = (unsigned)P_ >> 16, nbx_ = (Q_ >> 16) & 0xff, nblk_ = (unsigned)Q_ >> 24;    \
-                const int Wl_ = GM_SEL4(l_, W0, W1, W2, W3), Hl_ = GM_SEL4(l_, H0, H1, H2, H3);                                 \
-                const size_t ol_ = GM_SEL4(l_, o0, o1, o2, o3);                                                                 \
-                const unsigned inv_ = (65536u + (unsigned)nbx_ - 1u) / (unsigned)nbx_;   /* block -> block row: exact for < 256 blocks */ \
-                const char* mp_ = reinterpret_cast<const char*>(mirror + ol_ + (size_t)G_.f * Hl_ * Wl_ * C);                   \
-                const unsigned offA_ = (unsigned)(((ltid >> 7) * Wl_ + ((ltid >> 4) & 7)) * (C * 2) + (ltid & 15) * 16);        \
-                const unsigned offB_ = offA_ + (unsigned)(2 * Wl_ * C * 2);          /* row i + 16: two image rows further down */ \
+                const uint4 d_ = ctab[(itx_) * GM_CHUNKS_MAX + (ci_)];               /* (one address for the wave: a broadcast) */ \
+                const unsigned d0_ = __builtin_amdgcn_readfirstlane(d_.x), d1_ = __builtin_amdgcn_readfirstlane(d_.y),          \
+                               d2_ = __builtin_amdgcn_readfirstlane(d_.z), d3_ = __builtin_amdgcn_readfirstlane(d_.w);          \
+                const int l_ = (int)(d0_ & 3u);                                                                                 \
+                const unsigned offA_ = GM_SEL4(l_, oA0, oA1, oA2, oA3), offB_ = GM_SEL4(l_, oB0, oB1, oB2, oB3);                \
+                const char* mb_ = reinterpret_cast<const char*>(mirror);                                                        \
                 _Pragma("unroll") for (int b_ = 0; b_ < GM_CHUNK; ++b_) {                                                       \
-                    const int gb = min(c0_ + b_, nblk_ - 1);      /* (a chunk's blocks past the level's last repeat it: never used) */ \
-                    const int byi = (int)(((unsigned)gb * inv_) >> 16), bxi = gb - byi * nbx_;                                  \
-                    const char* sb_ = mp_ + (size_t)((unsigned)((y0_ + byi * 4) * Wl_ + x0_ + bxi * 8) * (unsigned)(C * 2));    \
+                    const char* sb_ = mb_ + (b_ == 0 ? (d0_ & ~3u) : (b_ == 1 ? d1_ : (b_ == 2 ? d2_ : d3_)));                  \
                     pre[2 * b_] = (GM_ABLATE & 1) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(sb_ + offA_);  \
                     pre[2 * b_ + 1] = (GM_ABLATE & 1) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(sb_ + offB_); \
                 }                                                                                                               \
@@ -716,36 +736,49 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
             // set being delivered was requested last and waits for vmcnt(0) -- i.e. for the request issued one step ago as well,
             // which makes the pipeline one step deep instead of two.  Past the batch's last chunk the stream repeats a valid chunk
             // (never read)
-            Geo G = geo_of(0), Gn = geo_of(1);
-            int it = 0, s = 0;
+            // per-lane offsets of rows i and i + 16 (two image rows further down) in a block of level l
+            const unsigned oA0 = (unsigned)(((ltid >> 7) * W0 + ((ltid >> 4) & 7)) * (C * 2) + (ltid & 15) * 16), oB0 = oA0 + (unsigned)(2 * W0 * C * 2),
+                           oA1 = (unsigned)(((ltid >> 7) * W1 + ((ltid >> 4) & 7)) * (C * 2) + (ltid & 15) * 16), oB1 = oA1 + (unsigned)(2 * W1 * C * 2),
+                           oA2 = (unsigned)(((ltid >> 7) * W2 + ((ltid >> 4) & 7)) * (C * 2) + (ltid & 15) * 16), oB2 = oA2 + (unsigned)(2 * W2 * C * 2),
+                           oA3 = (unsigned)(((ltid >> 7) * W3 + ((ltid >> 4) & 7)) * (C * 2) + (ltid & 15) * 16), oB3 = oA3 + (unsigned)(2 * W3 * C * 2);
+            // the loaders need an item's frame (< 0: no item) and number of chunks only
+#define GM_ITEM_FN(it_, f_, n_)                                                                                                 \
+            {                                                                                                                   \
+                const int4 a_ = ent[4 * min((it_), GM_ENTS - 1)];                                                               \
+                f_ = (it_) < GM_ENTS ? __builtin_amdgcn_readfirstlane(a_.z) : -1;                                               \
+                n_ = __builtin_amdgcn_readfirstlane(a_.w);                                                                      \
+            }
+            int it = 0, s = 0, f0, nch, fn, nchn;
+            GM_ITEM_FN(0, f0, nch)
+            GM_ITEM_FN(1, fn, nchn)
 #define GM_LSTEP(par_, pre)                                                                                                     \
-            {   /* the products read chunk s of item G: chunk s + 1 of the stream delivered, chunk s + 3 requested */          \
+            {   /* the products read chunk s of item `it`: chunk s + 1 of the stream delivered, chunk s + 3 requested */       \
                 GM_T(20);                                                                                                       \
-                const bool hasnext = Gn.f >= 0, rnext = s + 3 >= G.nchunks;                                                     \
-                const Geo Gr = (rnext && hasnext) ? Gn : G;                                                                     \
-                const int cr = rnext ? (hasnext ? s + 3 - G.nchunks : 0) : s + 3;                                               \
+                const bool hasnext = fn >= 0, rnext = s + 3 >= nch;                                                             \
+                const int itr = (rnext && hasnext) ? it + 1 : it;                                                               \
+                const int cr = rnext ? (hasnext ? s + 3 - nch : 0) : s + 3;                                                     \
                 GM_DELIVER(par_, pre)                                                                                           \
                 GM_T(21);                                                                                                       \
-                GM_REQUEST(Gr, cr, pre)                                                                                         \
+                GM_REQUEST(itr, cr, pre)                                                                                        \
                 GM_T(22);                                                                                                       \
                 if (!done) {     /* (the loop is left at its end only: an exit between the two steps merges their wait states) */ \
                     lds_barrier();                                                                                              \
                     GM_T(23);                                                                                                   \
-                    if (++s == G.nchunks) {                                                                                     \
+                    if (++s == nch) {                                                                                           \
                         if (!hasnext) done = true;                                                                              \
-                        else { G = Gn; ++it; Gn = geo_of(it + 1); s = 0; GM_T(12); }                                            \
+                        else { ++it; nch = nchn; GM_ITEM_FN(it + 1, fn, nchn) s = 0; GM_T(12); }                                \
                     }                                                                                                           \
                 }                                                                                                               \
             }
-            if (G.f < 0) {
+            if (f0 < 0) {
                 lds_barrier();                                           // (A)
                 more = false;
             } else {
                 GM_T(1);
-                GM_REQUEST(G, 0, preA)                                   // the batch's first item: its first chunks, exposed
-                GM_REQUEST(G, 1, preB)
+                GM_REQUEST(0, 0, preA)                                   // the batch's first item: its first chunks, exposed
+                GM_REQUEST(0, 1, preB)
                 GM_DELIVER(0, preA)
-                GM_REQUEST(G, 2, preA)
+                GM_REQUEST(0, 2, preA)
                 lds_barrier();                                           // (A) records, features and chunk 0 of the first item are in LDS
                 bool done = false;
                 do {
@@ -755,6 +788,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                 lds_barrier();                                           // (the product waves' last blend)
                 more = it + 1 >= GM_ENTS;
             }
+#undef GM_ITEM_FN
 #undef GM_LSTEP
         }
         if (!more) break;
@@ -763,7 +797,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
 #undef GM_DELIVER
     } else { if (GM_ROLE == 1) return;
       for (int base = 0;; base += GM_ENTS) {
-        GM_BATCH_HEAD()
+        GM_BATCH_HEAD(wave == 0)
         {
             // =================================================================== product waves: LDS, MFMA, stores -- and the NEXT item's
             // records and features, fetched under this item's steps (three short stages: a wait for them also waits for the tap stores
@@ -873,6 +907,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                         GM_PRO_STORE(Gn, recn)
                         pstage = 3;
                     }
+                    GM_T(45);
                     if (active && !(GM_ABLATE & 2)) {
                         // ---- products of chunk s: this wave's block of the chunk x its particle block, scattered into the windows
                         const int l = GM_LEVEL_OF(G, s);
@@ -889,6 +924,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                             // a lane's 4 x 4 pixels touch its particle's window iff dx0, dy0 in [-3, 7]; particles are binned by 4 x 4
                             // cell, a block of 32 consecutive ones covers part of the tile: a pixel block none of them reaches is skipped
                             const bool hit = (unsigned)(dx0 + 3) < 11u && (unsigned)(dy0 + 3) < 11u;
+                            GM_T(46);
                             if (__builtin_amdgcn_ballot_w64(hit) != 0ull || (GM_NOSKIP)) {
                             f32x16 acc;
 #pragma unroll
@@ -904,17 +940,37 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                             { int d_; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(d_) : "v"(acc[15])); asm volatile("" :: "s"(d_)); }
                             GM_T(41);
 #endif
-                            // branch-free: a value outside its particle's window goes to a per-lane dummy slot instead (16 selects + 16
-                            // unconditional ds_write_b32)
-                            const unsigned wbo = (unsigned)(GM_WIN_OFF + (l & 1) * GM_WIN_BYTES + jme * (GM_WIN_ROW * 4) + dy0 * 32 + dx0 * 4);
-                            const unsigned dmy = (unsigned)(GM_DUMMY_OFF + lane * 4);
-#pragma unroll
-                            for (int y = 0; y < 4; ++y)
-#pragma unroll
-                                for (int x = 0; x < 4; ++x) {
-                                    const bool ok = (unsigned)(dx0 + x) < 8u && (unsigned)(dy0 + y) < 8u;
-                                    *reinterpret_cast<float*>(smem + (ok ? wbo + (unsigned)(y * 32 + x * 4) : dmy)) = acc[y * 4 + x];
-                                }
+                            // the 16 values under execution masks = (x in the window) & (y in the window): four + four ballots, then per
+                            // value one scalar AND into exec and the write -- one assembly statement, so that nothing else runs under a
+                            // partial mask (a compare + select + write per value took twice the instructions)
+                            const unsigned wbo = lds0 + (unsigned)(GM_WIN_OFF + (l & 1) * GM_WIN_BYTES + jme * (GM_WIN_ROW * 4) + dy0 * 32 + dx0 * 4);
+                            const unsigned long long mx0 = __builtin_amdgcn_ballot_w64((unsigned)(dx0 + 0) < 8u), mx1 = __builtin_amdgcn_ballot_w64((unsigned)(dx0 + 1) < 8u),
+                                                     mx2 = __builtin_amdgcn_ballot_w64((unsigned)(dx0 + 2) < 8u), mx3 = __builtin_amdgcn_ballot_w64((unsigned)(dx0 + 3) < 8u),
+                                                     my0 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 0) < 8u), my1 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 1) < 8u),
+                                                     my2 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 2) < 8u), my3 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 3) < 8u);
+                            unsigned long long sv;
+                            asm volatile("s_mov_b64 %0, exec\n\t"
+                                         "s_and_b64 exec, %1, %5\n\tds_write_b32 %9, %10 offset:0\n\t"
+                                         "s_and_b64 exec, %2, %5\n\tds_write_b32 %9, %11 offset:4\n\t"
+                                         "s_and_b64 exec, %3, %5\n\tds_write_b32 %9, %12 offset:8\n\t"
+                                         "s_and_b64 exec, %4, %5\n\tds_write_b32 %9, %13 offset:12\n\t"
+                                         "s_and_b64 exec, %1, %6\n\tds_write_b32 %9, %14 offset:32\n\t"
+                                         "s_and_b64 exec, %2, %6\n\tds_write_b32 %9, %15 offset:36\n\t"
+                                         "s_and_b64 exec, %3, %6\n\tds_write_b32 %9, %16 offset:40\n\t"
+                                         "s_and_b64 exec, %4, %6\n\tds_write_b32 %9, %17 offset:44\n\t"
+                                         "s_and_b64 exec, %1, %7\n\tds_write_b32 %9, %18 offset:64\n\t"
+                                         "s_and_b64 exec, %2, %7\n\tds_write_b32 %9, %19 offset:68\n\t"
+                                         "s_and_b64 exec, %3, %7\n\tds_write_b32 %9, %20 offset:72\n\t"
+                                         "s_and_b64 exec, %4, %7\n\tds_write_b32 %9, %21 offset:76\n\t"
+                                         "s_and_b64 exec, %1, %8\n\tds_write_b32 %9, %22 offset:96\n\t"
+                                         "s_and_b64 exec, %2, %8\n\tds_write_b32 %9, %23 offset:100\n\t"
+                                         "s_and_b64 exec, %3, %8\n\tds_write_b32 %9, %24 offset:104\n\t"
+                                         "s_and_b64 exec, %4, %8\n\tds_write_b32 %9, %25 offset:108\n\t"
+                                         "s_mov_b64 exec, %0"
+                                         : "=&s"(sv)
+                                         : "s"(mx0), "s"(mx1), "s"(mx2), "s"(mx3), "s"(my0), "s"(my1), "s"(my2), "s"(my3), "v"(wbo),
+                                           "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]), "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15])
+                                         : "memory");
                             }
                         }
                     }

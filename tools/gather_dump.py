@@ -9,6 +9,15 @@ if sys.argv[1] == "--compare":
     d = (a - b).abs()
     print(f"max |a - b| = {d.max().item():.3e} over {a.numel()} taps ({int((d > 0).sum())} differ); max |a| = {a.abs().max().item():.3e}; "
           f"finite: {bool(torch.isfinite(a).all())} / {bool(torch.isfinite(b).all())}")
+    bad = (d > 1e-6).reshape(-1, 8, 4, 49).any(-1)          # (row = particle-major (b, n, s); taps = level x 49)
+    print("rows x levels that differ:", int(bad.sum()), "of", bad.numel(), "; by level:", bad.sum((0, 1)).tolist(), "; by frame s:", bad.sum((0, 2)).tolist())
+    idx = bad.any(-1).any(-1).nonzero().flatten()
+    print("first particles (row // 8):", idx[:20].tolist())
+    for r in idx[:3].tolist():
+        for s_ in range(2):
+            for l in range(4):
+                m = (d.reshape(-1, 8, 4, 7, 7)[r, s_, l] > 1e-6).int()       # taps k = ix * 7 + iy
+                print("particle", r, "frame", s_, "level", l, "differing taps [ix][iy]:", m.tolist())
     sys.exit(0)
 import _tunelib  # noqa: F401
 from pips_amd import ops, _lib

@@ -1,0 +1,4 @@
+#!/bin/sh
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
+PIPS_LIB_PATH=$R/build/libpips_trace.so timeout 200 python tools/gm_trace.py 2>&1 | grep -v amdgpu.ids | head -40 > $O/r5c34_trace.txt
+cat $O/r5c34_trace.txt

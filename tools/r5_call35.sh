@@ -1,0 +1,6 @@
+#!/bin/sh
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
+timeout 900 python -m pytest tests -m gpu -x -q -k "mfma or bf16_matrix or batches" 2>&1 | tail -5 | tee $O/r5c35_tests.txt
+timeout 300 python -u tools/gather_c4.py 2>&1 | grep -v amdgpu | grep "bf16 mode\|config-3" | tee $O/r5c35_gather.txt
+PIPS_LIB_PATH=$R/build/libpips_trace.so timeout 200 python tools/gm_trace.py 2>&1 | grep -v amdgpu.ids | head -24 > $O/r5c35_trace.txt
+cat $O/r5c35_trace.txt

@@ -1,0 +1,5 @@
+#!/bin/sh
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
+timeout 300 python tools/gather_dump.py /tmp/x_prod.pt 2>&1 | grep -v amdgpu | tail -1
+PIPS_LIB_PATH=$R/build/libpips_old.so timeout 300 python tools/gather_dump.py /tmp/x_old.pt 2>&1 | grep -v amdgpu | tail -1
+python tools/gather_dump.py --compare /tmp/x_old.pt /tmp/x_prod.pt | tee $O/r5c37_cmp.txt
