@@ -970,7 +970,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                                          : "=&s"(sv)
                                          : "s"(mx0), "s"(mx1), "s"(mx2), "s"(mx3), "s"(my0), "s"(my1), "s"(my2), "s"(my3), "v"(wbo),
                                            "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]), "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15])
-                                         : "memory");
+                                         : "memory", "scc");
                             }
                         }
                     }
