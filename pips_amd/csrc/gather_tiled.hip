@@ -512,28 +512,32 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
 // bandwidth), the tile's region is multiplied against ALL of the item's particles,
 //        D[region pixel][particle] = sum_c map[pixel][c] * feat[particle][c]        (v_mfma_f32_32x32x16_bf16)
 // -- CorrBlock.corr restricted to the tile -- and each particle then keeps the 8 x 8 window it needs.  The products outside the
-// windows are redundant (x 3.5 at level 0 ... x 1.5 at level 3) and still cost less than a tenth of the vector-ALU form.
-//   * ONE persistent block of 16 waves per compute unit, the waves SPECIALISED: 12 product waves and 4 loader waves.  The first cut
-//     (every wave loading, multiplying and storing; two blocks per compute unit for overlap) ran 350 us where its parts, timed
-//     alone, needed 65 (map loads) + 75 (products) + 40 (stores) + 42 (the rest): a wave's vector-memory counter is in order, so
-//     a wait for map loads also waited for the tap stores issued before them, and every step exposed a memory round trip.  Now a
-//     product wave issues no load at all (its stores are never waited for) and a loader wave nothing but loads;
-//   * an item's pixel blocks -- the region of each level cut into blocks of 8 x 4 pixels = the 32 rows of one MFMA -- form ONE
-//     sequence of chunks of four blocks (32 KiB: all 128 channels) over the four levels; in step s the loaders write chunk s + 1
-//     (requested two steps earlier) into stage buffer (s + 1) & 1 and request chunk s + 3,
-//     the product waves work on chunk s out of buffer s & 1; ONE barrier per step.  256-byte rows with the 16-byte chunk index
-//     XORed with (row & 15): fragment reads and staging writes are conflict-free;
-//   * B operand (features): the loaders convert the item's features fp32 -> bf16 (RNE) into LDS once per item; a product wave
-//     = (particle block pb of 32, block-in-chunk) keeps the 8 fragments of ITS lane's particle in registers for the item;
+// windows are redundant (11-33 % of a block's products land in a window) and still cost a fraction of the vector-ALU form.
+//   * ONE persistent block of 16 waves per compute unit, the waves SPECIALISED: 12 product waves and 4 loader waves, each role with
+//     its own loop over the batches of GM_ENTS work items.  The first cut (every wave loading, multiplying and storing; two blocks
+//     per compute unit for overlap) ran 350 us where its parts, timed alone, needed 65 (map loads) + 75 (products) + 40 (stores) +
+//     42 (the rest): a wave's vector-memory counter is in order, so a wait for map loads also waited for the tap stores issued
+//     before them, and every step exposed a memory round trip.  Now a loader wave issues nothing but map loads;
+//   * batch head (wave 0, lane = item): the items' geometry and the loaders' chunk table (gm_geo_store) into LDS;
+//   * a batch's pixel blocks -- the region of each level cut into blocks of 8 x 4 pixels = the 32 rows of one MFMA -- form ONE
+//     stream of chunks of four blocks (32 KiB: all 128 channels) over the items and their four levels; in the step whose products
+//     read chunk q (stage buffer q & 1) the loaders write chunk q + 1 (requested two steps earlier) and request chunk q + 3;
+//     ONE barrier per step.  256-byte rows with the 16-byte chunk index XORed with (row & 15): fragment reads and staging
+//     writes are conflict-free;
+//   * B operand (features) and records: the NEXT item's are fetched by the product waves under the current item's steps (fp32 ->
+//     bf16 RNE into LDS; second record buffer); a product wave = (particle block pb of 32, block-in-chunk) keeps the 8 fragments
+//     of ITS lane's particle in registers for the item, and skips a pixel block that no window of its 32 particles reaches;
 //   * the accumulator layout does the window test almost for free: a lane holds, for ITS particle (column), the 4 x 4 pixels
 //     x = 4 half + (r & 3), y = r >> 2 of the block, so the window coordinate of register r is (dx0 + (r & 3), dy0 + (r >> 2)) with
 //     ONE (dx0, dy0) per lane and block, the target address in the per-level window buffer win[particle][8][8] (+1 float of
 //     padding per particle: the 32 lanes of a write are 32 particles) is one base + immediates, and the validity of a value is
-//     the AND of an x- and a y-compare: 16 masked ds_write_b32 per block;
+//     the AND of an x- and a y-mask: 16 ds_write_b32 under execution masks;
 //   * two window buffers (level parity): the 2 x 2 blend of level l's 8 x 8 correlations to the 49 taps, in the reference's
 //     transposed order (k = ix * 7 + iy, :379-381) with the weights, scaling and operation order of gather_tiled_kernel's
-//     epilogue, runs in the step after the level's last chunk, beside the next level's products.  A window pixel outside the map is
-//     never written: the blend tests its four neighbours against the map (zeros padding, :324) instead of clearing the buffer.
+//     epilogue, by (particle, iy) rows of 7 taps, runs in the step after the level's last chunk (the last level's in the next item's
+//     step 0).  A window pixel outside the map is never written: the blend tests its neighbours against the map (zeros padding,
+//     :324) instead of clearing the buffer.
+// DESIGN.md 4f has the measurements that led here (tools/gm_trace.py).
 constexpr int GM_PWAVES = 12, GM_LWAVES = 4, GM_WAVES = GM_PWAVES + GM_LWAVES, GM_THREADS = GM_WAVES * 64;
 constexpr int GM_PTHREADS = GM_PWAVES * 64, GM_LTHREADS = GM_LWAVES * 64;
 constexpr int GM_PB = GMAX / 32;                  // particle blocks per item
