@@ -518,7 +518,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
 //     per compute unit for overlap) ran 350 us where its parts, timed alone, needed 65 (map loads) + 75 (products) + 40 (stores) +
 //     42 (the rest): a wave's vector-memory counter is in order, so a wait for map loads also waited for the tap stores issued
 //     before them, and every step exposed a memory round trip.  Now a loader wave issues nothing but map loads;
-//   * batch head (wave 0, lane = item): the items' geometry and the loaders' chunk table (gm_geo_store) into LDS;
+//   * batch head (first loader wave, lane = item): the items' geometry and the loaders' chunk table (gm_geo_store) into LDS;
 //   * a batch's pixel blocks -- the region of each level cut into blocks of 8 x 4 pixels = the 32 rows of one MFMA -- form ONE
 //     stream of chunks of four blocks (32 KiB: all 128 channels) over the items and their four levels; in the step whose products
 //     read chunk q (stage buffer q & 1) the loaders write chunk q + 1 (requested two steps earlier) and request chunk q + 3;
@@ -680,7 +680,8 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
     typedef GmGeo Geo;
 #define GM_LEVEL_OF(G_, ci_) (((ci_) >= G_.cs1) + ((ci_) >= G_.cs2) + ((ci_) >= G_.cs3))
     // ---- a batch = this block's next (up to) GM_ENTS work items: item i of the block is entry jb + i J of the XCD's list (frames xcd,
-    //      xcd + 8, ... one after another); lane-parallel look-up by wave 0, the items' geometry and chunk table (gm_geo_store) in LDS.  Each role
+    //      xcd + 8, ... one after another); lane-parallel look-up by the first loader wave (the loaders have the registers: in a product wave
+    //      it costs spills), the items' geometry and chunk table (gm_geo_store) in LDS.  Each role
     //      runs its own loop over the batches (one loop around both roles keeps either role's values alive through the other: spills)
 #define GM_BATCH_HEAD(LOOKUP_)                                                                                                      \
         lds_barrier();                                                                                                          \
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
         if (GM_ABLATE & 16) { if (ent[4 * (GM_ENTS - 1)].z < 0) break; continue; }
     if (loader) { if (GM_ROLE == 2) return;
       for (int base = 0;; base += GM_ENTS) {
-        GM_BATCH_HEAD(false)
+        GM_BATCH_HEAD(wave == GM_PWAVES)
         {
             // =================================================================== loader waves: nothing but loads (and LDS writes)
             // request: thread = (rows i = ltid >> 4 and i + 16 of every block, 16-byte chunk c = ltid & 15); a block's source is a
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
 #undef GM_DELIVER
     } else { if (GM_ROLE == 1) return;
       for (int base = 0;; base += GM_ENTS) {
-        GM_BATCH_HEAD(wave == 0)
+        GM_BATCH_HEAD(false)
         {
             // =================================================================== product waves: LDS, MFMA, stores -- and the NEXT item's
             // records and features, fetched under this item's steps (three short stages: a wait for them also waits for the tap stores
@@ -953,7 +954,9 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                                                      my0 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 0) < 8u), my1 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 1) < 8u),
                                                      my2 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 2) < 8u), my3 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 3) < 8u);
                             unsigned long long sv;
-                            asm volatile("s_mov_b64 %0, exec\n\t"
+                            // (the values come straight out of the last MFMA: an MFMA result read by a DS instruction needs up to 19 wait
+                            //  states, which the compiler inserts for its own instructions but not in front of an assembly statement)
+                            asm volatile("s_nop 15\n\ts_nop 7\n\ts_mov_b64 %0, exec\n\t"
                                          "s_and_b64 exec, %1, %5\n\tds_write_b32 %9, %10 offset:0\n\t"
                                          "s_and_b64 exec, %2, %5\n\tds_write_b32 %9, %11 offset:4\n\t"
                                          "s_and_b64 exec, %3, %5\n\tds_write_b32 %9, %12 offset:8\n\t"
