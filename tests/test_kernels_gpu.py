@@ -868,3 +868,22 @@ def test_gather_mfma_batches():
     X1 = torch.cat(outs, 0)
     assert torch.isfinite(X4).all()
     assert torch.equal(X4, X1)
+
+
+def test_gather_mfma_repeatable():
+    """Two launches of the bf16 matrix-core gather on the same inputs give the same bits (a hardware hazard or a race between the
+    product and loader waves shows up as run-to-run differences long before it moves an error norm: round 5's MFMA -> DS read hazard in
+    the window scatter did)."""
+    from pips_amd import ops, _lib
+    lib = _lib.load()
+    B, H8, W8, N = 2, 90, 160, 4096
+    F, M = B * 8, B * N * 8
+    g = torch.Generator(device=DEV).manual_seed(9)
+    pyr = ops.pyramid_mirror(torch.randn(lib.pips_pyramid_floats(F, H8 * 8, W8 * 8, 8), generator=g, device=DEV), F, H8 * 8, W8 * 8, 8)
+    ff = torch.randn(M, 128, generator=g, device=DEV)
+    co = torch.rand(M, 2, generator=g, device=DEV) * torch.tensor([W8 + 6.0, H8 + 6.0], device=DEV) - 3.0
+    assert lib.pips_gather_route(B, N, H8, W8, 32) == 2
+    X0 = ops.mixer_input_build_tiled(pyr, B, H8, W8, ff, co, bf16_maps=True).clone()
+    for _ in range(3):
+        X1 = ops.mixer_input_build_tiled(pyr, B, H8, W8, ff, co, bf16_maps=True)
+        assert torch.equal(X0, X1)
