@@ -101,7 +101,7 @@ __device__ __forceinline__ void corr_window(float cxm, float cym, int lvl, int H
 __global__ __launch_bounds__(1024) void bin_particles_kernel(const float* __restrict__ coords, int N, TiledLevels lv,
                                                              int tiles_x, int tiles_y, int max_items,
                                                              int4* __restrict__ order, int4* __restrict__ items,
-                                                             int* __restrict__ nitems) {
+                                                             int* __restrict__ nitems, int* __restrict__ slot_of) {
     const int H0 = lv.H[0], W0 = lv.W[0];
     extern __shared__ int sm[];
     const int ntiles = tiles_x * tiles_y, nbins = ntiles * 16;
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(1024) void bin_particles_kernel(const float* __rest
         const int pos = atomicAdd(&cursor[key_of(n)], 1);
         const size_t m = ((size_t)b * N + n) * S + s;
         const float cx = coords[m * 2 + 0], cy = coords[m * 2 + 1];
+        if (slot_of) slot_of[m] = f * N + pos;                      // (bf16 mode: where embed_rows_kernel puts the row's bf16 features)
 #pragma unroll
         for (int l = 0; l < PIPS_LEVELS; ++l) {
             int bx, by; float wx, wy;
@@ -172,7 +173,8 @@ __global__ __launch_bounds__(1024) void bin_particles_kernel(const float* __rest
 __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ ffeats,
                                                          const float* __restrict__ coords,
                                                          const float* __restrict__ times, int M,
-                                                         float* __restrict__ X) {
+                                                         float* __restrict__ X, const int* __restrict__ slot_of,
+                                                         uint4* __restrict__ featb) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= M) return;
     const int s = m % S;
@@ -182,7 +184,13 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
     const float tt = times[s];
     float* xrow = X + (size_t)m * PIPS_KIN_PAD;
     const float* ff = ffeats + (size_t)m * C;
-    if (lane < C / 4) reinterpret_cast<float4*>(xrow)[lane] = reinterpret_cast<const float4*>(ff)[lane];
+    if (lane < C / 4) {
+        const float4 v = reinterpret_cast<const float4*>(ff)[lane];
+        reinterpret_cast<float4*>(xrow)[lane] = v;
+        // bf16 mode: the row's features as bf16 (RNE), in the order of the frame's sorted particle list -- an item's features are
+        // then ONE contiguous run that gather_mfma_kernel's loaders stream like a chunk of the maps
+        if (featb) reinterpret_cast<uint2*>(featb)[(size_t)slot_of[m] * (C / 4) + lane] = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float val = a == 0 ? dx : (a == 1 ? dy : tt);
@@ -552,15 +560,25 @@ constexpr int GM_FEAT_OFF = GM_REC_OFF + 2 * GMAX * PIPS_LEVELS * 16;      // (t
 constexpr int GM_ENTS = 16;                       // work items looked up at a time (a batch; BASELINE configs[3] has 8 per block: tests/test_kernels_gpu.py
                                                   // ::test_gather_mfma_batches covers blocks that walk several batches)
 constexpr int GM_ENT_OFF = GM_FEAT_OFF + GMAX * C * 2;
-constexpr int GM_CHUNKS_MAX = 16;                 // chunks per item (TS = 16: 5 + 4 + 2 + 2 at most)
-constexpr int GM_CT_OFF = GM_ENT_OFF + GM_ENTS * 64;             // per item and chunk: the four blocks' byte offsets in the mirror
-constexpr int GM_LDS = GM_CT_OFF + GM_ENTS * GM_CHUNKS_MAX * 16;
+constexpr int GM_CHUNKS_MAX = 16;                 // stream elements per item: its features / records + its chunks (TS = 16: 5 + 4 + 2 + 2 at most)
+constexpr int GM_CT_OFF = GM_ENT_OFF + GM_ENTS * 64;             // per item and stream element: four 64-bit source addresses (pieces 0, 2, 4, 6)
+constexpr int GM_LDS = GM_CT_OFF + GM_ENTS * GM_CHUNKS_MAX * 32;
 constexpr int GM_TAPS = 49;                       // (2 r + 1)^2 taps per level (PIPS_NCORR = 4 x 49 is a mixer row's whole correlation block)
 constexpr int GM_PIECES = GM_CHUNK * 32 * 16 / GM_LTHREADS;                        // 16-byte pieces per loader thread and chunk (8)
 static_assert(GM_PB * GM_CHUNK == GM_PWAVES && GM_CHUNK * 32 * 16 % GM_LTHREADS == 0, "wave <-> (particle block, block of the chunk)");
 static_assert(GM_ENTS <= 64 && GM_LDS <= 160 * 1024 && GM_WIN_OFF % 16 == 0 && GM_REC_OFF % 16 == 0 && GM_FEAT_OFF % 16 == 0, "LDS layout");
 
+#ifndef GM_ABLATE
+#define GM_ABLATE 0      // debugging builds only (timing, wrong results): 1 no loads in the loaders, 2 no products / scatter, 4 no tap stores,
+                         // 8 no blend, 16 batch heads only, 32 no LDS writes in the loaders
+#endif
 typedef __bf16 bf16x8_gm __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_gm __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 GM_LD16(const char* p) {
+    if (GM_ABLATE & 1) return make_uint4((unsigned)(uintptr_t)p, 0u, 0u, 0u);
+    const u32x4_gm t = *reinterpret_cast<const u32x4_gm*>(p);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
 #ifdef GM_TRACE          // tuning builds (tools/gm_trace.py): time stamps of waves 0 (product) and 12 (loader) of blocks 0 and 1
 __device__ unsigned long long* g_gm_trace;
 constexpr int GM_TRN = 8192;
@@ -576,9 +594,6 @@ constexpr int GM_TRN = 8192;
 #endif
 #ifndef GM_NOSKIP
 #define GM_NOSKIP 0     // 1: no skipping of (pixel block, particle block) pairs without a window (probe)
-#endif
-#ifndef GM_ABLATE
-#define GM_ABLATE 0      // debugging builds only: 1 no map loads, 2 no products / scatter, 4 no stores, 8 no feature loads, 16 items only
 #endif
 
 // the level's staged region: the same rectangle as lane_geom() (window reach of every particle binned into the tile), cut into
@@ -599,8 +614,9 @@ __device__ __forceinline__ void gm_level_geom(int l, int tx, int ty, int Wl, int
 struct GmGeo { int first, count, f, P0, P1, P2, P3, Q0, Q1, Q2, Q3, cs1, cs2, cs3, nchunks; };
 // one lane's entry {tile, first, count, frame} -> the item's geometry, as 4 x int4 (the batch head: lane i works out item i once;
 // worked out per item by every wave instead, the scalar code sat on the loaders' path, tools/gm_trace.py)
-__device__ __forceinline__ void gm_geo_store(int4* geo, uint4* ct, int4 ev, int tiles_x, int W0, int W1, int W2, int W3, int H0, int H1, int H2,
-                                             int H3, unsigned ob0, unsigned ob1, unsigned ob2, unsigned ob3) {
+__device__ __forceinline__ void gm_geo_store(int4* geo, ulonglong4* ct, int4 ev, int N, int tiles_x, int W0, int W1, int W2, int W3, int H0, int H1,
+                                             int H2, int H3, unsigned ob0, unsigned ob1, unsigned ob2, unsigned ob3, unsigned long long mirror_a,
+                                             unsigned long long featb_a, unsigned long long order_a) {
     const int ty = ev.x / tiles_x, tx = ev.x - ty * tiles_x;
     int P0, P1, P2, P3, Q0, Q1, Q2, Q3;
     gm_level_geom(0, tx, ty, W0, H0, P0, Q0);
@@ -610,16 +626,23 @@ __device__ __forceinline__ void gm_geo_store(int4* geo, uint4* ct, int4 ev, int 
     const int cs1 = (((unsigned)Q0 >> 24) + GM_CHUNK - 1) / GM_CHUNK;                 // first chunk of level 1, 2, 3; number of chunks
     const int cs2 = cs1 + (((unsigned)Q1 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
     const int cs3 = cs2 + (((unsigned)Q2 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
-    const int nchunks = min(cs3 + (int)((((unsigned)Q3 >> 24) + GM_CHUNK - 1) / GM_CHUNK), GM_CHUNKS_MAX);
+    const int nchunks = min(cs3 + (int)((((unsigned)Q3 >> 24) + GM_CHUNK - 1) / GM_CHUNK), GM_CHUNKS_MAX - 1);
     geo[0] = make_int4(ev.y, ev.z, ev.w, nchunks);
     geo[1] = make_int4(P0, P1, P2, P3);
     geo[2] = make_int4(Q0, Q1, Q2, Q3);
     geo[3] = make_int4(cs1, cs2, cs3, 0);
-    // the loaders' table: chunk ci -> the byte offsets in the mirror of its four pixel blocks (multiples of 128: the level rides in
-    // the low bits of the first); a chunk's blocks past the level's last repeat it (never used).  Worked out here once per item --
-    // per chunk in the loaders it was 1.4 k clocks of scalar code on their path (tools/gm_trace.py)
+    // the loaders' table, one entry per element of the item's stream: the source ADDRESSES of the thread pieces 0, 2, 4, 6 (the odd
+    // pieces follow from them), the element's kind in the low bits of the first (addresses are multiples of 128): bits 0-1 the level
+    // of a map chunk, bit 2 = the item's run of bf16 feature rows and records.  Element 0 = that run (sorted order: slot f N +
+    // first; pieces 0-5 = 24 KiB of feature rows, pieces 6-7 = 6 KiB of records); element 1 + ci = map chunk ci, piece 2 b = pixel
+    // block b (a chunk's blocks past the level's last repeat it: never used).  Worked out here once per item -- per chunk in the
+    // loaders the address arithmetic was 1.4 k clocks of scalar code on their path (tools/gm_trace.py)
     if (ev.w < 0) return;
-    int ci = 0;
+    {
+        const unsigned long long slot = (unsigned long long)(ev.w * N + ev.y), fa = featb_a + slot * (C * 2);
+        ct[0] = make_ulonglong4(fa | 4ull, fa + 8192ull, fa + 16384ull, order_a + slot * (PIPS_LEVELS * 16));
+    }
+    int ci = 1;
 #pragma unroll
     for (int l = 0; l < PIPS_LEVELS; ++l) {
         const int P = l == 0 ? P0 : (l == 1 ? P1 : (l == 2 ? P2 : P3)), Q = l == 0 ? Q0 : (l == 1 ? Q1 : (l == 2 ? Q2 : Q3));
@@ -633,7 +656,7 @@ __device__ __forceinline__ void gm_geo_store(int4* geo, uint4* ct, int4 ev, int 
                 const int gb = min(c0 + b, nblk - 1), byi = gb / nbx, bxi = gb - byi * nbx;
                 d[b] = ob + (unsigned)((ev.w * Hl + y0 + byi * 4) * Wl + x0 + bxi * 8) * (unsigned)(C * 2);
             }
-            ct[ci] = make_uint4(d[0] | (unsigned)l, d[1], d[2], d[3]);
+            ct[ci] = make_ulonglong4((mirror_a + d[0]) | (unsigned long long)l, mirror_a + d[1], mirror_a + d[2], mirror_a + d[3]);
         }
     }
 }
@@ -652,7 +675,7 @@ __device__ __forceinline__ GmGeo gm_geo(const int4* geo, int it) {
 }
 
 __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned short* __restrict__ mirror, TiledLevels lv,
-                                                                const float* __restrict__ ffeats, int N, int max_items, int F,
+                                                                const uint4* __restrict__ featb, int N, int max_items, int F,
                                                                 const int4* __restrict__ order, const int4* __restrict__ items,
                                                                 const int* __restrict__ nitems, int tiles_x,
                                                                 float* __restrict__ X) {
@@ -665,7 +688,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
     const int xcd = blockIdx.x & 7, J = gridDim.x >> 3, jb = blockIdx.x >> 3;
     int4* rec = reinterpret_cast<int4*>(smem + GM_REC_OFF);
     int4* ent = reinterpret_cast<int4*>(smem + GM_ENT_OFF);
-    uint4* ctab = reinterpret_cast<uint4*>(smem + GM_CT_OFF);
+    ulonglong4* ctab = reinterpret_cast<ulonglong4*>(smem + GM_CT_OFF);
     const int jme = pb * 32 + l31;                                   // a product lane's particle (MFMA column) within the item
     const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);      // (for ds_write in assembly)
     // the levels' map sizes and offsets as scalars (static indices: a dynamically indexed kernel-argument array goes to scratch)
@@ -694,8 +717,10 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                 gi -= n;                                                                                                        \
             }                                                                                                                   \
             if (fr < F) { e = items[(size_t)fr * max_items + gi]; e.w = fr; }                                                   \
-            gm_geo_store(ent + 4 * lane, ctab + GM_CHUNKS_MAX * lane, e, tiles_x, W0, W1, W2, W3, H0, H1, H2, H3,               \
-                         (unsigned)(o0 * 2), (unsigned)(o1 * 2), (unsigned)(o2 * 2), (unsigned)(o3 * 2));                        \
+            gm_geo_store(ent + 4 * lane, ctab + GM_CHUNKS_MAX * lane, e, N, tiles_x, W0, W1, W2, W3, H0, H1, H2, H3,               \
+                         (unsigned)(o0 * 2), (unsigned)(o1 * 2), (unsigned)(o2 * 2), (unsigned)(o3 * 2),                         \
+                         (unsigned long long)reinterpret_cast<uintptr_t>(mirror), (unsigned long long)reinterpret_cast<uintptr_t>(featb), \
+                         (unsigned long long)reinterpret_cast<uintptr_t>(order));                                                \
         }                                                                                                                       \
         __syncthreads();                                                                                                        \
         bool more = true;                                                                                                       \
@@ -705,42 +730,56 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
         GM_BATCH_HEAD(wave == GM_PWAVES)
         {
             // =================================================================== loader waves: nothing but loads (and LDS writes)
-            // request: thread = (rows i = ltid >> 4 and i + 16 of every block, 16-byte chunk c = ltid & 15); a block's source is a
-            // wave-uniform base (the batch head's chunk table) + one of two per-lane offsets (per level, below).  No mask and no clamp: a slot outside the region holds
-            // whatever lies there in the buffer (a slack behind the mirror keeps the last level's last rows inside it,
-            // pips_pyramid_floats) -- a window pixel that falls on such a slot lies outside the map, and the blend tests that
-#define GM_REQUEST(itx_, ci_, pre)                                                                                              \
+            // A batch's items form ONE stream of elements: per item its run of bf16 feature rows and records (24 + 6 KiB, contiguous in
+            // the sorted order embed_rows_kernel / bin_particles_kernel wrote them in), then its map chunks (4 pixel blocks = 32 KiB
+            // each).  Element q goes global -> register set q & 1 -> LDS (the feature / record buffers, or stage buffer q & 1): in
+            // the step that consumes element q, element q + 1 is delivered and element q + 3 requested -- across item boundaries
+            // (an item has >= 5 elements).  A thread moves 8 pieces of 16 bytes per element: source = wave-uniform base (the batch
+            // head's table) + a per-lane offset; map rows i = ltid >> 4 and i + 16 of every block, 16-byte chunk c = ltid & 15.
+            // No mask and no clamp: a slot outside the region holds whatever lies there in the buffer (a slack behind the mirror
+            // keeps the last level's last rows inside it, pips_pyramid_floats) -- a window pixel that falls on such a slot lies
+            // outside the map, and the blend tests that; feature rows / records past the item's particles are never used either.
+            // Requests and deliveries are UNCONDITIONAL (addresses are selected, not instructions) and the two register sets
+            // alternate in straight-line code (two steps per loop iteration): behind a conditional request, or a run-time choice of
+            // the set, the compiler's wait-count pass must assume the set being delivered was requested last and waits for
+            // vmcnt(0) -- i.e. for the request issued one step ago as well, which makes the pipeline one step deep instead of two.
+            // Past the batch's last element the stream repeats a valid chunk (never read).
+            const unsigned offF = (unsigned)ltid * 16u, offF7 = (unsigned)min(ltid, GMAX * PIPS_LEVELS - 257) * 16u;   // (records: 6 KiB = pieces 6 and 7's first half)
+#define GM_REQUEST(itx_, e_, pre) { const ulonglong4 d_ = ctab[(itx_) * GM_CHUNKS_MAX + (e_)]; GM_REQUEST_D(d_, pre) }
+            // (d_: the element's table entry -- one address for the wave, a broadcast; the step loop reads it ahead of its delivery, so that
+            //  the read does not queue behind the delivery's eight LDS writes)
+#define GM_RFL64(x_) (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((x_) >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(x_)))
+#define GM_REQUEST_D(d_, pre)                                                                                                   \
             {                                                                                                                   \
-                const uint4 d_ = ctab[(itx_) * GM_CHUNKS_MAX + (ci_)];               /* (one address for the wave: a broadcast) */ \
-                const unsigned d0_ = __builtin_amdgcn_readfirstlane(d_.x), d1_ = __builtin_amdgcn_readfirstlane(d_.y),          \
-                               d2_ = __builtin_amdgcn_readfirstlane(d_.z), d3_ = __builtin_amdgcn_readfirstlane(d_.w);          \
-                const int l_ = (int)(d0_ & 3u);                                                                                 \
+                const unsigned long long a0_ = GM_RFL64(d_.x), a2_ = GM_RFL64(d_.y), a4_ = GM_RFL64(d_.z), a6_ = GM_RFL64(d_.w); \
+                const bool isf_ = (a0_ & 4ull) != 0;                                                                            \
+                const int l_ = (int)(a0_ & 3ull);                                                                               \
                 const unsigned offA_ = GM_SEL4(l_, oA0, oA1, oA2, oA3), offB_ = GM_SEL4(l_, oB0, oB1, oB2, oB3);                \
-                const char* mb_ = reinterpret_cast<const char*>(mirror);                                                        \
-                _Pragma("unroll") for (int b_ = 0; b_ < GM_CHUNK; ++b_) {                                                       \
-                    const char* sb_ = mb_ + (b_ == 0 ? (d0_ & ~3u) : (b_ == 1 ? d1_ : (b_ == 2 ? d2_ : d3_)));                  \
-                    pre[2 * b_] = (GM_ABLATE & 1) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(sb_ + offA_);  \
-                    pre[2 * b_ + 1] = (GM_ABLATE & 1) ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(sb_ + offB_); \
-                }                                                                                                               \
+                const unsigned ve_ = isf_ ? offF : offA_, vo_ = isf_ ? offF : offB_, v7_ = isf_ ? offF7 : offB_;                \
+                const unsigned long long odd_ = isf_ ? 4096ull : 0ull;               /* (a run's odd pieces: the next 4 KiB; a block's: its rows i + 16) */ \
+                const char* s0_ = reinterpret_cast<const char*>(a0_ & ~7ull); const char* s2_ = reinterpret_cast<const char*>(a2_); \
+                const char* s4_ = reinterpret_cast<const char*>(a4_);         const char* s6_ = reinterpret_cast<const char*>(a6_); \
+                /* (loaded as a native vector and re-packed: a struct copy from the selected pointers keeps `pre` in scratch memory) */ \
+                pre[0] = GM_LD16(s0_ + ve_); pre[1] = GM_LD16(s0_ + odd_ + vo_); pre[2] = GM_LD16(s2_ + ve_); pre[3] = GM_LD16(s2_ + odd_ + vo_); \
+                pre[4] = GM_LD16(s4_ + ve_); pre[5] = GM_LD16(s4_ + odd_ + vo_); pre[6] = GM_LD16(s6_ + ve_); pre[7] = GM_LD16(s6_ + odd_ + v7_); \
             }
-#define GM_DELIVER(ci_, pre)                                                                                                    \
+            // set `pre` -> LDS: a map chunk into stage buffer par_ (piece p = 2 block + row half at p * 4 KiB + this thread's swizzled
+            // slot), a feature / record element into the feature buffer (pieces 0-5: rows 16 p + (ltid >> 4), the same slot
+            // formula) and the record buffer rb_ of its item (pieces 6, 7: plain)
+#define GM_DELIVER(par_, pre, isf_, rb_)                                                                                        \
             {                                                                                                                   \
-                char* st_ = smem + ((ci_) & 1) * GM_STAGE + ldsA;                                                               \
-                _Pragma("unroll") for (int b_ = 0; b_ < GM_CHUNK; ++b_) {                                                       \
-                    *reinterpret_cast<uint4*>(st_ + b_ * GM_BLK_BYTES) = pre[2 * b_];                                           \
-                    *reinterpret_cast<uint4*>(st_ + b_ * GM_BLK_BYTES + 16 * 256) = pre[2 * b_ + 1];                            \
-                }                                                                                                               \
+                if (GM_ABLATE & 32) { asm volatile("" :: "v"(pre[0].x), "v"(pre[1].x), "v"(pre[2].x), "v"(pre[3].x), "v"(pre[4].x), "v"(pre[5].x), "v"(pre[6].x), "v"(pre[7].x)); } else { \
+                char* t05_ = smem + ((isf_) ? GM_FEAT_OFF : (par_) * GM_STAGE) + ldsA;                                          \
+                char* t6_ = (isf_) ? smem + GM_REC_OFF + (rb_) * (GMAX * PIPS_LEVELS * 16) + offF : t05_ + 6 * 4096;            \
+                char* t7_ = (isf_) ? smem + GM_REC_OFF + (rb_) * (GMAX * PIPS_LEVELS * 16) + 4096 + offF7 : t05_ + 7 * 4096;    \
+                *reinterpret_cast<uint4*>(t05_) = pre[0];             *reinterpret_cast<uint4*>(t05_ + 4096) = pre[1];          \
+                *reinterpret_cast<uint4*>(t05_ + 2 * 4096) = pre[2];  *reinterpret_cast<uint4*>(t05_ + 3 * 4096) = pre[3];      \
+                *reinterpret_cast<uint4*>(t05_ + 4 * 4096) = pre[4];  *reinterpret_cast<uint4*>(t05_ + 5 * 4096) = pre[5];      \
+                *reinterpret_cast<uint4*>(t6_) = pre[6];                                                                        \
+                *reinterpret_cast<uint4*>(t7_) = pre[7]; }                                                                      \
             }
             const int ldsA = (ltid >> 4) * 256 + (((ltid & 15) ^ ((ltid >> 4) & 15)) << 4);      // row i (and i + 16: same swizzle), chunk c
-            uint4 preA[GM_PIECES], preB[GM_PIECES];      // even / odd chunks: two requests in flight (a third set of 32 registers spills)
-            // The chunks of a batch's items form ONE stream q = 0, 1, 2 ...: chunk q goes through register set q & 1 into stage
-            // buffer q & 1; in the step whose products read chunk q, chunk q + 1 is delivered and chunk q + 3 requested -- across
-            // item boundaries (every item has >= 4 chunks, one per level at least: three chunks ahead is this item or the next)
-            // Requests and deliveries are UNCONDITIONAL and the two register sets alternate in straight-line code (two steps per loop
-            // iteration): behind a conditional request, or a run-time choice of the set, the compiler's wait-count pass must assume the
-            // set being delivered was requested last and waits for vmcnt(0) -- i.e. for the request issued one step ago as well,
-            // which makes the pipeline one step deep instead of two.  Past the batch's last chunk the stream repeats a valid chunk
-            // (never read)
+            uint4 preA[GM_PIECES], preB[GM_PIECES];      // even / odd elements: two requests in flight (a third set: same time, measured)
             // per-lane offsets of rows i and i + 16 (two image rows further down) in a block of level l
             const unsigned oA0 = (unsigned)(((ltid >> 7) * W0 + ((ltid >> 4) & 7)) * (C * 2) + (ltid & 15) * 16), oB0 = oA0 + (unsigned)(2 * W0 * C * 2),
                            oA1 = (unsigned)(((ltid >> 7) * W1 + ((ltid >> 4) & 7)) * (C * 2) + (ltid & 15) * 16), oB1 = oA1 + (unsigned)(2 * W1 * C * 2),
@@ -756,20 +795,26 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
             int it = 0, s = 0, f0, nch, fn, nchn;
             GM_ITEM_FN(0, f0, nch)
             GM_ITEM_FN(1, fn, nchn)
-#define GM_LSTEP(par_, pre)                                                                                                     \
-            {   /* the products read chunk s of item `it`: chunk s + 1 of the stream delivered, chunk s + 3 requested */       \
+            bool kA = false, kB = false;                  // what set A / B holds: a feature / record element?  for which record buffer?
+            int rA = 0, rB = 0;
+#define GM_LSTEP(par_, pre, k_, r_)                                                                                             \
+            {   /* the step consumes element s of item `it` (0: its features, the previous item's last blend; 1 + c: chunk c):    \
+                   element s + 1 of the stream delivered, element s + 3 requested */                                            \
                 GM_T(20);                                                                                                       \
-                const bool hasnext = fn >= 0, rnext = s + 3 >= nch;                                                             \
+                const int nel = nch + 1;                                                                                        \
+                const bool hasnext = fn >= 0, rnext = s + 3 >= nel;                                                             \
                 const int itr = (rnext && hasnext) ? it + 1 : it;                                                               \
-                const int cr = rnext ? (hasnext ? s + 3 - nch : 0) : s + 3;                                                     \
-                GM_DELIVER(par_, pre)                                                                                           \
+                const int er = rnext ? (hasnext ? s + 3 - nel : 1) : s + 3;                                                     \
+                const ulonglong4 dn_ = ctab[itr * GM_CHUNKS_MAX + er];                                                          \
+                GM_DELIVER(par_, pre, k_, r_)                                                                                   \
                 GM_T(21);                                                                                                       \
-                GM_REQUEST(itr, cr, pre)                                                                                        \
+                GM_REQUEST_D(dn_, pre)                                                                                          \
+                k_ = er == 0; r_ = itr & 1;                                                                                     \
                 GM_T(22);                                                                                                       \
                 if (!done) {     /* (the loop is left at its end only: an exit between the two steps merges their wait states) */ \
                     lds_barrier();                                                                                              \
                     GM_T(23);                                                                                                   \
-                    if (++s == nch) {                                                                                           \
+                    if (++s == nel) {                                                                                           \
                         if (!hasnext) done = true;                                                                              \
                         else { ++it; nch = nchn; GM_ITEM_FN(it + 1, fn, nchn) s = 0; GM_T(12); }                                \
                     }                                                                                                           \
@@ -780,15 +825,15 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                 more = false;
             } else {
                 GM_T(1);
-                GM_REQUEST(0, 0, preA)                                   // the batch's first item: its first chunks, exposed
+                GM_REQUEST(0, 0, preA)                                   // the batch's first item: its features / records and first chunks, exposed
                 GM_REQUEST(0, 1, preB)
-                GM_DELIVER(0, preA)
+                GM_DELIVER(0, preA, true, 0)
                 GM_REQUEST(0, 2, preA)
-                lds_barrier();                                           // (A) records, features and chunk 0 of the first item are in LDS
+                lds_barrier();                                           // (A) the first item's features and records are in LDS
                 bool done = false;
                 do {
-                    GM_LSTEP(1, preB)
-                    GM_LSTEP(0, preA)
+                    GM_LSTEP(1, preB, kB, rB)
+                    GM_LSTEP(0, preA, kA, rA)
                 } while (!done);
                 lds_barrier();                                           // (the product waves' last blend)
                 more = it + 1 >= GM_ENTS;
@@ -799,50 +844,25 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
         if (!more) break;
       }
 #undef GM_REQUEST
+#undef GM_REQUEST_D
+#undef GM_RFL64
 #undef GM_DELIVER
     } else { if (GM_ROLE == 1) return;
       for (int base = 0;; base += GM_ENTS) {
         GM_BATCH_HEAD(false)
         {
-            // =================================================================== product waves: LDS, MFMA, stores -- and the NEXT item's
-            // records and features, fetched under this item's steps (three short stages: a wait for them also waits for the tap stores
-            // issued before, which by then are steps old).  Records: thread t < 384 holds (particle j, level l) = 4 j + l; slots past the
-            // item's particles get a far-away anchor.  Features: thread t -> particle j = t >> 3, channels 16 (t & 7) .. + 15; fp32 -> bf16
-            // RNE into LDS rows of 256 bytes, 16-byte chunk index XORed with row & 15 (the fragment reads are conflict-free)
-#define GM_PRO_LOAD1(G_)                                                                                                        \
-            {   /* (32-bit byte offsets from scalar bases: the launcher checks that records and features stay below 4 GiB) */  \
-                const char* ob_ = reinterpret_cast<const char*>(order + ((size_t)G_.f * N + G_.first) * PIPS_LEVELS);            \
-                prr = *reinterpret_cast<const int4*>(ob_ + (unsigned)min(min(tid, GMAX * PIPS_LEVELS - 1), G_.count * PIPS_LEVELS - 1) * 16u); \
-                prm = *reinterpret_cast<const int*>(ob_ + (unsigned)min(tid >> 3, G_.count - 1) * (unsigned)(PIPS_LEVELS * 16) + 12u); \
-            }
-#define GM_PRO_LOAD2()                                                                                                          \
-            {                                                                                                                   \
-                const char* fp_ = reinterpret_cast<const char*>(ffeats) + ((unsigned)prm * (unsigned)(C * 4) + (unsigned)((tid & 7) * 64)); \
-                _Pragma("unroll") for (int k = 0; k < 4; ++k) prf[k] = *reinterpret_cast<const float4*>(fp_ + 16 * k);          \
-            }
-#define GM_PRO_STORE(G_, recp_)                                                                                                 \
-            {                                                                                                                   \
-                const int j_ = tid >> 3, c_ = (tid & 7) * 2;                                                                    \
-                const unsigned keep_ = (j_ < G_.count && !(GM_ABLATE & 8)) ? 0xffffffffu : 0u;                                  \
-                char* fr_ = smem + GM_FEAT_OFF + j_ * 256;                                                                      \
-                *reinterpret_cast<uint4*>(fr_ + ((c_ ^ (j_ & 15)) << 4)) =                                                      \
-                    make_uint4(pack2_bf16(prf[0].x, prf[0].y) & keep_, pack2_bf16(prf[0].z, prf[0].w) & keep_,                  \
-                               pack2_bf16(prf[1].x, prf[1].y) & keep_, pack2_bf16(prf[1].z, prf[1].w) & keep_);                 \
-                *reinterpret_cast<uint4*>(fr_ + (((c_ + 1) ^ (j_ & 15)) << 4)) =                                                \
-                    make_uint4(pack2_bf16(prf[2].x, prf[2].y) & keep_, pack2_bf16(prf[2].z, prf[2].w) & keep_,                  \
-                               pack2_bf16(prf[3].x, prf[3].y) & keep_, pack2_bf16(prf[3].z, prf[3].w) & keep_);                 \
-                if ((tid >> 2) >= G_.count) prr = make_int4((int)(20000u | (20000u << 16)), 0, 0, -1);                          \
-                if (tid < GMAX * PIPS_LEVELS) (recp_)[tid] = prr;                                                               \
-            }
+            // =================================================================== product waves: LDS, MFMA, tap stores -- no load at all
+            // (an item's features and records come in through the loaders' stream: the step that consumes that element is the item's
+            // first, and hosts the PREVIOUS item's last blend)
             // the step after a level's last chunk: 2x2 blend of its 8x8 correlations to the 49 taps, k = ix*7 + iy (transposed, :379-381);
-            // neighbours outside the map count as zero (:324).  The last level's blend runs in the NEXT item's step 0 (its records are in
-            // the other record buffer, its windows in the buffer level 0 does not use)
+            // neighbours outside the map count as zero (:324).  The last level's blend runs in the NEXT item's first step (its records are
+            // in the other record buffer, its windows in the buffer level 0 does not use)
 #define GM_BLEND(l_, recb_, cnt_)                                                                                               \
             {   /* a thread = one (particle, iy) row of 7 taps: the two window rows it needs are read once (16 values instead of  \
                    4 per tap), the in-map tests are per column / row, the weights per thread; 7 stores of 7-float runs per particle */ \
                 const int Wl = GM_SEL4(l_, W0, W1, W2, W3), Hl = GM_SEL4(l_, H0, H1, H2, H3);                                   \
                 const float* winf = reinterpret_cast<const float*>(smem + GM_WIN_OFF + ((l_) & 1) * GM_WIN_BYTES);              \
-                for (int idx = tid; idx < (cnt_) * 7; idx += GM_PTHREADS) {                                                     \
+                for (int idx = tid; idx < ((GM_ABLATE & 8) ? 0 : (cnt_) * 7); idx += GM_PTHREADS) {                            \
                     const int j = idx / 7, tj = idx - j * 7;                                                                    \
                     const int4 r = (recb_)[j * PIPS_LEVELS + (l_)];                                                             \
                     const float* wv = winf + j * GM_WIN_ROW + tj * 8;                                                           \
@@ -868,49 +888,69 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                     }                                                                                                           \
                 }                                                                                                               \
             }
-            int4 prr = make_int4(0, 0, 0, 0);
-            int prm = 0;
-            float4 prf[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) prf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            {
-                const Geo G0 = geo_of(0);
-                if (G0.f >= 0) {                         // the batch's first item: exposed
-                    GM_PRO_LOAD1(G0)
-                    GM_PRO_LOAD2()
-                    GM_PRO_STORE(G0, rec)
-                }
+            // the window scatter of one (pixel block, particle block) product: the 16 values under execution masks = (x in the window) & (y in
+            // the window): four + four ballots, then per value one scalar AND into exec and the write -- one assembly statement, so that
+            // nothing else runs under a partial mask (a compare + select + write per value took twice the instructions).  The values
+            // may come straight out of the last MFMA: an MFMA result read by a DS instruction needs up to 19 wait states, which the
+            // compiler inserts for its own instructions but not in front of an assembly statement
+#define GM_SCATTER(acc, l_, dx0, dy0)                                                                                           \
+            {                                                                                                                   \
+                const unsigned wbo = lds0 + (unsigned)(GM_WIN_OFF + ((l_) & 1) * GM_WIN_BYTES + jme * (GM_WIN_ROW * 4) + (dy0) * 32 + (dx0) * 4); \
+                const unsigned long long mx0 = __builtin_amdgcn_ballot_w64((unsigned)((dx0) + 0) < 8u), mx1 = __builtin_amdgcn_ballot_w64((unsigned)((dx0) + 1) < 8u), \
+                                         mx2 = __builtin_amdgcn_ballot_w64((unsigned)((dx0) + 2) < 8u), mx3 = __builtin_amdgcn_ballot_w64((unsigned)((dx0) + 3) < 8u), \
+                                         my0 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 0) < 8u), my1 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 1) < 8u), \
+                                         my2 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 2) < 8u), my3 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 3) < 8u); \
+                unsigned long long sv;                                                                                          \
+                asm volatile("s_nop 15\n\ts_nop 7\n\ts_mov_b64 %0, exec\n\t"                                                    \
+                "s_and_b64 exec, %1, %5\n\tds_write_b32 %9, %10 offset:0\n\t"                                                   \
+                "s_and_b64 exec, %2, %5\n\tds_write_b32 %9, %11 offset:4\n\t"                                                   \
+                "s_and_b64 exec, %3, %5\n\tds_write_b32 %9, %12 offset:8\n\t"                                                   \
+                "s_and_b64 exec, %4, %5\n\tds_write_b32 %9, %13 offset:12\n\t"                                                  \
+                "s_and_b64 exec, %1, %6\n\tds_write_b32 %9, %14 offset:32\n\t"                                                  \
+                "s_and_b64 exec, %2, %6\n\tds_write_b32 %9, %15 offset:36\n\t"                                                  \
+                "s_and_b64 exec, %3, %6\n\tds_write_b32 %9, %16 offset:40\n\t"                                                  \
+                "s_and_b64 exec, %4, %6\n\tds_write_b32 %9, %17 offset:44\n\t"                                                  \
+                "s_and_b64 exec, %1, %7\n\tds_write_b32 %9, %18 offset:64\n\t"                                                  \
+                "s_and_b64 exec, %2, %7\n\tds_write_b32 %9, %19 offset:68\n\t"                                                  \
+                "s_and_b64 exec, %3, %7\n\tds_write_b32 %9, %20 offset:72\n\t"                                                  \
+                "s_and_b64 exec, %4, %7\n\tds_write_b32 %9, %21 offset:76\n\t"                                                  \
+                "s_and_b64 exec, %1, %8\n\tds_write_b32 %9, %22 offset:96\n\t"                                                  \
+                "s_and_b64 exec, %2, %8\n\tds_write_b32 %9, %23 offset:100\n\t"                                                 \
+                "s_and_b64 exec, %3, %8\n\tds_write_b32 %9, %24 offset:104\n\t"                                                 \
+                "s_and_b64 exec, %4, %8\n\tds_write_b32 %9, %25 offset:108\n\t"                                                 \
+                "s_mov_b64 exec, %0"                                                                                            \
+                : "=&s"(sv)                                                                                                     \
+                : "s"(mx0), "s"(mx1), "s"(mx2), "s"(mx3), "s"(my0), "s"(my1), "s"(my2), "s"(my3), "v"(wbo),                     \
+                "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]), "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15])\
+                : "memory", "scc");                                                                                             \
             }
             GM_T(1);
             lds_barrier();                                               // (A)
-            int g = 0, countp = 0;                                       // stream index of the item's chunk 0; the previous item's particles
+            int g = 0, countp = 0;                                       // stream index of the item's element 0; the previous item's particles
             for (int it = 0; it < GM_ENTS; ++it) {
                 const Geo G = geo_of(it);
                 if (G.f < 0) { more = false; break; }
-                const Geo Gn = geo_of(it + 1);
-                const bool hasnext = Gn.f >= 0;
-                int pstage = hasnext ? 0 : 3;            // next item's records / features: 0 nothing, 1 records + row index requested, 2 rows requested, 3 in LDS
+                const bool hasnext = geo_of(it + 1).f >= 0;
                 const int count = G.count, nchunks = G.nchunks, cs1 = G.cs1, cs2 = G.cs2, cs3 = G.cs3;
                 const int4* recp = rec + (it & 1) * (GMAX * PIPS_LEVELS);
-                int4* recn = rec + ((it + 1) & 1) * (GMAX * PIPS_LEVELS);        // the next item's = the previous item's buffer
+                const int4* recq = rec + ((it + 1) & 1) * (GMAX * PIPS_LEVELS);  // the previous item's records
                 GM_T(30);
                 uint4 bfr[8];                                            // B operand: this lane's particle, channels 16 ks + 8 half ... + 8
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
                     bfr[ks] = *reinterpret_cast<const uint4*>(smem + GM_FEAT_OFF + jme * 256 + (((ks * 2 + half) ^ (jme & 15)) << 4));
+                // ---- the item's first step (its features / records element): the previous item's last level
+                if (it > 0) { GM_BLEND(3, recq, countp) GM_T(43); }
+                lds_barrier();
+                GM_T(44);
                 const bool active = pb * 32 < count;                     // (wave-uniform) this wave's particle block holds particles
                 for (int s = 0; s < nchunks; ++s) {
                     GM_T(40);
-                    // the next item's prologue (the feature buffer is free behind step 0's barrier, the other record buffer behind the
-                    // previous item's last blend in step 0)
-                    if (pstage == 0 && s >= 1) { GM_PRO_LOAD1(Gn) pstage = 1; }
-                    else if (pstage == 1 && s >= 3) { GM_PRO_LOAD2() pstage = 2; }
-                    else if (pstage == 2 && s >= 5) { GM_PRO_STORE(Gn, recn) pstage = 3; }
-                    if (s == nchunks - 1 && pstage < 3) {                // (an item of fewer than six chunks: the rest, exposed)
-                        if (pstage < 1) GM_PRO_LOAD1(Gn)
-                        if (pstage < 2) GM_PRO_LOAD2()
-                        GM_PRO_STORE(Gn, recn)
-                        pstage = 3;
+                    // the blend of the level that ended with the previous step, AHEAD of this step's products (behind them it cost 7 %: measured)
+                    if (s == cs1 || s == cs2 || s == cs3) {
+                        const int l = GM_LEVEL_OF(G, s - 1);
+                        GM_BLEND(l, recp, count)
+                        GM_T(43);
                     }
                     GM_T(45);
                     if (active && !(GM_ABLATE & 2)) {
@@ -928,13 +968,13 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                             const int dx0 = bxi * 8 + 4 * half - bxr, dy0 = byi * 4 - byr;
                             // a lane's 4 x 4 pixels touch its particle's window iff dx0, dy0 in [-3, 7]; particles are binned by 4 x 4
                             // cell, a block of 32 consecutive ones covers part of the tile: a pixel block none of them reaches is skipped
-                            const bool hit = (unsigned)(dx0 + 3) < 11u && (unsigned)(dy0 + 3) < 11u;
+                            const bool hit = (unsigned)(dx0 + 3) < 11u && (unsigned)(dy0 + 3) < 11u && jme < count;       // (slots past the item's particles hold the records behind it)
                             GM_T(46);
                             if (__builtin_amdgcn_ballot_w64(hit) != 0ull || (GM_NOSKIP)) {
                             f32x16 acc;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                            const char* ap = smem + ((g + s) & 1) * GM_STAGE + bl * GM_BLK_BYTES + l31 * 256;
+                            const char* ap = smem + ((g + s + 1) & 1) * GM_STAGE + bl * GM_BLK_BYTES + l31 * 256;
 #pragma unroll
                             for (int ks = 0; ks < 8; ++ks) {
                                 const uint4 a = *reinterpret_cast<const uint4*>(ap + (((ks * 2 + half) ^ (l31 & 15)) << 4));
@@ -945,50 +985,11 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                             { int d_; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(d_) : "v"(acc[15])); asm volatile("" :: "s"(d_)); }
                             GM_T(41);
 #endif
-                            // the 16 values under execution masks = (x in the window) & (y in the window): four + four ballots, then per
-                            // value one scalar AND into exec and the write -- one assembly statement, so that nothing else runs under a
-                            // partial mask (a compare + select + write per value took twice the instructions)
-                            const unsigned wbo = lds0 + (unsigned)(GM_WIN_OFF + (l & 1) * GM_WIN_BYTES + jme * (GM_WIN_ROW * 4) + dy0 * 32 + dx0 * 4);
-                            const unsigned long long mx0 = __builtin_amdgcn_ballot_w64((unsigned)(dx0 + 0) < 8u), mx1 = __builtin_amdgcn_ballot_w64((unsigned)(dx0 + 1) < 8u),
-                                                     mx2 = __builtin_amdgcn_ballot_w64((unsigned)(dx0 + 2) < 8u), mx3 = __builtin_amdgcn_ballot_w64((unsigned)(dx0 + 3) < 8u),
-                                                     my0 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 0) < 8u), my1 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 1) < 8u),
-                                                     my2 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 2) < 8u), my3 = __builtin_amdgcn_ballot_w64((unsigned)(dy0 + 3) < 8u);
-                            unsigned long long sv;
-                            // (the values come straight out of the last MFMA: an MFMA result read by a DS instruction needs up to 19 wait
-                            //  states, which the compiler inserts for its own instructions but not in front of an assembly statement)
-                            asm volatile("s_nop 15\n\ts_nop 7\n\ts_mov_b64 %0, exec\n\t"
-                                         "s_and_b64 exec, %1, %5\n\tds_write_b32 %9, %10 offset:0\n\t"
-                                         "s_and_b64 exec, %2, %5\n\tds_write_b32 %9, %11 offset:4\n\t"
-                                         "s_and_b64 exec, %3, %5\n\tds_write_b32 %9, %12 offset:8\n\t"
-                                         "s_and_b64 exec, %4, %5\n\tds_write_b32 %9, %13 offset:12\n\t"
-                                         "s_and_b64 exec, %1, %6\n\tds_write_b32 %9, %14 offset:32\n\t"
-                                         "s_and_b64 exec, %2, %6\n\tds_write_b32 %9, %15 offset:36\n\t"
-                                         "s_and_b64 exec, %3, %6\n\tds_write_b32 %9, %16 offset:40\n\t"
-                                         "s_and_b64 exec, %4, %6\n\tds_write_b32 %9, %17 offset:44\n\t"
-                                         "s_and_b64 exec, %1, %7\n\tds_write_b32 %9, %18 offset:64\n\t"
-                                         "s_and_b64 exec, %2, %7\n\tds_write_b32 %9, %19 offset:68\n\t"
-                                         "s_and_b64 exec, %3, %7\n\tds_write_b32 %9, %20 offset:72\n\t"
-                                         "s_and_b64 exec, %4, %7\n\tds_write_b32 %9, %21 offset:76\n\t"
-                                         "s_and_b64 exec, %1, %8\n\tds_write_b32 %9, %22 offset:96\n\t"
-                                         "s_and_b64 exec, %2, %8\n\tds_write_b32 %9, %23 offset:100\n\t"
-                                         "s_and_b64 exec, %3, %8\n\tds_write_b32 %9, %24 offset:104\n\t"
-                                         "s_and_b64 exec, %4, %8\n\tds_write_b32 %9, %25 offset:108\n\t"
-                                         "s_mov_b64 exec, %0"
-                                         : "=&s"(sv)
-                                         : "s"(mx0), "s"(mx1), "s"(mx2), "s"(mx3), "s"(my0), "s"(my1), "s"(my2), "s"(my3), "v"(wbo),
-                                           "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]), "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15])
-                                         : "memory", "scc");
+                            GM_SCATTER(acc, l, dx0, dy0)
                             }
                         }
                     }
                     GM_T(42);
-                    if (s == 0) {
-                        if (it > 0) { GM_BLEND(3, recn, countp) GM_T(43); }
-                    } else if (s == cs1 || s == cs2 || s == cs3) {
-                        const int l = GM_LEVEL_OF(G, s - 1);
-                        GM_BLEND(l, recp, count)
-                        GM_T(43);
-                    }
                     lds_barrier();
                     GM_T(44);
                 }
@@ -996,7 +997,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                     GM_BLEND(3, recp, count)
                     lds_barrier();
                 }
-                g += nchunks;
+                g += nchunks + 1;
                 countp = count;
             }
 #undef GM_BLEND
@@ -1017,9 +1018,11 @@ size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8) {
     const int F = B * S;
     const int max_items = tiled_max_items(N, H8, W8);
     const size_t ntiles = (size_t)cdiv(W8, TS) * cdiv(H8, TS);
-    return align_up((size_t)F * N * PIPS_LEVELS * sizeof(int4), 256) + align_up((size_t)F * max_items * sizeof(int4), 256) +
+    // (records and bf16 feature rows: GMAX slots of slack behind the last frame -- an item's run is fetched whole)
+    return align_up(((size_t)F * N + GMAX) * PIPS_LEVELS * sizeof(int4), 256) + align_up((size_t)F * max_items * sizeof(int4), 256) +
            align_up((size_t)F * sizeof(int), 256) + align_up(ntiles * NW * 32 * sizeof(int), 256) +
-           align_up(ntiles * NW * MAXP * 64 * sizeof(unsigned), 256);
+           align_up(ntiles * NW * MAXP * 64 * sizeof(unsigned), 256) + align_up((size_t)F * N * sizeof(int), 256) +
+           align_up(((size_t)F * N + GMAX) * C * 2, 256);
 }
 
 // Selection: dense query sets (on average >= 16 particles per 16x16 level-0 tile) take the tiled kernel;
@@ -1055,11 +1058,13 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     const int tiles_x = cdiv(W8, TS), tiles_y = cdiv(H8, TS), ntiles = tiles_x * tiles_y;
     const int max_items = tiled_max_items(N, H8, W8);
     char* p = (char*)scratch;
-    int4* order = (int4*)p; p += align_up((size_t)F * N * PIPS_LEVELS * sizeof(int4), 256);
+    int4* order = (int4*)p; p += align_up(((size_t)F * N + GMAX) * PIPS_LEVELS * sizeof(int4), 256);
     int4* items = (int4*)p; p += align_up((size_t)F * max_items * sizeof(int4), 256);
     int* nitems = (int*)p; p += align_up((size_t)F * sizeof(int), 256);
     int* gpk_tab = (int*)p; p += align_up((size_t)ntiles * NW * 32 * sizeof(int), 256);
-    unsigned* doff_tab = (unsigned*)p;
+    unsigned* doff_tab = (unsigned*)p; p += align_up((size_t)ntiles * NW * MAXP * 64 * sizeof(unsigned), 256);
+    int* slot_of = (int*)p; p += align_up((size_t)F * N * sizeof(int), 256);
+    uint4* featb = (uint4*)p;                                        // bf16 mode: the features as bf16, in sorted order
     const size_t bin_lds = ((size_t)2 * 16 * ntiles + ntiles + 1) * sizeof(int);
     PIPS_CHECK_ARG(bin_lds <= 64 * 1024, "tiled gather: map too large for the tile histogram");
     PIPS_CHECK_ARG((lvl_off[PIPS_LEVELS - 1] + (size_t)F * lvlH[PIPS_LEVELS - 1] * lvlW[PIPS_LEVELS - 1] * C) * 4 < (1ull << 32) && (size_t)B * N * S * PIPS_KIN_PAD * 4 < (1ull << 32) &&
@@ -1074,7 +1079,7 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     }
     if (ev) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(bin_particles_kernel, dim3(F), dim3(1024), bin_lds, st, coords, N, lv, tiles_x, tiles_y, max_items,
-                       order, items, nitems);
+                       order, items, nitems, mirror ? slot_of : nullptr);
     PIPS_CHECK_LAUNCH("bin_particles_kernel");
     if (mirror == nullptr) {
         hipLaunchKernelGGL(tile_table_kernel, dim3(ntiles), dim3(NW * 64), 0, st, lv, tiles_x, gpk_tab, doff_tab);
@@ -1082,7 +1087,8 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     }
     const int M = B * N * S;
     if (ev) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(embed_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ffeats, coords, times, M, X);
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ffeats, coords, times, M, X,
+                       mirror ? slot_of : nullptr, mirror ? featb : nullptr);
     PIPS_CHECK_LAUNCH("embed_rows_kernel");
     {
         static std::atomic<unsigned long long> raised{0};
@@ -1101,7 +1107,7 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
         static std::atomic<unsigned long long> raised_gm{0};
         const int rc = ensure_dynamic_lds(raised_gm, (const void*)gather_mfma_kernel, GM_LDS);
         if (rc != PIPS_OK) return rc;
-        hipLaunchKernelGGL(gather_mfma_kernel, dim3(grid), dim3(GM_THREADS), GM_LDS, st, mirror, lv, ffeats, N, max_items, F,
+        hipLaunchKernelGGL(gather_mfma_kernel, dim3(grid), dim3(GM_THREADS), GM_LDS, st, mirror, lv, featb, N, max_items, F,
                            order, items, nitems, tiles_x, X);
         if (ev) (void)hipEventRecord(ev[3], st);
         PIPS_CHECK_LAUNCH("gather_mfma_kernel");
