@@ -570,7 +570,7 @@ static_assert(GM_ENTS <= 64 && GM_LDS <= 160 * 1024 && GM_WIN_OFF % 16 == 0 && G
 
 #ifndef GM_ABLATE
 #define GM_ABLATE 0      // debugging builds only (timing, wrong results): 1 no loads in the loaders, 2 no products / scatter, 4 no tap stores,
-                         // 8 no blend, 16 batch heads only, 32 no LDS writes in the loaders
+                         // 8 no blend, 16 batch heads only, 32 no LDS writes in the loaders, 64 every map chunk read from one place
 #endif
 typedef __bf16 bf16x8_gm __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_gm __attribute__((ext_vector_type(4)));
@@ -757,8 +757,11 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                 const unsigned offA_ = GM_SEL4(l_, oA0, oA1, oA2, oA3), offB_ = GM_SEL4(l_, oB0, oB1, oB2, oB3);                \
                 const unsigned ve_ = isf_ ? offF : offA_, vo_ = isf_ ? offF : offB_, v7_ = isf_ ? offF7 : offB_;                \
                 const unsigned long long odd_ = isf_ ? 4096ull : 0ull;               /* (a run's odd pieces: the next 4 KiB; a block's: its rows i + 16) */ \
-                const char* s0_ = reinterpret_cast<const char*>(a0_ & ~7ull); const char* s2_ = reinterpret_cast<const char*>(a2_); \
-                const char* s4_ = reinterpret_cast<const char*>(a4_);         const char* s6_ = reinterpret_cast<const char*>(a6_); \
+                const bool fix_ = (GM_ABLATE & 64) && !isf_;                         /* (timing probe: every map chunk = the buffer's first 32 KiB) */ \
+                const char* s0_ = fix_ ? reinterpret_cast<const char*>(mirror) : reinterpret_cast<const char*>(a0_ & ~7ull);    \
+                const char* s2_ = fix_ ? s0_ + 8192 : reinterpret_cast<const char*>(a2_);                                       \
+                const char* s4_ = fix_ ? s0_ + 16384 : reinterpret_cast<const char*>(a4_);                                      \
+                const char* s6_ = fix_ ? s0_ + 24576 : reinterpret_cast<const char*>(a6_);                                      \
                 /* (loaded as a native vector and re-packed: a struct copy from the selected pointers keeps `pre` in scratch memory) */ \
                 pre[0] = GM_LD16(s0_ + ve_); pre[1] = GM_LD16(s0_ + odd_ + vo_); pre[2] = GM_LD16(s2_ + ve_); pre[3] = GM_LD16(s2_ + odd_ + vo_); \
                 pre[4] = GM_LD16(s4_ + ve_); pre[5] = GM_LD16(s4_ + odd_ + vo_); pre[6] = GM_LD16(s6_ + ve_); pre[7] = GM_LD16(s6_ + odd_ + v7_); \
