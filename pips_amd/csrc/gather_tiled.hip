@@ -525,16 +525,17 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
 //     its own loop over the batches of GM_ENTS work items.  The first cut (every wave loading, multiplying and storing; two blocks
 //     per compute unit for overlap) ran 350 us where its parts, timed alone, needed 65 (map loads) + 75 (products) + 40 (stores) +
 //     42 (the rest): a wave's vector-memory counter is in order, so a wait for map loads also waited for the tap stores issued
-//     before them, and every step exposed a memory round trip.  Now a loader wave issues nothing but map loads;
-//   * batch head (first loader wave, lane = item): the items' geometry and the loaders' chunk table (gm_geo_store) into LDS;
-//   * a batch's pixel blocks -- the region of each level cut into blocks of 8 x 4 pixels = the 32 rows of one MFMA -- form ONE
-//     stream of chunks of four blocks (32 KiB: all 128 channels) over the items and their four levels; in the step whose products
-//     read chunk q (stage buffer q & 1) the loaders write chunk q + 1 (requested two steps earlier) and request chunk q + 3;
-//     ONE barrier per step.  256-byte rows with the 16-byte chunk index XORed with (row & 15): fragment reads and staging
-//     writes are conflict-free;
-//   * B operand (features) and records: the NEXT item's are fetched by the product waves under the current item's steps (fp32 ->
-//     bf16 RNE into LDS; second record buffer); a product wave = (particle block pb of 32, block-in-chunk) keeps the 8 fragments
-//     of ITS lane's particle in registers for the item, and skips a pixel block that no window of its 32 particles reaches;
+//     before them, and every step exposed a memory round trip.  Now a loader wave issues nothing but loads, a product wave none;
+//   * batch head (first loader wave, lane = item): the items' geometry and the loaders' address table (gm_geo_store) into LDS;
+//   * a batch's items form ONE stream of 32-KiB elements: per item its run of bf16 feature rows and records (embed_rows_kernel and
+//     bin_particles_kernel write them in the sorted order, so the run is contiguous), then its map chunks -- the region of each
+//     level cut into pixel blocks of 8 x 4 pixels = the 32 rows of one MFMA, four blocks per chunk.  In the step that consumes
+//     element q the loaders write element q + 1 (requested two steps earlier) into LDS (feature / record buffers, or stage buffer
+//     (q + 1) & 1) and request element q + 3; ONE barrier per step.  256-byte rows with the 16-byte chunk index XORed with
+//     (row & 15): fragment reads and staging writes are conflict-free;
+//   * the product waves issue no load: a wave = (particle block pb of 32, block-in-chunk) reads the 8 B fragments of ITS lane's
+//     particle from the feature buffer in the item's first step (which also hosts the previous item's last blend) and skips a
+//     pixel block that no window of its 32 particles reaches;
 //   * the accumulator layout does the window test almost for free: a lane holds, for ITS particle (column), the 4 x 4 pixels
 //     x = 4 half + (r & 3), y = r >> 2 of the block, so the window coordinate of register r is (dx0 + (r & 3), dy0 + (r >> 2)) with
 //     ONE (dx0, dy0) per lane and block, the target address in the per-level window buffer win[particle][8][8] (+1 float of
@@ -542,8 +543,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_tiled_kernel(const float* _
 //     the AND of an x- and a y-mask: 16 ds_write_b32 under execution masks;
 //   * two window buffers (level parity): the 2 x 2 blend of level l's 8 x 8 correlations to the 49 taps, in the reference's
 //     transposed order (k = ix * 7 + iy, :379-381) with the weights, scaling and operation order of gather_tiled_kernel's
-//     epilogue, by (particle, iy) rows of 7 taps, runs in the step after the level's last chunk (the last level's in the next item's
-//     step 0).  A window pixel outside the map is never written: the blend tests its neighbours against the map (zeros padding,
+//     epilogue, by (particle, iy) rows of 7 taps, runs at the top of the step after the level's last chunk (the last level's in the
+//     next item's first step).  A window pixel outside the map is never written: the blend tests its neighbours against the map (zeros padding,
 //     :324) instead of clearing the buffer.
 // DESIGN.md 4f has the measurements that led here (tools/gm_trace.py).
 constexpr int GM_PWAVES = 12, GM_LWAVES = 4, GM_WAVES = GM_PWAVES + GM_LWAVES, GM_THREADS = GM_WAVES * 64;
