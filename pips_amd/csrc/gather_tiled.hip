@@ -571,7 +571,7 @@ static_assert(GM_ENTS <= 64 && GM_LDS <= 160 * 1024 && GM_WIN_OFF % 16 == 0 && G
 
 #ifndef GM_ABLATE
 #define GM_ABLATE 0      // debugging builds only (timing, wrong results): 1 no loads in the loaders, 2 no products / scatter, 4 no tap stores,
-                         // 8 no blend, 16 batch heads only, 32 no LDS writes in the loaders, 64 every map chunk read from one place
+                         // 8 no blend, 16 batch heads only, 32 no LDS writes in the loaders, 64 every map chunk read from one place, 128 no fragment reads in the products
 #endif
 typedef __bf16 bf16x8_gm __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_gm __attribute__((ext_vector_type(4)));
@@ -981,7 +981,8 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                             const char* ap = smem + ((g + s + 1) & 1) * GM_STAGE + bl * GM_BLK_BYTES + l31 * 256;
 #pragma unroll
                             for (int ks = 0; ks < 8; ++ks) {
-                                const uint4 a = *reinterpret_cast<const uint4*>(ap + (((ks * 2 + half) ^ (l31 & 15)) << 4));
+                                const uint4 a = (GM_ABLATE & 128) ? make_uint4((unsigned)ks, (unsigned)lane, 0u, 0u)      // (timing probe: no fragment reads)
+                                                                  : *reinterpret_cast<const uint4*>(ap + (((ks * 2 + half) ^ (l31 & 15)) << 4));
                                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_gm*>(&a),
                                                                               *reinterpret_cast<const bf16x8_gm*>(&bfr[ks]), acc, 0, 0, 0);
                             }
