@@ -1,7 +1,8 @@
 """Per-step timeline of gather_mfma_kernel (a -DGM_TRACE build, PIPS_LIB_PATH): s_memtime stamps of the product wave 0 and the loader wave 12
 of blocks 0 and 1 at config-4 geometry.  Prints the mean clocks between consecutive stamps by (from tag -> to tag).
-tags: 1 item start | loader: 10 prologue loads done, 11 chunk 0 delivered, 12 barrier A, 20 step top, 21 chunk delivered, 22 next requested,
-23 barrier | product: 30 barrier A, 40 step top, 41 MFMAs done, 42 scatter done, 43 blend done, 44 barrier"""
+tags: 1 batch start | loader: 12 next item, 20 step top, 21 element delivered, 22 next element requested, 23 barrier passed |
+product: 30 item start, 43 blend done, 44 barrier passed, 40 step top, 45 before the products, 46 window test done, 41 MFMAs done, 42 scatter done.
+A stamp costs ~160 clocks; a stamp right behind another one also waits for its store (flat: it counts in lgkmcnt) -- ~700 clocks."""
 import os, sys, ctypes, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
