@@ -69,7 +69,10 @@ extern "C" {
 #define PIPS_FLAG_BF16_STREAM 64  /* with PIPS_FLAG_BF16_MIXER (window length 8): the mixer's residual stream is a bf16 tensor, as
                                      PreNormResidual's `fn(norm(x)) + x` is under autocast (nets/pips.py:93-100: both terms bf16) --
                                      token mixing and the down-projections read it, add in fp32 and round once on the way out;
-                                     LayerNorm statistics, GELU and accumulation stay fp32 */
+                                     LayerNorm statistics, GELU and accumulation stay fp32.  IGNORED for window lengths other than
+                                     8 (the generic-S token mixing keeps an fp32 stream).  pips_amd.Pips sets it by default with a
+                                     bf16 mixer since round 5 (outputs differ from rounds 1-4 by ~1e-2 px at BASELINE configs[2];
+                                     Pips.mixer_stream_dtype = torch.float32 restores the fp32 stream) */
 #define PIPS_FLAG_BF16_MAPS   32  /* pips_track / pips_mixer_input_build_ex: the correlation gather reads the bf16 MIRROR of the
                                      pyramid (behind the fp32 levels, pips_pyramid_mirror_offset; written by the bf16 encoder or
                                      pips_pyramid_mirror) -- the reference's rounding point under autocast, where the encoder's
@@ -81,7 +84,13 @@ extern "C" {
                                      it; takes precedence over the two BF16 flags */
 
 const char* pips_last_error(void);
-/* 2 (round 4).  History: 1 -> 2: the pyramid buffer of EVERY encoder mode is pips_pyramid_floats() long (the bf16 encoder writes
+/* 3 (round 6).  History: 2 -> 3 (buffer contracts that grew in round 5; a caller holding buffers sized by the v2 rules gets
+ * out-of-range reads on a dense query set with PIPS_FLAG_BF16_MAPS): pips_pyramid_floats() includes a SLACK behind the bf16 mirror
+ * (4 rows + 16 pixels of the coarsest level: gather_mfma_kernel fetches whole 8 x 4 pixel blocks unmasked past the last level's
+ * last frame), and the tiled gather's scratch (inside pips_track_workspace_bytes* / pips_workspace_bytes) carries the slot map,
+ * the bf16 feature rows of the sorted order and a batch of slots of slack -- size every buffer with the query functions of THIS
+ * version; PIPS_EPI_RES_BF16 is a public constant; pips_mixer_gemm_train honours PIPS_FLAG_BF16_STREAM.
+ * 1 -> 2: the pyramid buffer of EVERY encoder mode is pips_pyramid_floats() long (the bf16 encoder writes
  * a bf16 mirror of the four levels behind them, at pips_pyramid_mirror_offset -- a buffer sized from the level offsets alone
  * is too short); the PIPS_PACK_FFN arena section and pips_mixer_fwd_bf16_fused (round 3's fused FeedForward, measured slower than
  * the two GEMMs again in round 4 -- tools/experiments/) are gone. */
@@ -119,7 +128,7 @@ int    pips_repack_weights_s(const void* const* params_host, int nparams, void* 
 int    pips_delta_stride(int S);
 size_t pips_mixer_workspace_bytes_s(int M, int S);
 int    pips_mixer_fwd_s(const void* arena, const float* X, int M, int S, int flags, float* delta,
-                        void* workspace, size_t workspace_bytes, void* stream);     /* flags: BF16_MIXER / SPLIT_BF16 */
+                        void* workspace, size_t workspace_bytes, void* stream);     /* flags: BF16_MIXER (+ BF16_STREAM at S = 8) / SPLIT_BF16 */
 size_t pips_track_workspace_bytes_s(int B, int N, int S);
 /* pips_track / pips_track_ce (below) with the window length as an argument; ce_* may be NULL */
 int    pips_track_s(const void* arena, const float* pyramid, int B, int T, int H8, int W8, const float* xys,
@@ -295,9 +304,16 @@ int    pips_conv_nhwc_f32(const float* in, int F, int H, int W, int Cin,
                           const float* wgt, const float* bias, int Cout, int ksize, int cstride, int pad,
                           float* out, float* stats, int* tiles_m_host, void* stream);
 
+/* epi values of the GEMM building blocks; PIPS_EPI_RES_BF16 is OR-ed to PIPS_EPI_RESIDUAL for pips_gemm_bf16 with out_bf16 = 1:
+ * the residual R is a bf16 tensor too (the mixer's bf16 residual stream, PIPS_FLAG_BF16_STREAM).  Any other combination with it is
+ * rejected (PIPS_E_ARG) -- without out_bf16 a bf16 R would be read as fp32. */
+#define PIPS_EPI_BIAS      0
+#define PIPS_EPI_GELU      1
+#define PIPS_EPI_RESIDUAL  2
+#define PIPS_EPI_RES_BF16  0x1000
 /* bf16-operand building block (BASELINE config 3): A fp32 (rounded to bf16 while staged) or bf16 [M][lda], W bf16 [N][K]
- * (round-to-nearest-even of the fp32 weights), fp32 accumulation, C fp32 or bf16 [M][ldc]; epi as pips_gemm_f32.
- * K % 32 == 0 (K % 64 unless A and C are fp32). */
+ * (round-to-nearest-even of the fp32 weights), fp32 accumulation, C fp32 or bf16 [M][ldc]; epi as pips_gemm_f32
+ * (+ PIPS_EPI_RES_BF16).  K % 32 == 0 (K % 64 unless A and C are fp32). */
 int    pips_gemm_bf16(const void* A, int a_bf16, int lda, const void* W, const float* bias, void* C, int out_bf16, int ldc,
                       int M, int N, int K, int epi, const float* R, int ldr, void* stream);
 /* Which kernel pips_gemm_bf16 (and the bf16 mixer of pips_forward) takes for a problem with bias and, for epi = residual, an

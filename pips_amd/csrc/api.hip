@@ -167,7 +167,7 @@ using namespace pips;
 extern "C" {
 
 const char* pips_last_error(void) { return g_err; }
-int pips_abi_version(void) { return 2; }
+int pips_abi_version(void) { return 3; }
 
 size_t pips_weight_arena_bytes(void) { return pips_weight_arena_bytes_s(PIPS_S); }
 int pips_delta_stride(int S) { return (S < 1 || S > PIPS_S_MAX) ? 0 : arena_layout(S).nout_pad; }
@@ -1005,7 +1005,11 @@ int pips_mixer_gemm_train(const void* arena_v, int M, int flags, void* workspace
         set_error("mixer_gemm_train: workspace %zu < %zu bytes", workspace_bytes, pips_mixer_workspace_bytes_s(M, PIPS_S));
         return PIPS_E_WORKSPACE;
     }
-    const int mm = (flags & PIPS_FLAG_SPLIT_BF16) ? 2 : ((flags & PIPS_FLAG_BF16_MIXER) ? 1 : 0);
+    // the mode pips_mixer_fwd_s derives from the same flags (incl. PIPS_FLAG_BF16_STREAM: the workspace's x is then a bf16 stream and
+    // the down-projection the bf16-residual kernel the forward launches)
+    const int mm0 = mixer_mode(flags);
+    const int xb = mm0 == 3 ? 1 : 0;
+    const int mm = mm0 == 3 ? 1 : mm0;
     hipStream_t st = (hipStream_t)stream;
     const ArenaLayout& A = arena_layout(PIPS_S);
     const float* arena = (const float*)arena_v;
@@ -1033,8 +1037,8 @@ int pips_mixer_gemm_train(const void* arena_v, int M, int flags, void* workspace
         const MixLayerW& L = A.mix[d];
         if (mm == 2) return pips_gemm_f32x3(h, 4 * PIPS_DMIX, tw + A.t_w2[d], arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
                                             EPI_RESIDUAL, x, PIPS_DMIX, stream);
-        if (mm == 1) return gemm_h(h, 1, 4 * PIPS_DMIX, hw + A.h_w2[d], arena + L.b2, x, 0, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
-                                   EPI_RESIDUAL, x, PIPS_DMIX, st);
+        if (mm == 1) return gemm_h(h, 1, 4 * PIPS_DMIX, hw + A.h_w2[d], arena + L.b2, x, xb, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX,
+                                   EPI_RESIDUAL | (xb ? EPI_RES_BF16 : 0), x, PIPS_DMIX, st);
         return pips_gemm_f32(h, 4 * PIPS_DMIX, arena + L.w2, arena + L.b2, x, PIPS_DMIX, M, PIPS_DMIX, 4 * PIPS_DMIX, EPI_RESIDUAL,
                              x, PIPS_DMIX, stream);
     };

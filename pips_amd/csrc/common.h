@@ -200,7 +200,7 @@ int device_cus();
 enum Epilogue { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
 // flag in GemmArgs::epi beside EPI_RESIDUAL (bf16-operand GEMMs with a bf16 output): the residual R is bf16 as well -- the mixer's
 // residual stream under autocast (nets/pips.py:93-100 adds two bf16 tensors)
-constexpr int EPI_RES_BF16 = 0x1000;
+constexpr int EPI_RES_BF16 = PIPS_EPI_RES_BF16;      // public: include/pips_hip.h
 
 struct GemmArgs {
     const float* A;      // plain: [M][lda]; conv: NHWC input of frame 0

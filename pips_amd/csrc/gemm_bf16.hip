@@ -440,6 +440,9 @@ int launch_gemm_bf16(const GemmArgs& a, int a_bf16, int out_bf16, hipStream_t st
     PIPS_CHECK_ARG((unsigned long long)a.M * (unsigned long long)a.lda < (1ull << 32) &&
                        (unsigned long long)a.N * (unsigned long long)a.K < (1ull << 32),
                    "gemm_bf16: operand exceeds 2^32 elements");
+    // a bf16 residual exists only beside a bf16 output of the residual epilogue: anything else would read a bf16 R as fp32
+    PIPS_CHECK_ARG(!(a.epi & EPI_RES_BF16) || (out_bf16 && (a.epi & 0xff) == EPI_RESIDUAL),
+                   "gemm_bf16: PIPS_EPI_RES_BF16 needs out_bf16 and the residual epilogue (epi = PIPS_EPI_RESIDUAL | PIPS_EPI_RES_BF16)");
     if (gemm_bf16_t4_takes(a, a_bf16, out_bf16)) return launch_gemm_bf16_t4(a, st);      // the config-3 down-projection
     {
         int tpb = 1;

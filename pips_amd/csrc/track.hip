@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 
 // The same gather on the bf16 MIRROR of the pyramid (bf16 mode, PIPS_FLAG_BF16_MAPS): under torch.autocast the encoder's output
 // is a bf16 tensor and CorrBlock.corr multiplies bf16 operands (nets/pips.py:394-395), so bf16 map values are the reference's own
-// rounding point; features, products and sums stay fp32 here.  What it buys is INSTRUCTIONS, not bytes: the direct gather is bound by
+// rounding point; the track features are rounded to bf16 on load (round 6: one rounding contract with gather_mfma_kernel), products
+// (exact in fp32) and sums stay fp32.  What it buys is INSTRUCTIONS, not bytes: the direct gather is bound by
 // the rate of its vector-memory instructions (16 384 blocks x 4 waves x 32 loads at ~30 clocks each = the 107 us it takes at
 // BASELINE configs[2]); with 8 channels per lane a wave load covers FOUR pixels, 16 loads per level instead of 32.
 // Lane = (pixel of the group lane >> 4, channel octet lane & 15); 16 partial dot products per lane, transpose-reduced over the 16
@@ -275,7 +276,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         const int bx = (int)fx0 - PIPS_RADIUS, by = (int)fy0 - PIPS_RADIUS;
 
         const int psel = lane >> 4, c8 = lane & 15;
-        const float4 fa = *reinterpret_cast<const float4*>(ff + c8 * 8), fb = *reinterpret_cast<const float4*>(ff + c8 * 8 + 4);
+        // BOTH operands are bf16 (round 6): under autocast torch.matmul casts the track features as well as the maps
+        // (nets/pips.py:394-397), and gather_mfma_kernel -- the dense route of the same mode -- multiplies bf16 x bf16.  The
+        // features are rounded here (RNE, the hardware convert) so that the two routes differ in summation order only.
+        float4 fa = *reinterpret_cast<const float4*>(ff + c8 * 8), fb = *reinterpret_cast<const float4*>(ff + c8 * 8 + 4);
+        {
+            const unsigned p0 = pack2_bf16(fa.x, fa.y), p1 = pack2_bf16(fa.z, fa.w), p2 = pack2_bf16(fb.x, fb.y), p3 = pack2_bf16(fb.z, fb.w);
+            fa = make_float4(bf16_lo(p0), bf16_hi(p0), bf16_lo(p1), bf16_hi(p1));
+            fb = make_float4(bf16_lo(p2), bf16_hi(p2), bf16_lo(p3), bf16_hi(p3));
+        }
         const unsigned short* base = mirror + lv.off[lvl] + (size_t)frame * H * W * C + c8 * 8;
         uint4 t[16];
         bool ok[16];

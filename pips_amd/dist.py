@@ -30,6 +30,13 @@ def _world(group=None):
     return 0, 1
 
 
+def _live(group=None) -> bool:
+    """A process group exists: the collectives RUN, also with one rank (a one-rank ``all_gather_into_tensor`` is a copy through
+    the backend -- that is how the 1-GPU box executes the RCCL branch, tests/test_dist_gpu.py::test_rccl_one_rank).  Without a
+    process group the sharded entry points are plain single-process calls."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def shard_range(total: int, rank: int, world: int):
     """Contiguous range of ``rank`` out of ``total`` clips / particles; requires an even split so the packed
     all-gather needs no padding (``pad_to_world`` pads a batch that does not divide)."""
@@ -81,7 +88,7 @@ def _all_gather_cat(mine: torch.Tensor, dim: int, group=None) -> torch.Tensor:
 def all_gather_result(trajs_e: torch.Tensor, vis_e: torch.Tensor, group=None, dim: int = 0):
     """Every rank receives the full ``trajs_e (B,S,N,2)`` and ``vis_e (B,S,N)`` from per-rank shards along ``dim``
     (0 = clips, 2 = particles).  One ``all_gather_into_tensor`` of the packed ``[x, y, vis]``."""
-    if _world(group)[1] == 1:
+    if not _live(group):
         return trajs_e, vis_e
     out = _all_gather_cat(pack_result(trajs_e, vis_e), dim, group)
     return out[..., :2].contiguous(), out[..., 2].contiguous()
@@ -105,7 +112,7 @@ def encode_sharded(model, rgbs, group=None):
     from . import _lib, ops
     from .pips import FeatureCache
     rank, world = _world(group)
-    if world == 1:
+    if not _live(group):
         return model.encode(rgbs)
     B, T, _, H, W = rgbs.shape
     lo, hi = shard_range(T, rank, world)
@@ -133,7 +140,7 @@ def track_sharded_particles(model, xys, rgbs, iters=6, group=None, encode="repli
     rank, world = _world(group)
     if encode not in ("replicate", "frames"):
         raise ValueError("encode must be 'replicate' or 'frames'")
-    cache = encode_sharded(model, rgbs, group) if encode == "frames" and world > 1 else model.encode(rgbs)
+    cache = encode_sharded(model, rgbs, group) if encode == "frames" else model.encode(rgbs)
     xp, n = pad_to_world(xys, world, dim=1)
     lo, hi = shard_range(xp.shape[1], rank, world)
     out = model.track(cache, xp[:, lo:hi], iters=iters, **kw)
@@ -151,6 +158,6 @@ def track_chained_sharded(model, rgbs, xy0, iters=6, group=None):
     xp, n = pad_to_world(xy0, world, dim=1)
     lo, hi = shard_range(xp.shape[1], rank, world)
     mine = drivers.track_chained(model, rgbs, xp[:, lo:hi], iters=iters)          # (1,T,n/G,2)
-    if world == 1:
+    if not _live(group):
         return mine
     return _all_gather_cat(mine, 2, group)[:, :, :n].contiguous()

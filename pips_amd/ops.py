@@ -29,6 +29,7 @@ def _f32(t):
 
 
 PACK_FP32, PACK_BF16, PACK_SPLIT = 1, 2, 4
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_RES_BF16 = 0, 1, 2, 0x1000          # include/pips_hip.h: PIPS_EPI_*
 
 
 def pack_more(arena, sections, S=8):
@@ -346,7 +347,7 @@ def gemm_bf16(A, W, bias=None, epi=0, R=None, out_bf16=False):
     Cm = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=A.device)
     if R is not None and R.dtype == torch.bfloat16:      # a bf16 residual (with a bf16 output): the mixer's bf16 residual stream
         assert out_bf16 and epi == 2
-        epi = epi | 0x1000
+        epi = epi | EPI_RES_BF16
         R = R.contiguous()
     with torch.cuda.device(A.device):
         _lib.check(lib.pips_gemm_bf16(_lib.ptr(A), int(A.dtype == torch.bfloat16), K, _lib.ptr(W), _lib.ptr(bias), _lib.ptr(Cm),

@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.pips_abi_version() == 2        # 2: the pyramid buffer carries its bf16 mirror; the PACK_FFN section and pips_mixer_fwd_bf16_fused are gone
+    assert lib.pips_abi_version() == 3        # 3: slack behind the bf16 mirror, larger tiled-gather scratch, PIPS_EPI_RES_BF16 public (2: bf16 mirror in the pyramid buffer)
     assert lib.pips_weight_arena_bytes() > 28677713 * 4
     # sizing queries are pure host functions
     assert lib.pips_workspace_bytes(1, 8, 368, 496, 256, 8) > 0

@@ -82,8 +82,8 @@ def test_config3_geometry_bf16_residual_stream(weights_tamed):
     fp32-stream form against the autocast oracle (2e-2 px), both distances printed; the down-projections must reach the
     assembly kernel's bf16-stream form."""
     from oracle import pips_oracle as O
-    from pips_amd import Pips, _lib
-    assert _lib.load().pips_gemm_bf16_route(B * N * S, 512, 2048, 2 | 0x1000, 1, 1) == 3
+    from pips_amd import Pips, _lib, ops
+    assert _lib.load().pips_gemm_bf16_route(B * N * S, 512, 2048, 2 | ops.EPI_RES_BF16, 1, 1) == 3
     xys, rgbs = _inputs()
     m = Pips(S=8, stride=8)
     m.load_state_dict(weights_tamed)

@@ -93,9 +93,13 @@ def test_config4_gather_bf16_matrix_cores_vs_oracle():
     Xm = ops.mixer_input_build_tiled(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu()
     Xd = ops.mixer_input_build(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu()
     err = float((Xm[:, 128:324].double() - _pm(ref)).abs().max())
+    errd = float((Xd[:, 128:324].double() - _pm(ref)).abs().max())
     dd = float((Xm[:, 128:324] - Xd[:, 128:324]).abs().max())
-    print(f"config-4 geometry, bf16 mode: matrix-core gather vs fp64 oracle on bf16 operands {err:.2e}, vs the direct bf16-map kernel {dd:.2e}")
-    assert err < 1.5e-4 and dd < 0.2        # (sample positions are fp32 here, fp64 in the yardstick: ~5e-5 at 160-pixel-wide maps)
+    print(f"config-4 geometry, bf16 mode: matrix-core gather vs fp64 oracle on bf16 operands {err:.2e}, the direct bf16-map kernel vs the "
+          f"same oracle {errd:.2e}, route against route {dd:.2e}")
+    # (sample positions are fp32 here, fp64 in the yardstick: ~5e-5 at 160-pixel-wide maps; the two routes share them and the
+    #  operands -- round 6 -- so they differ by summation order only)
+    assert err < 1.5e-4 and errd < 1.5e-4 and dd < 1e-4
     assert torch.equal(Xm[8:16, 128:324], torch.zeros(8, 196))
     assert torch.equal(Xd[:, :128], Xm[:, :128]) and torch.equal(Xd[:, 324:], Xm[:, 324:])
 
@@ -135,6 +139,37 @@ def test_config4_geometry_bf16_mode_end_to_end_against_autocast_oracle(weights_t
     print(f"config-4 geometry, bf16 mode end to end (B=1, N=4096, I=6): HIP vs bf16-autocast oracle {e_bf:.2e} px (vis logits {e_vis:.2e}), "
           f"HIP vs fp32 oracle {e_32:.2e} px, autocast oracle vs fp32 oracle {e_ref:.2e} px")
     assert e_bf < 2e-2 and e_32 < 2e-2 and e_vis < 0.15
+
+
+def test_bf16_mode_dense_query_set_agrees_with_its_particle_shards(weights_tamed):
+    """The advisor's round-5 finding: in the bf16 mode a particle's correlations depended on WHICH gather kernel its query set
+    reached (dense sets: bf16 x bf16 on the matrix cores; sparse sets: fp32 features x bf16 maps), so `dist.track_sharded_particles`
+    -- which turns one dense set into G sparse ones -- changed a particle's result by 7e-3 per tap.  Round 6: both routes round the
+    features to bf16 (nets/pips.py:394-397 casts both matmul operands).  One clip, a 2048-point grid on 46 x 62 maps under autocast:
+    the whole set (route 2 asserted) against its eight shards of 256 (route 0 asserted), same cached maps.  What is left is the
+    order of the fp32 sums in the gather (<= 1e-4 per tap, tests/test_kernels_gpu.py) and, from the second iteration on, what the
+    bf16 mixer makes of a tap that rounds the other way: printed, gated at a quarter of the bf16 mode's own 2e-2 px budget."""
+    from pips_amd import Pips, _lib
+    lib = _lib.load()
+    B, H, W, N, G = 1, 368, 496, 2048, 8
+    assert lib.pips_gather_route(B, N, H // 8, W // 8, 32) == 2 and lib.pips_gather_route(B, N // G, H // 8, W // 8, 32) == 0
+    g = torch.Generator().manual_seed(9)
+    rgbs = torch.randint(0, 256, (B, 8, 3, H, W), generator=g).float().to(DEV)
+    xys = (_grid(N, H, W).unsqueeze(0) + torch.rand(B, N, 2, generator=g) * 2.0).to(DEV)
+    m = Pips(stride=8)
+    m.load_state_dict(weights_tamed)
+    m = m.to(DEV).eval()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        cache = m.encode(rgbs)
+        assert cache.bf16_maps
+        whole = m.track(cache, xys, iters=6)
+        parts = [m.track(cache, xys[:, r * (N // G):(r + 1) * (N // G)].contiguous(), iters=6) for r in range(G)]
+    e1 = float((whole[0][0] - torch.cat([p[0][0] for p in parts], dim=2)).abs().max())
+    e6 = float((whole[0][-1] - torch.cat([p[0][-1] for p in parts], dim=2)).abs().max())
+    ev = float((whole[2] - torch.cat([p[2] for p in parts], dim=2)).abs().max())
+    print(f"bf16 mode, dense set (matrix-core gather) vs its 8 particle shards (direct gather): first iterate {e1:.2e} px, after 6 "
+          f"iterations {e6:.2e} px, vis logits {ev:.2e}")
+    assert e1 < 2e-3 and e6 < 5e-3 and ev < 5e-2
 
 
 def test_config4_teacher_forced_iteration(weights_raw):

@@ -4,6 +4,8 @@ secondary axis for B < G -- particles sharded on replicated or frame-sharded map
 
 * ``test_rccl_*`` need >= 2 visible GPUs and skip on the 1-GPU gpurun box; on a multi-GPU node they are the first thing
   that sends the real ``Pips`` through ``init_process_group("nccl", device_id=...)`` (RCCL over xGMI).
+* ``test_rccl_one_rank`` runs on the 1-GPU box: one rank, backend nccl -- the communicator and every collective of pips_amd.dist
+  execute in RCCL (as copies), bit-equal to the plain forward.
 * ``test_two_ranks_share_one_gpu_gloo`` runs everywhere a GPU is visible: two ranks on cuda:0, gloo for the exchange (RCCL
   refuses two ranks on one device) -- the real model, the real shard / pack / gather / unpack code, only the transport differs.
   Its log goes to gpurun_out/ (copied to profiles/ by hand).
@@ -126,6 +128,23 @@ def test_rccl_bench_line_two_ranks():
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
     assert res["config"]["collective"].endswith("nccl (RCCL)")
     assert res["collective_ms"]["median_ms"] > 0
+
+
+def test_rccl_one_rank():
+    """What ONE GPU allows of the RCCL path (round 6): ``init_process_group("nccl", world_size=1, device_id=cuda:0)`` loads
+    librccl, creates the communicator and runs every collective of pips_amd.dist -- the packed ``all_gather_into_tensor`` of
+    ``track_sharded`` (clips), ``track_sharded_particles`` on replicated AND frame-sharded maps (one all-gather per pyramid
+    level + one on the particle axis) and ``track_chained_sharded`` -- on device tensors through the real ``nccl`` backend
+    (pips_amd.dist runs its collectives whenever a process group exists, also with one rank).  Bit-equal to the plain forward.
+    It cannot show scaling; it shows that the RCCL branch executes."""
+    res = _run_ranks(1, "nccl", share_device=False)
+    assert [r[0] for r in res] == [0] and res[0][1], res
+    assert res[0][2] == "nccl"
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "rccl_one_rank.log"), "w") as f:
+        f.write("tests/test_dist_gpu.py::test_rccl_one_rank: init_process_group('nccl', world_size=1, device_id=cuda:0); track_sharded, "
+                "track_sharded_particles (replicate, frames), track_chained_sharded: every collective through RCCL on device tensors\n")
+        f.write(f"rank 0: gathered == plain single-process results bit for bit: {res[0][1]}  backend {res[0][2]}\n")
 
 
 def test_two_ranks_share_one_gpu_gloo():

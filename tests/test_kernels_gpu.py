@@ -460,12 +460,15 @@ def test_mixer_input_build_tiled_bf16_mfma(B, N, H8, W8, spread):
     pyr = ops.pyramid_mirror(_pack_pyramid(pyr_ref, B, H8 * 8, W8 * 8, 8), B * 8, H8 * 8, W8 * 8, 8)
     ff, co = _pm(ffeats).to(DEV), _pm(coords).to(DEV)
     X = ops.mixer_input_build_tiled(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu()
-    Xd = ops.mixer_input_build(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu()                    # direct kernel: fp32 features x bf16 maps
+    Xd = ops.mixer_input_build(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu()                    # direct kernel: the SAME bf16 x bf16 products (round 6)
     assert torch.equal(X[:, :128], Xd[:, :128]) and torch.equal(X[:, 324:], Xd[:, 324:])       # features, embedding, padding
     err = float((X[:, 128:324].double() - _pm(ref)).abs().max())
+    errd = float((Xd[:, 128:324].double() - _pm(ref)).abs().max())
     dd = float((X[:, 128:324] - Xd[:, 128:324]).abs().max())
-    print(f"bf16 matrix-core gather vs fp64 oracle on bf16 operands {err:.2e}; vs the direct bf16-map kernel (fp32 features) {dd:.2e}")
-    assert err < 1e-4 and dd < 0.2          # (sample positions: fp32 here, fp64 in the yardstick)
+    print(f"bf16 matrix-core gather vs fp64 oracle on bf16 operands {err:.2e}; the direct bf16-map kernel vs the same oracle {errd:.2e}; "
+          f"route against route {dd:.2e}")
+    # one rounding contract whatever the route: the two kernels differ by the order of their fp32 sums only
+    assert err < 1e-4 and errd < 1e-4 and dd < 1e-4          # (sample positions: fp32 here, fp64 in the yardstick)
     assert torch.equal(X.view(B * N, 8, 544)[1, 6, 128:324], torch.zeros(196))                   # fully outside the map: zeros padding
 
 
@@ -541,9 +544,11 @@ def test_mixer_input_build(B, N, H8, W8):
 
 @pytest.mark.parametrize("B,N,H8,W8", [(1, 24, 16, 20), (2, 9, 17, 25), (1, 5, 46, 62)])
 def test_mixer_input_build_bf16_maps(B, N, H8, W8):
-    """The gather of the bf16 mode (PIPS_FLAG_BF16_MAPS): the kernel reads the bf16 mirror of the pyramid, features and sums stay
-    fp32 -- against the oracle's CorrBlock on maps rounded to bf16 the same way (fp32 tolerance), border windows included, and
-    within bf16 rounding of the fp32 gather."""
+    """The gather of the bf16 mode (PIPS_FLAG_BF16_MAPS): the kernel reads the bf16 mirror of the pyramid and rounds the track
+    features to bf16 on load -- under autocast torch.matmul casts BOTH operands (nets/pips.py:394-397); products (exact) and sums
+    fp32.  Against the oracle's CorrBlock on maps AND features rounded the same way, in fp32 and in fp64 (the yardstick of
+    test_config4_gather_bf16_matrix_cores_vs_oracle), border windows included, and within bf16 rounding of the fp32 gather.  The
+    feature columns of X stay fp32 (the in-projection rounds them itself)."""
     from pips_amd import ops
     O = _oracle()
     fmaps, ffeats, coords = _random_state(B, N, H8, W8, seed=3)
@@ -551,16 +556,19 @@ def test_mixer_input_build_bf16_maps(B, N, H8, W8):
     coords[0, :, 1] = torch.tensor([W8 - 1.0, H8 - 1.0])
     pyr_ref = O.build_pyramid(fmaps)
     pyr_bf = [p.bfloat16().float() for p in pyr_ref]                     # the mirror holds bf16(level), level by level
-    X_ref = O.mixer_input(ffeats, O.corr_sample(pyr_bf, ffeats, coords), coords)
+    ff_bf = ffeats.bfloat16().float()
+    X_ref = O.mixer_input(ffeats, O.corr_sample(pyr_bf, ff_bf, coords), coords)
+    ref64 = O.corr_sample([p.double() for p in pyr_bf], ff_bf.double(), coords.double())          # (B,8,N,196)
     pyr = ops.pyramid_mirror(_pack_pyramid(pyr_ref, B, H8 * 8, W8 * 8, 8), B * 8, H8 * 8, W8 * 8, 8)
     ff, co = _pm(ffeats).to(DEV), _pm(coords).to(DEV)
     X = ops.mixer_input_build(pyr, B, H8, W8, ff, co, bf16_maps=True).cpu().view(B * N, 8, 544)
     X32 = ops.mixer_input_build(pyr, B, H8, W8, ff, co).cpu().view(B * N, 8, 544)
     assert torch.equal(X[..., :128], X_ref[..., :128]) and torch.equal(X[..., 324:], X32[..., 324:])
     err = float((X[..., 128:324] - X_ref[..., 128:324]).abs().max())
+    err64 = float((X[..., 128:324].reshape(B * N * 8, 196).double() - _pm(ref64)).abs().max())
     d32 = float((X[..., 128:324] - X32[..., 128:324]).abs().max())
-    print(f"bf16-map gather vs oracle on bf16-rounded maps {err:.2e}; vs the fp32 gather {d32:.2e}")
-    assert err < 5e-5 and 1e-4 < d32 < 0.2
+    print(f"bf16-map gather vs oracle on bf16-rounded operands {err:.2e} (fp64 oracle {err64:.2e}); vs the fp32 gather {d32:.2e}")
+    assert err < 5e-5 and err64 < 5e-5 and 1e-4 < d32 < 0.3
 
 
 @pytest.mark.parametrize("B,N,H8,W8,spread", [(1, 300, 46, 62, 0.7), (2, 1024, 33, 40, 3.0), (1, 77, 16, 20, 0.0)])
@@ -642,6 +650,22 @@ def test_gemm_bf16(M, N, K, epi, out_bf16):
         assert float((out - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
 
 
+def test_gemm_bf16_rejects_bf16_residual_flag_without_bf16_output():
+    """PIPS_EPI_RES_BF16 (public since ABI 3) is defined beside a bf16 output of the residual epilogue only: with an fp32 C, or on
+    another epilogue, the flag used to be ignored silently and a bf16 R read as fp32 -- now PIPS_E_ARG."""
+    from pips_amd import ops, _lib
+    lib = _lib.load()
+    M, N, K = 256, 256, 128
+    A = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16)
+    W = torch.zeros(N, K, device=DEV, dtype=torch.bfloat16)
+    R = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    for out_bf16, epi in ((0, ops.EPI_RESIDUAL | ops.EPI_RES_BF16), (1, ops.EPI_GELU | ops.EPI_RES_BF16), (1, ops.EPI_BIAS | ops.EPI_RES_BF16)):
+        Cm = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        rc = lib.pips_gemm_bf16(_lib.ptr(A), 1, K, _lib.ptr(W), None, _lib.ptr(Cm), out_bf16, N, M, N, K, epi, _lib.ptr(R), N, ops._stream())
+        assert rc != 0 and b"PIPS_EPI_RES_BF16" in lib.pips_last_error()
+    assert ops.gemm_bf16(A, W, None, epi=2, R=R, out_bf16=True).dtype == torch.bfloat16          # the defined combination
+
+
 @pytest.mark.parametrize("M,N,K", [(16384, 512, 2048), (8192, 512, 2048), (32896, 256, 128), (2048, 512, 2048), (1000, 384, 128)])
 def test_gemm_bf16_residual_stream(M, N, K):
     """The down-projection with a bf16 residual stream (EPI_RES_BF16: bf16 R, bf16 C -- nets/pips.py:93-100 under autocast): the
@@ -658,7 +682,7 @@ def test_gemm_bf16_residual_stream(M, N, K):
     ref = A.double() @ W.double().t() + b.double() + R.double()
     err = (out.double() - ref).abs()
     assert bool((err <= ref.abs() * 2.0 ** -8 + 2e-5).all()), float((err / (ref.abs() + 1e-2)).max())
-    route = _lib.load().pips_gemm_bf16_route(M, N, K, 2 | 0x1000, 1, 1)
+    route = _lib.load().pips_gemm_bf16_route(M, N, K, 2 | ops.EPI_RES_BF16, 1, 1)
     takes = M % 128 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 128) * (N // 256) * 2 >= _cus()      # from half a tile per compute unit
     assert route == (3 if takes else 0)
 
