@@ -243,7 +243,9 @@ def pmc_traffic(kernel_substr):
     WRITE_SIZE in separate runs of the same commands, tools/profile_round.sh; a live bench run cannot collect PMC
     counters itself).  Returns (bytes or None, source)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))      # the latest round's passes
+    import re
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")) if re.search(r"r\d+_pmc_traffic\.json$", f)]
+    files.sort(key=lambda f: int(re.search(r"r(\d+)_pmc_traffic", f).group(1)))           # the latest round's passes (r10 after r9)
     name = os.path.basename(files[-1]) if files else "r2_pmc_traffic.json"
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]

@@ -320,6 +320,13 @@ __global__ __launch_bounds__(WGM * WGN * KS * 64) void gemm_x3_kernel(GemmArgs p
 #undef PIPS_MFMA3B
 #undef PIPS_SB
 
+    // The epilogue reads the accumulators (v_accvgpr_read).  hipcc pads that MFMA -> VALU read itself, but on the branchy path into the
+    // epilogue of the KS = 1 forms its padding came out 3 wait states short of its own table (tools/asm_hazard_lint.py: 9 of 12, across two
+    // taken branches): state the distance explicitly, once per tile.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 11");
+    __builtin_amdgcn_sched_barrier(0);
+
     if (!ksplit_reduce<KS, WGM * WGN, TM, TN>(acc, reinterpret_cast<float*>(smem), ks, wmn, lane)) return;
 
     if (CONV) {

@@ -187,3 +187,51 @@ def test_build_script_dependencies_exist_and_asm_is_current(tmp_path):
         env["PIPS_GEN_OUT"] = str(out6)
         subprocess.check_call([sys.executable, os.path.join(root, "tools", gen)], env=env, stdout=subprocess.DEVNULL)
         assert out6.read_text() == open(os.path.join(root, "pips_amd", "csrc", inc)).read()
+
+
+def _lint():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("asm_hazard_lint", os.path.join(root, "tools", "asm_hazard_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, root
+
+
+def test_asm_hazard_lint_passes_head_and_flags_the_round5_scatter():
+    """Every instruction stream of the shipped library -- hipcc's code and the 37 k lines of generated / hand-written assembly that
+    its hazard recognizer never sees -- holds the software wait states of tools/asm_hazard_lint.py's table (MFMA result -> any
+    reader or writer, VALU-written SGPR / VCC -> VALU / vector memory / lane select, M0 -> LDS-DMA, ...): the disassembly of
+    libpips_hip.so has no finding.  The negative fixture is the scatter of gather_mfma_kernel as commit a4e2782~1 built it -- the MFMA ->
+    DS-read hazard round 5 met by accident: the lint must flag its four ds_write_b32."""
+    L, root = _lint()
+    from pips_amd import _build
+    findings, st = L.lint_path(_build.build_library(verbose=False))
+    assert st["kernels"] > 100 and st["mfma"] > 10000, st          # the whole library was read
+    assert findings == [], findings[:5]
+    neg, _ = L.lint_path(os.path.join(root, "tests", "golden", "hazard_negative_gather_mfma_pre_a4e2782.s"))
+    assert len(neg) == 4 and all("v_mfma_f32_32x32x16_bf16 result -> read by ds_write_b32" in f["rule"] for f in neg), neg
+    assert sorted(f["have"] for f in neg) == [4, 6, 8, 10] and all(f["need"] == 12 for f in neg)
+
+
+def test_hazard_table_matches_the_compilers_recognizer():
+    """gfx950's wait-state table is not in this image; the lint's numbers are pinned against hipcc's own hazard recognizer: one probe
+    kernel per producer / consumer pair (tools/asm_hazard_probe.hip, builtins + sched_barriers), the s_nops hipcc inserts are the
+    requirement."""
+    L, _ = _lint()
+    rows = L.measure_probes()
+    assert len(rows) >= 28
+    bad = [r for r in rows if r[1] != r[2]]
+    assert not bad, bad
+
+
+def test_generators_take_their_wait_states_from_one_place():
+    """The five pasted `s_nop 15; s_nop 15` pairs of rounds 4-5 are gone: every generator takes its guards from tools/asm_guards.py,
+    whose numbers are the lint's table."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gens = sorted(glob.glob(os.path.join(root, "tools", "gen_*.py")))
+    assert len(gens) == 6
+    for g in gens:
+        src = open(g).read()
+        assert "import asm_guards" in src and "s_nop 15" not in src, g

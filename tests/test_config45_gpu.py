@@ -145,13 +145,13 @@ def test_bf16_mode_dense_query_set_agrees_with_its_particle_shards(weights_tamed
     """The advisor's round-5 finding: in the bf16 mode a particle's correlations depended on WHICH gather kernel its query set
     reached (dense sets: bf16 x bf16 on the matrix cores; sparse sets: fp32 features x bf16 maps), so `dist.track_sharded_particles`
     -- which turns one dense set into G sparse ones -- changed a particle's result by 7e-3 per tap.  Round 6: both routes round the
-    features to bf16 (nets/pips.py:394-397 casts both matmul operands).  One clip, a 2048-point grid on 46 x 62 maps under autocast:
-    the whole set (route 2 asserted) against its eight shards of 256 (route 0 asserted), same cached maps.  What is left is the
+    features to bf16 (nets/pips.py:394-397 casts both matmul operands).  One clip, a 2304-point grid on 46 x 62 maps under autocast:
+    the whole set (route 2 asserted) against its eight shards of 288 (route 0 asserted), same cached maps.  What is left is the
     order of the fp32 sums in the gather (<= 1e-4 per tap, tests/test_kernels_gpu.py) and, from the second iteration on, what the
     bf16 mixer makes of a tap that rounds the other way: printed, gated at a quarter of the bf16 mode's own 2e-2 px budget."""
     from pips_amd import Pips, _lib
     lib = _lib.load()
-    B, H, W, N, G = 1, 368, 496, 2048, 8
+    B, H, W, N, G = 1, 368, 496, 2304, 8                      # a 48 x 48 grid, 288 queries per shard
     assert lib.pips_gather_route(B, N, H // 8, W // 8, 32) == 2 and lib.pips_gather_route(B, N // G, H // 8, W // 8, 32) == 0
     g = torch.Generator().manual_seed(9)
     rgbs = torch.randint(0, 256, (B, 8, 3, H, W), generator=g).float().to(DEV)

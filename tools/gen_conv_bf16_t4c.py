@@ -28,6 +28,10 @@ Registers (all clobbered):
     s[40:55] descriptors A, W, C, bias;  s[56:64] tap offsets;  s[65:77] loop state
 """
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import asm_guards as G  # noqa: E402  (wait-state guards: the numbers live in tools/asm_hazard_lint.py)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "conv_bf16_t4c_asm.inc"))
@@ -135,6 +139,7 @@ def load_piece(e, s, kw):
         if kw != 1:
             e.raw("v_and_b32 v%d, %d, v%d" % (TMP, 1 if kw == 0 else 2, FLG + s))
             e.raw("v_cmp_ne_u32 vcc, 0, v%d" % TMP)
+            G.emit_sgpr_to_valu_guard(e.raw)                   # VCC written by a VALU compare -> v_cndmask reads it
             e.raw("v_cndmask_b32 v%d, v%d, v%d, vcc" % (off, off, VOOB))
         e.vmem("buffer_load_dwordx4 v[%d:%d], v%d, s[%d:%d], 0 offen" % (reg, reg + 3, off, RS_A, RS_A + 3), ("st", s))
     else:
@@ -162,8 +167,10 @@ def column_flags(e, pix0):
         e.raw("v_mul_lo_u32 v%d, v%d, %%[imgW]" % (TMP + 1, TMP + 1))
         e.raw("v_sub_u32 v%d, v%d, v%d" % (TMP, TMP, TMP + 1))            # column
         e.raw("v_cmp_eq_u32 vcc, 0, v%d" % TMP)
+        G.emit_sgpr_to_valu_guard(e.raw)
         e.raw("v_cndmask_b32_e64 v%d, 0, 1, vcc" % (FLG + s))
         e.raw("v_cmp_eq_u32 vcc, %%[wm1], v%d" % TMP)
+        G.emit_sgpr_to_valu_guard(e.raw)
         e.raw("v_cndmask_b32_e64 v%d, 0, 2, vcc" % (TMP + 1))
         e.raw("v_or_b32 v%d, v%d, v%d" % (FLG + s, FLG + s, TMP + 1))
 
@@ -224,8 +231,7 @@ def epilogue(e, free_par):
     """the finished tile: + bias, bf16, 16-byte stores (dropped by the frame's descriptor past its last pixel).  Temporaries: the
     fragment set that does not hold the next tile's first fragments.  Entered with a full wait, left with its stores in flight."""
     e.drain()
-    e.raw("s_nop 15")
-    e.raw("s_nop 15")
+    G.emit_mfma_result_guard(e.raw, "v_mfma_f32_16x16x32_bf16")      # the tile's last MFMAs -> v_accvgpr_read
     base = FA[free_par]
     BIAS, XS, OS = base, [base + 8, base + 16], [OREG, OREG + 4]
     k = 0

@@ -26,6 +26,10 @@ the same way; rows behind the frame's last pixel are masked): one float4 per (wa
 Registers: class Cfg.  All clobbered; v[216:255] stay with the compiler.
 """
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import asm_guards as G  # noqa: E402  (wait-state guards: the numbers live in tools/asm_hazard_lint.py)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "conv_f32_t4_asm.inc"))
@@ -152,6 +156,7 @@ def load_piece(e, c, ring, s, kw):
         if kw != 1 and "noflags" not in ABLATE:
             e.raw("v_and_b32 v%d, %d, v%d" % (c.tmp, 1 if kw == 0 else 2, c.flg + s))
             e.raw("v_cmp_ne_u32 vcc, 0, v%d" % c.tmp)
+            G.emit_sgpr_to_valu_guard(e.raw)                   # VCC written by a VALU compare -> v_cndmask reads it
             e.raw("v_cndmask_b32 v%d, v%d, v%d, vcc" % (off, off, c.voob))
         e.vmem("buffer_load_dwordx4 v[%d:%d], v%d, s[%d:%d], 0 offen" % (reg, reg + 3, off, RS_A, RS_A + 3), ("st", ring, s))
     else:
@@ -187,8 +192,10 @@ def column_flags(e, c, pix0):
         e.raw("v_mul_lo_u32 v%d, v%d, %%[imgW]" % (T + 1, T + 1))
         e.raw("v_sub_u32 v%d, v%d, v%d" % (T, T, T + 1))                  # column
         e.raw("v_cmp_eq_u32 vcc, 0, v%d" % T)
+        G.emit_sgpr_to_valu_guard(e.raw)
         e.raw("v_cndmask_b32_e64 v%d, 0, 1, vcc" % (c.flg + s))
         e.raw("v_cmp_eq_u32 vcc, %%[wm1], v%d" % T)
+        G.emit_sgpr_to_valu_guard(e.raw)
         e.raw("v_cndmask_b32_e64 v%d, 0, 2, vcc" % (T + 1))
         e.raw("v_or_b32 v%d, v%d, v%d" % (c.flg + s, c.flg + s, T + 1))
 
@@ -245,8 +252,7 @@ def epilogue(e, c):
         tile_advance(e, c)
         return
     e.need_loads()
-    e.raw("s_nop 15")
-    e.raw("s_nop 15")
+    G.emit_mfma_result_guard(e.raw, "v_mfma_f32_32x32x2_f32")            # the tile's last MFMAs -> v_accvgpr_read
     T, CNT, D = c.tmp, c.cnt, c.d
     e.raw("s_sub_u32 s%d, %%[npix], s%d" % (S_NVR, S_P))                  # pixels of the frame from this tile's first on (>= 1)
     e.raw("s_mul_i32 s%d, s%d, %d" % (S_C0, S_P, 4 * c.cout))             # the tile's first output row, bytes

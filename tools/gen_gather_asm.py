@@ -21,6 +21,10 @@ Registers (everything from v23 / s16 up is private to the statement):
     s[36:67]     feature set 0: two slots x 16 channels;  s[68:99] feature set 1
 """
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import asm_guards as G  # noqa: E402  (wait-state guards: the numbers live in tools/asm_hazard_lint.py)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "gather_item_asm.inc"))
@@ -145,8 +149,10 @@ def setup(a):
             a("v_add_u32 v%d, s%d, v%d" % (px, S_U, wi))
             a("v_add_u32 v%d, s%d, v%d" % (py, S_U + 1, wj))
             a("v_cmp_gt_u32 vcc, s%d, v%d" % (W, px))              # px < W (unsigned: also px >= 0)
+            G.emit_sgpr_to_valu_guard(a)                           # VCC from a VALU compare -> v_cndmask: two wait states (gfx940+)
             a("v_cndmask_b32 v%d, 0, 1, vcc" % t)
             a("v_cmp_gt_u32 vcc, s%d, v%d" % (H, py))
+            G.emit_sgpr_to_valu_guard(a)
             a("v_cndmask_b32 v%d, 0, v%d, vcc" % (t, t))
             a("v_lshl_or_b32 v%d, v%d, %d, v%d" % (INM, t, bit, INM))
             a("v_subrev_u32 v%d, s%d, v%d" % (rx, x0, px))         # px - x0, clamped into the staged region
@@ -402,6 +408,7 @@ def epilogue(a):
             a("s_cbranch_scc1 %df" % inside)
             a("v_and_b32 v%d, %s, v%d" % (t, hex(1 << (4 * k + l)), INM))
             a("v_cmp_ne_u32 vcc, 0, v%d" % t)
+            G.emit_sgpr_to_valu_guard(a)
             a("v_cndmask_b32 v%d, 0, v%d, vcc" % (d[l], d[l]))                 # zeros padding outside the map
             a("%d:" % inside)
             for i, off in enumerate((0, 4, 32, 36)):                          # nw, ne, sw, se
@@ -409,13 +416,18 @@ def epilogue(a):
         a("v_readlane_b32 s%d, %%[row], %d" % (S_T, 4 * k))
         a("s_mul_i32 s%d, s%d, %d" % (S_T, S_T, KIN_PAD * 4))
         a("s_waitcnt lgkmcnt(0)")
+        # the 16 blend weights of the slot (4 levels x nw / ne / sw / se) go to SGPRs FIRST -- the feature sets are free in the
+        # epilogue -- and are used afterwards: an SGPR written by v_readlane needs two wait states before a VALU instruction
+        # reads it (gfx940+; rounds 2-5 used one SGPR per weight, read by the very next instruction)
         for l in range(LEVELS):
             for i in range(4):
-                a("v_readlane_b32 s%d, v%d, %d" % (S_U, w[i], 4 * k + l))
+                a("v_readlane_b32 s%d, v%d, %d" % (SET[0] + 4 * l + i, w[i], 4 * k + l))
+        for l in range(LEVELS):
+            for i in range(4):
                 if i == 0:
-                    a("v_mul_f32 v%d, s%d, v%d" % (o + l, S_U, FA + 4 * l))
+                    a("v_mul_f32 v%d, s%d, v%d" % (o + l, SET[0] + 4 * l, FA + 4 * l))
                 else:
-                    a("v_fmac_f32 v%d, s%d, v%d" % (o + l, S_U, FA + 4 * l + i))
+                    a("v_fmac_f32 v%d, s%d, v%d" % (o + l, SET[0] + 4 * l + i, FA + 4 * l + i))
         a("v_add_u32 v%d, s%d, v%d" % (t, S_T, l4))
         a("s_bfm_b64 exec, 49, 0")                                               # lanes 0..48
         for l in range(LEVELS):

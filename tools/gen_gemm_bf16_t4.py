@@ -17,6 +17,10 @@ Registers (all clobbered by the statement):
     s[40:59]     buffer descriptors A, W, R, C, bias;  s[60:75] loop state and row offsets
 """
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import asm_guards as G  # noqa: E402  (wait-state guards: the numbers live in tools/asm_hazard_lint.py)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "gemm_bf16_t4_asm.inc"))
@@ -235,8 +239,7 @@ def body(stream_bf16=False):
     e.lgkm, e.vm = [], []
     for j in range(8):
         e.vmem("buffer_load_dwordx4 v[%d:%d], %%[voB], s[%d:%d], 0 offen offset:%d" % (4 * j, 4 * j + 3, RS_B, RS_B + 3, 64 * j), ("bias", j))
-    e.raw("s_nop 15")
-    e.raw("s_nop 15")                                         # MFMA results -> v_accvgpr_read
+    G.emit_mfma_result_guard(e.raw, "v_mfma_f32_16x16x32_bf16")    # MFMA results -> v_accvgpr_read
     for j in range(8):
         e.need_vm({("bias", j)})
         for i in range(4):

@@ -17,6 +17,10 @@ Registers (all clobbered by the statement):
     s[40:55]     buffer descriptors A, W, C, bias;  s[56:61] loop state;  s[62:81] GELU constants;  s[82:89] row-block offsets of C
 """
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import asm_guards as G  # noqa: E402  (wait-state guards: the numbers live in tools/asm_hazard_lint.py)
 import struct
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -215,8 +219,7 @@ def epilogue(e):
     Entered with a full wait (the next tile's first fragments / blocks have landed under the K loop's tail); left with its
     last stores in flight -- they retire under the next tile's K loop."""
     e.drain()
-    e.raw("s_nop 15")
-    e.raw("s_nop 15")
+    G.emit_mfma_result_guard(e.raw, "v_mfma_f32_16x16x32_bf16")    # the tile's last MFMAs -> v_accvgpr_read
     BIAS = E                                                 # 8 registers
     # (X, T, Q, O) x 2.  The O registers (what a store reads, some time after it issues) sit OUTSIDE the fragment area: the
     # next tile's K loop starts while this tile's last stores are still reading their data / on their way to memory

@@ -34,6 +34,10 @@ Registers (all clobbered):
     s[84:95] loop state
 """
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import asm_guards as G  # noqa: E402  (wait-state guards: the numbers live in tools/asm_hazard_lint.py)
 import struct
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -350,8 +354,7 @@ def residual_loads(sh):
 def epilogue_u(e, sh, epi):
     """the wave's 64 x 64 block: + bias, GELU or + residual, 16-byte stores; left with its last stores in flight"""
     e.need_loads()
-    e.raw("s_nop 15")
-    e.raw("s_nop 15")
+    G.emit_mfma_result_guard(e.raw, "v_mfma_f32_32x32x2_f32")      # the tile's last MFMAs -> v_accvgpr_read
     EP, BIAS = sh.ep, sh.bias
     sets = [(EP, EP + 8, EP + 16), (EP + 24, EP + 32, EP + 40)] if epi == "gelu" else [(EP, 0, 0), (EP + 8, 0, 0)]
     k = 0
@@ -393,8 +396,7 @@ def epilogue_d(e, sh):
     """the four partial 64 x 64 tiles -> LDS -> every wave sums ONE 32 x 32 block in the order ((0 + 1) + 2) + 3, + bias + residual"""
     e.need_loads()
     e.barrier()                                              # every wave is done with the stage buffers
-    e.raw("s_nop 15")
-    e.raw("s_nop 15")
+    G.emit_mfma_result_guard(e.raw, "v_mfma_f32_32x32x2_f32")      # the tile's last MFMAs -> v_accvgpr_read
     for b in range(4):                                       # MFMA block b = i + 2 j, quad q -> red[ks][4 b + q][lane] (16 B each)
         for q in range(4):
             a = 16 * b + 4 * q
@@ -555,6 +557,7 @@ def body_e():
 
     def dma(buf, k):
         e.raw("s_add_u32 m0, %%[ldsw], %d" % (buf * EBUF + 8 * k * 128))
+        G.emit_m0_guard(e.raw)                               # SALU writes M0 -> the LDS-DMA load reads it: one wait state
         e.vmem("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (sh.vo + k, RS_A, RS_A + 3, S_SOA), ("st", buf, k))
 
     def advance():

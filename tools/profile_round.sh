@@ -22,4 +22,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pr_w_head -o p -- $HEAD > /dev
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pr_f_c4 -o p -- $C4 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pr_w_c4 -o p -- $C4 > /dev/null 2>&1
 python $R/tools/pmc_to_json.py $R/gpurun_out/prof_${TAG}_pmc_traffic.json /tmp/pr_f_head /tmp/pr_w_head /tmp/pr_f_c4 /tmp/pr_w_c4
+# BASELINE configs[2] leg (bf16, B = 8 per GPU): its own file -- several kernel names also occur in the headline command
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pr_f_c3 -o p -- $C3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pr_w_c3 -o p -- $C3 > /dev/null 2>&1
+python $R/tools/pmc_to_json.py $R/gpurun_out/prof_${TAG}_pmc_traffic_config3.json /tmp/pr_f_c3 /tmp/pr_w_c3
 head -12 $R/gpurun_out/prof_${TAG}_config4_kernel_stats.txt
