@@ -862,41 +862,52 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
             // neighbours outside the map count as zero (:324).  The last level's blend runs in the NEXT item's first step (its records are
             // in the other record buffer, its windows in the buffer level 0 does not use)
 #define GM_BLEND(l_, recb_, cnt_)                                                                                               \
-            {   /* a thread = one (particle, iy) row of 7 taps: the two window rows it needs are read once (16 values instead of  \
-                   4 per tap), the in-map tests are per column / row, the weights per thread; 7 stores of 7-float runs per particle */ \
+            {   /* a thread = one (particle, ix) column of 7 taps k = ix * 7 + iy = 28 contiguous bytes of the mixer row (round 6: a 16-    \
+                   and a 12-byte store instead of seven 4-byte ones 28 bytes apart); the two window columns it needs are read once (16 \
+                   values instead of 4 per tap); windows wholly inside the map -- all of a wave's, as a rule -- skip the per-pixel tests */ \
                 const int Wl = GM_SEL4(l_, W0, W1, W2, W3), Hl = GM_SEL4(l_, H0, H1, H2, H3);                                   \
                 const float* winf = reinterpret_cast<const float*>(smem + GM_WIN_OFF + ((l_) & 1) * GM_WIN_BYTES);              \
                 for (int idx = tid; idx < ((GM_ABLATE & 8) ? 0 : (cnt_) * 7); idx += GM_PTHREADS) {                            \
-                    const int j = idx / 7, tj = idx - j * 7;                                                                    \
+                    const int j = idx / 7, ti = idx - j * 7;                                                                    \
                     const int4 r = (recb_)[j * PIPS_LEVELS + (l_)];                                                             \
-                    const float* wv = winf + j * GM_WIN_ROW + tj * 8;                                                           \
-                    float z0[8], z1[8];                                                                                         \
-                    _Pragma("unroll") for (int c = 0; c < 8; ++c) { z0[c] = wv[c]; z1[c] = wv[8 + c]; }                         \
-                    const int px = (int)(short)(r.x & 0xffff), py = (r.x >> 16) + tj;     /* map pixel of the row's first north-west neighbour */ \
-                    const bool y0in = (unsigned)py < (unsigned)Hl, y1in = (unsigned)(py + 1) < (unsigned)Hl;                    \
-                    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                             \
-                        const bool xin = (unsigned)(px + c) < (unsigned)Wl;                                                     \
-                        z0[c] = (xin && y0in) ? z0[c] : 0.f;                                                                    \
-                        z1[c] = (xin && y1in) ? z1[c] : 0.f;                                                                    \
+                    const float* wv = winf + j * GM_WIN_ROW + ti;                                                               \
+                    float za[8], zb[8];                                       /* window columns ti, ti + 1, rows 0..7 */         \
+                    _Pragma("unroll") for (int c = 0; c < 8; ++c) { za[c] = wv[8 * c]; zb[c] = wv[8 * c + 1]; }                 \
+                    const int px = (int)(short)(r.x & 0xffff) + ti, py = (r.x >> 16);     /* map pixel of the column's first north-west neighbour */ \
+                    if (__builtin_amdgcn_ballot_w64(!(px >= 0 && px + 1 < Wl && py >= 0 && py + 7 < Hl)) != 0ull) {              \
+                        const bool x0in = (unsigned)px < (unsigned)Wl, x1in = (unsigned)(px + 1) < (unsigned)Wl;                \
+                        _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                         \
+                            const bool yin = (unsigned)(py + c) < (unsigned)Hl;                                                 \
+                            za[c] = (yin && x0in) ? za[c] : 0.f;                                                                \
+                            zb[c] = (yin && x1in) ? zb[c] : 0.f;                                                                \
+                        }                                                                                                       \
                     }                                                                                                           \
                     const float wx = __int_as_float(r.y), wy = __int_as_float(r.z);                                             \
                     const float e = 1.0f - wx, so = 1.0f - wy;                                                                  \
                     const float k128 = 0.08838834764831845f;                  /* the 1/sqrt(128) of :397 rides on the weights */ \
                     const float w0 = __fmul_rn(__fmul_rn(so, e), k128), w1 = __fmul_rn(__fmul_rn(so, wx), k128),                \
                                 w2 = __fmul_rn(__fmul_rn(wy, e), k128), w3 = __fmul_rn(__fmul_rn(wy, wx), k128);                \
-                    float* xo = X + ((size_t)r.w * PIPS_KIN_PAD + C + GM_TAPS * (l_) + tj);                                     \
-                    _Pragma("unroll") for (int ti = 0; ti < 7; ++ti) {                                                          \
-                        float o = __fmul_rn(w0, z0[ti]);                                                                        \
-                        o = fmaf(w1, z0[ti + 1], o); o = fmaf(w2, z1[ti], o); o = fmaf(w3, z1[ti + 1], o);                      \
-                        if (!(GM_ABLATE & 4)) xo[ti * 7] = o;                                                                   \
+                    float o_[7];                                                                                                \
+                    _Pragma("unroll") for (int tj = 0; tj < 7; ++tj) {                                                          \
+                        float o = __fmul_rn(w0, za[tj]);                                                                        \
+                        o = fmaf(w1, zb[tj], o); o = fmaf(w2, za[tj + 1], o); o = fmaf(w3, zb[tj + 1], o);                      \
+                        o_[tj] = o;                                                                                             \
+                    }                                                                                                           \
+                    if (!(GM_ABLATE & 4)) {                                   /* (the runs are 4-byte aligned) */                 \
+                        typedef float f4u_ __attribute__((ext_vector_type(4), aligned(4)));                                     \
+                        typedef float f3u_ __attribute__((ext_vector_type(3), aligned(4)));                                     \
+                        float* xo = X + ((size_t)r.w * PIPS_KIN_PAD + C + GM_TAPS * (l_) + 7 * ti);                             \
+                        *reinterpret_cast<f4u_*>(xo) = (f4u_){o_[0], o_[1], o_[2], o_[3]};                                      \
+                        *reinterpret_cast<f3u_*>(xo + 4) = (f3u_){o_[4], o_[5], o_[6]};                                         \
                     }                                                                                                           \
                 }                                                                                                               \
             }
             // the window scatter of one (pixel block, particle block) product: the 16 values under execution masks = (x in the window) & (y in
             // the window): four + four ballots, then per value one scalar AND into exec and the write -- one assembly statement, so that
             // nothing else runs under a partial mask (a compare + select + write per value took twice the instructions).  The values
-            // may come straight out of the last MFMA: an MFMA result read by a DS instruction needs up to 19 wait states, which the
-            // compiler inserts for its own instructions but not in front of an assembly statement
+            // may come straight out of the last MFMA: an MFMA result read by a DS instruction needs 12 wait states (v_mfma_f32_32x32x16_bf16,
+            // tools/asm_hazard_lint.py), which the compiler inserts for its own instructions but not in front of an assembly statement:
+            // s_nop 10 = 11, + s_mov + s_and (rounds 5: s_nop 15 + s_nop 7)
 #define GM_SCATTER(acc, l_, dx0, dy0)                                                                                           \
             {                                                                                                                   \
                 const unsigned wbo = lds0 + (unsigned)(GM_WIN_OFF + ((l_) & 1) * GM_WIN_BYTES + jme * (GM_WIN_ROW * 4) + (dy0) * 32 + (dx0) * 4); \
@@ -905,7 +916,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
                                          my0 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 0) < 8u), my1 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 1) < 8u), \
                                          my2 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 2) < 8u), my3 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 3) < 8u); \
                 unsigned long long sv;                                                                                          \
-                asm volatile("s_nop 15\n\ts_nop 7\n\ts_mov_b64 %0, exec\n\t"                                                    \
+                asm volatile("s_nop 10\n\ts_mov_b64 %0, exec\n\t"                                                              \
                 "s_and_b64 exec, %1, %5\n\tds_write_b32 %9, %10 offset:0\n\t"                                                   \
                 "s_and_b64 exec, %2, %5\n\tds_write_b32 %9, %11 offset:4\n\t"                                                   \
                 "s_and_b64 exec, %3, %5\n\tds_write_b32 %9, %12 offset:8\n\t"                                                   \
@@ -979,13 +990,18 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                             const char* ap = smem + ((g + s + 1) & 1) * GM_STAGE + bl * GM_BLK_BYTES + l31 * 256;
+                            // all eight fragment reads in flight, THEN the MFMAs (round 6: left alone hipcc reads one fragment at a time into one
+                            // register set, each MFMA behind its own LDS round trip)
+                            uint4 afr[8];
 #pragma unroll
-                            for (int ks = 0; ks < 8; ++ks) {
-                                const uint4 a = (GM_ABLATE & 128) ? make_uint4((unsigned)ks, (unsigned)lane, 0u, 0u)      // (timing probe: no fragment reads)
-                                                                  : *reinterpret_cast<const uint4*>(ap + (((ks * 2 + half) ^ (l31 & 15)) << 4));
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_gm*>(&a),
+                            for (int ks = 0; ks < 8; ++ks)
+                                afr[ks] = (GM_ABLATE & 128) ? make_uint4((unsigned)ks, (unsigned)lane, 0u, 0u)            // (timing probe: no fragment reads)
+                                                            : *reinterpret_cast<const uint4*>(ap + (((ks * 2 + half) ^ (l31 & 15)) << 4));
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int ks = 0; ks < 8; ++ks)
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_gm*>(&afr[ks]),
                                                                               *reinterpret_cast<const bf16x8_gm*>(&bfr[ks]), acc, 0, 0, 0);
-                            }
 #ifdef GM_TRACE
                             { int d_; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(d_) : "v"(acc[15])); asm volatile("" :: "s"(d_)); }
                             GM_T(41);
@@ -1015,6 +1031,563 @@ __global__ __launch_bounds__(GM_THREADS) void gather_mfma_kernel(const unsigned 
 #undef GM_SEL4
 #undef geo_of
 }
+
+#ifndef PIPS_GM_V_DEFAULT
+#define PIPS_GM_V_DEFAULT 1     // the bf16 mode's kernel: 1 gather_mfma_kernel, 2 gather_mfma2_kernel (round 6's re-cut: variant builds, A/B and bit comparison)
+#endif
+#if PIPS_GM_V_DEFAULT == 2 || defined(PIPS_TUNING)
+// ---------------------------------------------------------------------------- gather_mfma2_kernel (round 6; variant builds only)
+// NOT in the product library (PIPS_GM_V_DEFAULT == 2 or -DPIPS_TUNING builds it): bit-identical to gather_mfma_kernel and 3-4 % SLOWER on the
+// same box (149-153 against 143-149 us, profiles/r6_probe_gather_mfma2.txt) -- kept with its probes because they name what the two share.
+// The same work items, products, window scatter and blend arithmetic as gather_mfma_kernel above, re-cut along what its trace showed
+// (profiles/r5_probe_gather_mfma_trace_final.txt: of the ~3.3 k clocks of a step the MFMAs are 0.3 k; the loaders spend 2 k on address
+// arithmetic, eight register loads and eight ds_write_b128 per thread, the product waves 1.4 k on the blend every third step and ~1.5 k
+// on per-step geometry):
+//   * the map chunks and the records go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no register round trip, no
+//     ds_write, no staging registers; a 1 KiB piece = 4 consecutive pixels of 256 B, the XOR swizzle of the 256-byte rows applied on
+//     the GLOBAL side (the lane that fills LDS position (row, p) fetches chunk p ^ (row & 15));
+//   * THREE stage buffers: at the top of step q the two request waves ask for the chunk of step q + 2 (16 pieces each: two pixel
+//     blocks per wave) and then wait for everything older, i.e. the chunk of step q + 1, requested a whole step ago.  With two buffers the request could only go
+//     out once the step before had released its buffer and had to land within ONE step: the first cut ran at the loaded memory
+//     latency, 107 us for the requests alone (profiles/r6_probe_gather_mfma2_ablation.txt);
+//   * the 2 x 2 blend of a finished level has its own two waves (g2_blend_role): it runs beside the NEXT level's products, one slice
+//     per step, off everybody's critical path; a thread = one (particle, ix) column of 7 taps, which are 28 contiguous bytes of the
+//     mixer row (16 + 12-byte stores instead of seven 4-byte ones);
+//   * the product waves take their particle's bf16 feature row (the B operand) straight from memory into registers, behind the previous
+//     item's last products: no feature buffer in LDS (that is where the third stage buffer fits) and no step of its own (13 steps per
+//     interior item instead of 14);
+//   * per-step geometry comes from the batch head's table (level, block coordinates), the per-level anchors are read once per item.
+// Arithmetic and summation order are gather_mfma_kernel's: results are bit-identical (tools/gather_dump.py, tests/test_kernels_gpu.py).
+constexpr int G2_NSTAGE = 3;
+constexpr int G2_WIN_OFF = G2_NSTAGE * GM_STAGE + 128;               // (the scatter's per-lane base may lie up to 108 bytes below a particle's window)
+constexpr int G2_REC_OFF = G2_WIN_OFF + 2 * GM_WIN_BYTES;
+constexpr int G2_ENT_OFF = G2_REC_OFF + 2 * GMAX * PIPS_LEVELS * 16; // per item 4 x int4: {first, count, f, nchunks}, {cs1, cs2, cs3, -}, {P0..P3}, {base0..base3}
+constexpr int G2_CT_OFF = G2_ENT_OFF + GM_ENTS * 64;                 // per item and chunk uint2 {level | nvalid << 2, (bxi | byi << 4) << 8 b}
+constexpr int G2_LDS = G2_CT_OFF + GM_ENTS * GM_CHUNKS_MAX * 8;
+static_assert(GMAX * 7 <= GM_PTHREADS, "the blend: one (particle, column) per product thread");
+static_assert(G2_LDS <= 160 * 1024 && G2_WIN_OFF % 16 == 0 && G2_REC_OFF % 16 == 0 && G2_ENT_OFF % 16 == 0, "LDS layout");
+
+#ifndef G2_ROLE
+#define G2_ROLE 0        // compile-time probe of one role's register use: 1 aux only, 2 product only
+#endif
+#ifndef G2_ABLATE
+#define G2_ABLATE 0      // timing probes (wrong results): 1 no DMA, 2 no products, 4 no tap stores, 8 no blend, 16 no window scatter, 32 no fragment reads
+#endif
+
+#ifdef G2_TRACE          // tuning builds (tools/g2_trace.py): clocks per phase of a step, summed over the launch, for the product wave 0 and the aux wave 12 of
+                         // blocks 0 and 1 -- accumulated in registers, written once at the end (no store inside the pipeline)
+__device__ unsigned long long* g_g2_trace;
+#define G2_TDECL unsigned long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = __builtin_amdgcn_s_memtime(); int tsteps_ = 0;
+#define G2_T(i_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc_[i_] += t_ - tprev_; tprev_ = t_; }
+#define G2_TSTEP ++tsteps_;
+#define G2_TRACE_SYNC(acc_) { int d_; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(d_) : "v"(acc_[15])); asm volatile("" :: "s"(d_)); }
+#define G2_TDUMP(role_) if (g_g2_trace && blockIdx.x < 2 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == GM_PWAVES)) { \
+        unsigned long long* o_ = g_g2_trace + ((size_t)blockIdx.x * 2 + (role_)) * 16;                                          \
+        for (int i_ = 0; i_ < 8; ++i_) o_[i_] = tacc_[i_];                                                                      \
+        o_[8] = (unsigned long long)tsteps_; }
+#else
+#define G2_TDECL
+#define G2_T(i_)
+#define G2_TSTEP
+#define G2_TRACE_SYNC(acc_)
+#define G2_TDUMP(role_)
+#endif
+
+// lane i of the batch head: item i's geometry and chunk table
+__device__ __forceinline__ void g2_geo_store(int4* geo, uint2* ct, int4 ev, int tiles_x, int W0, int W1, int W2, int W3, int H0, int H1,
+                                             int H2, int H3, unsigned ob0, unsigned ob1, unsigned ob2, unsigned ob3) {
+    const int ty = ev.x / tiles_x, tx = ev.x - ty * tiles_x;
+    int P0, P1, P2, P3, Q0, Q1, Q2, Q3;
+    gm_level_geom(0, tx, ty, W0, H0, P0, Q0);
+    gm_level_geom(1, tx, ty, W1, H1, P1, Q1);
+    gm_level_geom(2, tx, ty, W2, H2, P2, Q2);
+    gm_level_geom(3, tx, ty, W3, H3, P3, Q3);
+    const int cs1 = (((unsigned)Q0 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    const int cs2 = cs1 + (((unsigned)Q1 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    const int cs3 = cs2 + (((unsigned)Q2 >> 24) + GM_CHUNK - 1) / GM_CHUNK;
+    const int nchunks = min(cs3 + (int)((((unsigned)Q3 >> 24) + GM_CHUNK - 1) / GM_CHUNK), GM_CHUNKS_MAX);
+    geo[0] = make_int4(ev.y, ev.z, ev.w, nchunks);
+    geo[1] = make_int4(cs1, cs2, cs3, 0);
+    geo[2] = make_int4(P0, P1, P2, P3);
+    if (ev.w < 0) return;
+    // byte offset (in the bf16 mirror) of the region's corner pixel per level
+#define G2_BASE(P_, W_, H_, ob_) ((ob_) + (unsigned)((ev.w * (H_) + (int)((unsigned)(P_) >> 16)) * (W_) + ((P_) & 0xffff)) * (unsigned)(C * 2))
+    geo[3] = make_int4((int)G2_BASE(P0, W0, H0, ob0), (int)G2_BASE(P1, W1, H1, ob1), (int)G2_BASE(P2, W2, H2, ob2), (int)G2_BASE(P3, W3, H3, ob3));
+#undef G2_BASE
+    int ci = 0;
+#pragma unroll
+    for (int l = 0; l < PIPS_LEVELS; ++l) {
+        const int Q = l == 0 ? Q0 : (l == 1 ? Q1 : (l == 2 ? Q2 : Q3));
+        const int nbx = (Q >> 16) & 0xff, nblk = (unsigned)Q >> 24;
+        for (int c0 = 0; c0 < nblk && ci < GM_CHUNKS_MAX; c0 += GM_CHUNK, ++ci) {
+            unsigned bxy = 0;
+#pragma unroll
+            for (int b = 0; b < GM_CHUNK; ++b) {
+                const int gb = min(c0 + b, nblk - 1), byi = gb / nbx, bxi = gb - byi * nbx;     // (blocks past the level's last repeat it: never used)
+                bxy |= (unsigned)(bxi | (byi << 4)) << (8 * b);
+            }
+            ct[ci] = make_uint2((unsigned)l | ((unsigned)min(nblk - c0, GM_CHUNK) << 2), bxy);
+        }
+    }
+}
+
+// the two roles are separate functions: each gets its own register allocation (one body with both roles keeps either role's values alive
+// through the other: 10 spilled vector registers and 142 spilled scalars in the first cut)
+#define G2_SEL4(l_, a0, a1, a2, a3) ((l_) == 0 ? (a0) : ((l_) == 1 ? (a1) : ((l_) == 2 ? (a2) : (a3))))
+#define G2_RFL(x_) __builtin_amdgcn_readfirstlane((int)(x_))
+    // item `it_` of the batch: f < 0 or it_ >= GM_ENTS: no item
+#define G2_ITEM(it_, first_, count_, f_, nch_)                                                                                  \
+    { const int4 a_ = ent[4 * min((it_), GM_ENTS - 1)];                                                                         \
+      first_ = G2_RFL(a_.x); count_ = G2_RFL(a_.y); f_ = (it_) < GM_ENTS ? G2_RFL(a_.z) : -1; nch_ = G2_RFL(a_.w); }
+struct G2Args {
+    const unsigned short* mirror; const uint4* featb; const int4* order; const int4* items; const int* nitems; float* X;
+    int N, max_items, F, tiles_x;
+    int W0, W1, W2, W3, H0, H1, H2, H3;
+    unsigned ob0, ob1, ob2, ob3;
+};
+
+__device__ __attribute__((noinline)) void g2_aux_role(const G2Args& A) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, J = gridDim.x >> 3, jb = blockIdx.x >> 3;
+    int4* ent = reinterpret_cast<int4*>(smem + G2_ENT_OFF);
+    uint2* ctab = reinterpret_cast<uint2*>(smem + G2_CT_OFF);
+    // (the argument block lives in the kernel's private memory: its fields arrive in vector registers -- make them scalars again)
+    const int N = G2_RFL(A.N), F = G2_RFL(A.F), W0 = G2_RFL(A.W0), W1 = G2_RFL(A.W1), W2 = G2_RFL(A.W2), W3 = G2_RFL(A.W3),
+              H0 = G2_RFL(A.H0), H1 = G2_RFL(A.H1), H2 = G2_RFL(A.H2), H3 = G2_RFL(A.H3), max_items = G2_RFL(A.max_items), tiles_x = G2_RFL(A.tiles_x);
+    const unsigned ob0 = (unsigned)G2_RFL(A.ob0), ob1 = (unsigned)G2_RFL(A.ob1), ob2 = (unsigned)G2_RFL(A.ob2), ob3 = (unsigned)G2_RFL(A.ob3);
+#define G2_RFLP(T_, p_) reinterpret_cast<T_>((unsigned long long)(unsigned)G2_RFL((unsigned)(unsigned long long)reinterpret_cast<uintptr_t>(p_)) | \
+                                           ((unsigned long long)(unsigned)G2_RFL((unsigned)((unsigned long long)reinterpret_cast<uintptr_t>(p_) >> 32)) << 32))
+    const int4* __restrict__ items = G2_RFLP(const int4*, A.items);
+    const int* __restrict__ nitems = G2_RFLP(const int*, A.nitems);
+    const int aw = wave - GM_PWAVES;                                     // request wave 0..1: the chunk's blocks 2 aw, 2 aw + 1
+    // the request stream is ~30 instructions per step and everything else waits for what it fetches: it goes first.  (The aux waves are
+    // the youngest of their SIMDs: at equal priority the three product waves beside them won the issue arbitration and a step's eight
+    // requests took ~1.9 k clocks instead of ~0.8 k, tools/g2_trace.py)
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+    // raw buffer descriptors as plain SGPR values (wave-uniform by construction: the requests below are assembly statements)
+    u4v rs_map, rs_rec;
+    {
+        const unsigned long long pm = (unsigned long long)reinterpret_cast<uintptr_t>(A.mirror), pr = (unsigned long long)reinterpret_cast<uintptr_t>(A.order);
+        rs_map = (u4v){(unsigned)G2_RFL((unsigned)pm), (unsigned)G2_RFL((unsigned)(pm >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
+        rs_rec = (u4v){(unsigned)G2_RFL((unsigned)pr), (unsigned)G2_RFL((unsigned)(pr >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
+    }
+    // per-lane source offset inside a 1 KiB piece whose first row is 4 k (mod 16): row (lane >> 4), chunk (lane & 15) ^ row
+    unsigned vo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vo[k] = (unsigned)((lane >> 4) * 256 + ((((lane & 15) ^ (4 * k + (lane >> 4))) & 15) << 4));
+    const unsigned vlin = (unsigned)lane * 16u;
+    const unsigned pitch0 = (unsigned)W0 * (C * 2), pitch1 = (unsigned)W1 * (C * 2), pitch2 = (unsigned)W2 * (C * 2), pitch3 = (unsigned)W3 * (C * 2);
+    // LDS-DMA requests are ASSEMBLY statements: behind the builtin the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read
+    // that follows (it cannot tell the blend's window reads from the stage being filled) -- which makes the pipeline one request deep
+    // -- and a waterfall loop around every request whose descriptor it cannot prove uniform.  M0 (the LDS address of a piece) is saved
+    // and restored; `s_nop 4`: an SGPR fresh from v_readfirstlane needs 5 wait states before a vector-memory instruction reads it;
+    // one SALU instruction sits between every write of M0 and the load that uses it (tools/asm_hazard_lint.py checks the built code).
+    // 8 pieces of one pixel block: image rows 0..3 (pitch pt_) x pixel quads 0..1 (1 KiB apart) -> 8 KiB at LDS address lb_
+#define G2_DMA8(lb_, so_, pt_)                                                                                                  \
+    if (!(G2_ABLATE & 1)) {                                                                                                     \
+        unsigned t0_, t1_, ms_;                                                                                                 \
+        asm volatile("s_nop 4\n\ts_mov_b32 %[ms], m0\n\t"                                                                      \
+                     "s_mov_b32 m0, %[lb]\n\ts_add_u32 %[t1], %[so], 0x400\n\tbuffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"   \
+                     "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t0], %[so], %[pt]\n\tbuffer_load_dwordx4 %[v1], %[rs], %[t1] offen lds\n\t" \
+                     "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t1], %[t0], 0x400\n\tbuffer_load_dwordx4 %[v2], %[rs], %[t0] offen lds\n\t" \
+                     "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t0], %[t0], %[pt]\n\tbuffer_load_dwordx4 %[v3], %[rs], %[t1] offen lds\n\t" \
+                     "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t1], %[t0], 0x400\n\tbuffer_load_dwordx4 %[v0], %[rs], %[t0] offen lds\n\t" \
+                     "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t0], %[t0], %[pt]\n\tbuffer_load_dwordx4 %[v1], %[rs], %[t1] offen lds\n\t" \
+                     "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[t1], %[t0], 0x400\n\tbuffer_load_dwordx4 %[v2], %[rs], %[t0] offen lds\n\t" \
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v3], %[rs], %[t1] offen lds\n\t"                \
+                     "s_mov_b32 m0, %[ms]"                                                                                      \
+                     : [t0] "=&s"(t0_), [t1] "=&s"(t1_), [ms] "=&s"(ms_)                                                        \
+                     : [rs] "s"(rs_map), [lb] "s"(G2_RFL(lb_)), [so] "s"(G2_RFL(so_)), [pt] "s"(G2_RFL(pt_)), [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]) \
+                     : "memory", "scc");                                                                                        \
+    }
+    // one plain 1 KiB piece (records)
+#define G2_DMA1(lb_, so_)                                                                                                       \
+    if (!(G2_ABLATE & 1)) {                                                                                                     \
+        unsigned ms_;                                                                                                           \
+        asm volatile("s_nop 4\n\ts_mov_b32 %[ms], m0\n\ts_mov_b32 m0, %[lb]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[rs], %[so] offen lds\n\t" \
+                     "s_mov_b32 m0, %[ms]"                                                                                      \
+                     : [ms] "=&s"(ms_) : [rs] "s"(rs_rec), [lb] "s"(G2_RFL(lb_)), [so] "s"(G2_RFL(so_)), [v] "v"(vlin) : "memory");             \
+    }
+    // chunk s_ of item it_, block `aw` -> stage st_
+#define G2_REQUEST_CHUNK(it_, s_, st_)                                                                                          \
+    {                                                                                                                           \
+        const uint2 m_ = ctab[(it_) * GM_CHUNKS_MAX + (s_)];                                                                    \
+        const int4 bs_ = ent[4 * (it_) + 3];                                                                                    \
+        const int l_ = G2_RFL(m_.x) & 3, bxy_ = (G2_RFL(m_.y) >> (16 * aw)) & 0xffff;                                           \
+        const unsigned pt_ = G2_SEL4(l_, pitch0, pitch1, pitch2, pitch3);                                                       \
+        const unsigned bse_ = (unsigned)G2_RFL(G2_SEL4(l_, bs_.x, bs_.y, bs_.z, bs_.w));                                        \
+        const unsigned soa_ = bse_ + (unsigned)((bxy_ >> 4) & 15) * 4u * pt_ + (unsigned)(bxy_ & 15) * (8u * C * 2);            \
+        const unsigned sob_ = bse_ + (unsigned)((bxy_ >> 12) & 15) * 4u * pt_ + (unsigned)((bxy_ >> 8) & 15) * (8u * C * 2);    \
+        const unsigned lb_ = lds0 + (unsigned)((st_) * GM_STAGE + 2 * aw * GM_BLK_BYTES);                                       \
+        G2_DMA8(lb_, soa_, pt_)                                                                                                 \
+        G2_DMA8(lb_ + (unsigned)GM_BLK_BYTES, sob_, pt_)                                                                        \
+    }
+    // an item's records (6 plain pieces: three per wave) -> REC[rb_]
+#define G2_REQUEST_RECORDS(f_, first_, rb_)                                                                                     \
+    {                                                                                                                           \
+        const unsigned slot_ = (unsigned)((f_) * N + (first_));                                                                 \
+        const unsigned lr_ = lds0 + (unsigned)(G2_REC_OFF + (rb_) * (GMAX * PIPS_LEVELS * 16) + aw * 3072);                     \
+        const unsigned sr_ = slot_ * (PIPS_LEVELS * 16) + (unsigned)aw * 3072u;                                                 \
+        G2_DMA1(lr_, sr_)                                                                                                       \
+        G2_DMA1(lr_ + 1024u, sr_ + 1024u)                                                                                       \
+        G2_DMA1(lr_ + 2048u, sr_ + 2048u)                                                                                       \
+    }
+    G2_TDECL
+    for (int base = 0;; base += GM_ENTS) {
+        // ---- batch head: this block's next (up to) GM_ENTS work items (gather_mfma_kernel's order), lane-parallel in the first aux wave
+        lds_barrier();
+        if (aw == 0 && lane < GM_ENTS) {
+            int gi = jb + (base + lane) * J, fr = xcd;
+            int4 e = make_int4(0, 0, 0, -1);
+            for (; fr < F; fr += 8) {
+                const int n = nitems[fr];
+                if (gi < n) break;
+                gi -= n;
+            }
+            if (fr < F) { e = items[(size_t)fr * max_items + gi]; e.w = fr; }
+            g2_geo_store(ent + 4 * lane, ctab + GM_CHUNKS_MAX * lane, e, tiles_x, W0, W1, W2, W3, H0, H1, H2, H3, ob0, ob1, ob2, ob3);
+        }
+        __syncthreads();
+        bool more = true;
+        int first0, count0, f0, nch0;
+        G2_ITEM(0, first0, count0, f0, nch0)
+        (void)count0;
+        if (f0 < 0) break;
+        // ---- prologue of the batch: the first item's records and first two chunks, exposed
+        G2_REQUEST_RECORDS(f0, first0, 0)
+        G2_REQUEST_CHUNK(0, 0, 0)
+        {
+            int f1, first1, count1, nch1;
+            G2_ITEM(1, first1, count1, f1, nch1)
+            (void)first1; (void)count1; (void)nch1;
+            if (nch0 > 1) G2_REQUEST_CHUNK(0, 1, 1)
+            else if (f1 >= 0) G2_REQUEST_CHUNK(1, 0, 1)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                               // (P)
+        G2_T(6)
+        int st = 0;                                                  // the stage this step consumes (q mod 3)
+        for (int it = 0; it < GM_ENTS; ++it) {
+            int first, count, f, nch, firstn, countn, fn, nchn;
+            G2_ITEM(it, first, count, f, nch)
+            if (f < 0) { more = false; break; }
+            G2_ITEM(it + 1, firstn, countn, fn, nchn)
+            (void)first; (void)countn; (void)count;
+            const int cs1 = G2_RFL(ent[4 * it + 1].x);
+            for (int s = 0; s < nch; ++s) {
+                // step q: [records of the next item, once] [REQUEST chunk q + 2 -- its stage was released by the barrier of step q - 1]
+                // [wait: everything older than that request, i.e. chunk q + 1, requested a step ago: two steps of latency cover] [barrier]
+                G2_T(0)
+                // (the next item's records: once level 0's steps are over -- the blend waves read the PREVIOUS item's records, in the same
+                //  buffer, through all of them)
+                if (s == cs1 && fn >= 0) G2_REQUEST_RECORDS(fn, firstn, (it + 1) & 1)
+                bool requested = false;
+                {
+                    const int st2 = st == 0 ? 2 : st - 1;            // (q + 2) mod 3
+                    if (s + 2 < nch) { G2_REQUEST_CHUNK(it, s + 2, st2) requested = true; }
+                    else if (fn >= 0 && s + 2 - nch < nchn) { G2_REQUEST_CHUNK(it + 1, s + 2 - nch, st2) requested = true; }
+                }
+                G2_T(2)
+                if (requested && !(G2_ABLATE & 1)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                G2_T(4)
+                lds_barrier();
+                G2_T(5)
+                G2_TSTEP
+                st = st == 2 ? 0 : st + 1;
+            }
+            if (fn < 0) { more = it + 1 >= GM_ENTS; break; }
+        }
+        if (!more) break;
+    }
+    G2_TDUMP(1)
+#undef G2_DMA8
+#undef G2_DMA1
+#undef G2_RFLP
+#undef G2_REQUEST_CHUNK
+#undef G2_REQUEST_RECORDS
+}
+
+// The two blend waves: the 2 x 2 blend of a finished level's 8 x 8 correlations to the 49 taps (k = ix * 7 + iy, transposed, :379-381) runs
+// beside the products of the NEXT level, in slices -- one per step of that level (it reads the window buffer of the other parity; the
+// last level's blend runs beside the next item's level 0).  These waves issue nothing but LDS reads and tap stores, so nobody waits for
+// their stores: in the product waves the blend sat on the critical path of every third step (30 of 145 us), in the request waves its
+// stores sat in front of every `s_waitcnt vmcnt`.
+__device__ __attribute__((noinline)) void g2_blend_role(const G2Args& A) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int bt = threadIdx.x - (GM_PWAVES + 2) * 64;                    // 0..127
+    int4* rec = reinterpret_cast<int4*>(smem + G2_REC_OFF);
+    int4* ent = reinterpret_cast<int4*>(smem + G2_ENT_OFF);
+    const int W0 = G2_RFL(A.W0), W1 = G2_RFL(A.W1), W2 = G2_RFL(A.W2), W3 = G2_RFL(A.W3),
+              H0 = G2_RFL(A.H0), H1 = G2_RFL(A.H1), H2 = G2_RFL(A.H2), H3 = G2_RFL(A.H3);
+#define G2_RFLP(T_, p_) reinterpret_cast<T_>((unsigned long long)(unsigned)G2_RFL((unsigned)(unsigned long long)reinterpret_cast<uintptr_t>(p_)) | \
+                                           ((unsigned long long)(unsigned)G2_RFL((unsigned)((unsigned long long)reinterpret_cast<uintptr_t>(p_) >> 32)) << 32))
+    float* __restrict__ X = G2_RFLP(float*, A.X);
+#undef G2_RFLP
+    // one column: idx_ = particle * 7 + ix of level l_ (records recb_): 7 taps = 28 contiguous bytes of the mixer row (16 + 12-byte stores); the two
+    // window columns it needs are read once; neighbours outside the map count as zero (:324) -- a window pixel outside the map is never written,
+    // the in-map tests replace clearing the buffer; weights, scaling and operation order of gather_tiled_kernel's epilogue
+#define G2_BLEND1(l_, recb_, idx_)                                                                                              \
+    {                                                                                                                           \
+        const int Wl = G2_SEL4(l_, W0, W1, W2, W3), Hl = G2_SEL4(l_, H0, H1, H2, H3);                                           \
+        const float* winf = reinterpret_cast<const float*>(smem + G2_WIN_OFF + ((l_) & 1) * GM_WIN_BYTES);                      \
+        const int j = (idx_) / 7, ti = (idx_) - j * 7;                                                                          \
+        const int4 r = (recb_)[j * PIPS_LEVELS + (l_)];                                                                         \
+        const float* wv = winf + j * GM_WIN_ROW + ti;                                                                           \
+        float za[8], zb[8];                                                   /* window columns ti, ti + 1, rows 0..7 */         \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) { za[c] = wv[8 * c]; zb[c] = wv[8 * c + 1]; }                             \
+        const int px = (int)(short)(r.x & 0xffff) + ti, py = (r.x >> 16);                                                       \
+        /* (windows wholly inside the map -- all of a wave's, as a rule -- skip the per-pixel tests) */                          \
+        if (__builtin_amdgcn_ballot_w64(!(px >= 0 && px + 1 < Wl && py >= 0 && py + 7 < Hl)) != 0ull) {                          \
+            const bool x0in = (unsigned)px < (unsigned)Wl, x1in = (unsigned)(px + 1) < (unsigned)Wl;                            \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                     \
+                const bool yin = (unsigned)(py + c) < (unsigned)Hl;                                                             \
+                za[c] = (yin && x0in) ? za[c] : 0.f;                                                                            \
+                zb[c] = (yin && x1in) ? zb[c] : 0.f;                                                                            \
+            }                                                                                                                   \
+        }                                                                                                                       \
+        const float wx = __int_as_float(r.y), wy = __int_as_float(r.z);                                                         \
+        const float e = 1.0f - wx, so = 1.0f - wy;                                                                              \
+        const float k128 = 0.08838834764831845f;                              /* the 1/sqrt(128) of :397 rides on the weights */ \
+        const float w0 = __fmul_rn(__fmul_rn(so, e), k128), w1 = __fmul_rn(__fmul_rn(so, wx), k128),                            \
+                    w2 = __fmul_rn(__fmul_rn(wy, e), k128), w3 = __fmul_rn(__fmul_rn(wy, wx), k128);                            \
+        float o_[7];                                                                                                            \
+        _Pragma("unroll") for (int tj = 0; tj < 7; ++tj) {                                                                      \
+            float o = __fmul_rn(w0, za[tj]);                                                                                    \
+            o = fmaf(w1, zb[tj], o); o = fmaf(w2, za[tj + 1], o); o = fmaf(w3, zb[tj + 1], o);                                  \
+            o_[tj] = o;                                                                                                         \
+        }                                                                                                                       \
+        if (!(G2_ABLATE & 4)) {                                                                                                 \
+            /* (a GLOBAL pointer: a flat store also counts in lgkmcnt and would stall every LDS wait; the runs are 4-byte aligned) */ \
+            typedef float f4u_ __attribute__((ext_vector_type(4), aligned(4)));                                                 \
+            typedef float f3u_ __attribute__((ext_vector_type(3), aligned(4)));                                                 \
+            __attribute__((address_space(1))) float* xo_ =                                                                      \
+                (__attribute__((address_space(1))) float*)(X + ((size_t)r.w * PIPS_KIN_PAD + C + GM_TAPS * (l_) + 7 * ti));     \
+            *reinterpret_cast<__attribute__((address_space(1))) f4u_*>(xo_) = (f4u_){o_[0], o_[1], o_[2], o_[3]};               \
+            *reinterpret_cast<__attribute__((address_space(1))) f3u_*>(xo_ + 4) = (f3u_){o_[4], o_[5], o_[6]};                  \
+        } else { asm volatile("" :: "v"(o_[0]), "v"(o_[1]), "v"(o_[2]), "v"(o_[3]), "v"(o_[4]), "v"(o_[5]), "v"(o_[6])); }       \
+    }
+    // the steps of level L_ (s0_ <= s < s1_) host the blend of the level before (lb_, records recb_, cnt_ particles): step k takes the
+    // columns [k R, (k + 1) R), R = ceil(columns / steps)
+#define G2_BLEVEL(s0_, s1_, lb_, recb_, cnt_)                                                                                   \
+    {                                                                                                                           \
+        const int ns_ = (s1_) - (s0_), rows_ = (cnt_) * 7, R_ = ns_ > 0 ? (rows_ + ns_ - 1) / ns_ : 0;                          \
+        for (int s = (s0_); s < (s1_); ++s) {                                                                                   \
+            const int r0_ = (s - (s0_)) * R_, r1_ = min(r0_ + R_, rows_);                                                       \
+            if (!(G2_ABLATE & 8))                                                                                               \
+                for (int idx = r0_ + bt; idx < r1_; idx += 128) G2_BLEND1(lb_, recb_, idx)                                      \
+            lds_barrier();                                                                                                      \
+        }                                                                                                                       \
+    }
+    for (;;) {
+        lds_barrier();                                                   // (batch head)
+        __syncthreads();
+        bool more = true;
+        int first0, count0, f0, nch0;
+        G2_ITEM(0, first0, count0, f0, nch0)
+        (void)count0; (void)nch0; (void)first0;
+        if (f0 < 0) break;
+        lds_barrier();                                                   // (P)
+        int countp = 0;
+        for (int it = 0; it < GM_ENTS; ++it) {
+            int first, count, f, nch, firstn, countn, fn, nchn;
+            G2_ITEM(it, first, count, f, nch)
+            if (f < 0) { more = false; break; }
+            G2_ITEM(it + 1, firstn, countn, fn, nchn)
+            (void)first; (void)firstn; (void)countn; (void)nchn;
+            const int4 cs = ent[4 * it + 1];
+            const int cs1 = G2_RFL(cs.x), cs2 = G2_RFL(cs.y), cs3 = G2_RFL(cs.z);
+            const int4* recp = rec + (it & 1) * (GMAX * PIPS_LEVELS);
+            const int4* recq = rec + ((it + 1) & 1) * (GMAX * PIPS_LEVELS);      // the previous item's records
+            G2_BLEVEL(0, cs1, 3, recq, (it > 0 ? countp : 0))
+            G2_BLEVEL(cs1, cs2, 0, recp, count)
+            G2_BLEVEL(cs2, cs3, 1, recp, count)
+            G2_BLEVEL(cs3, nch, 2, recp, count)
+            countp = count;
+            if (fn < 0) {                                                // the batch's last item: its last level, exposed
+                if (!(G2_ABLATE & 8))
+                    for (int idx = bt; idx < count * 7; idx += 128) G2_BLEND1(3, recp, idx)
+                more = it + 1 >= GM_ENTS;
+                break;
+            }
+        }
+        if (!more) break;
+    }
+#undef G2_BLEND1
+#undef G2_BLEVEL
+}
+
+__device__ __attribute__((noinline)) void g2_product_role(const G2Args& A) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = wave % GM_PB, bl = wave / GM_PB;                  // product wave = (particle block, block of the chunk)
+    int4* rec = reinterpret_cast<int4*>(smem + G2_REC_OFF);
+    int4* ent = reinterpret_cast<int4*>(smem + G2_ENT_OFF);
+    uint2* ctab = reinterpret_cast<uint2*>(smem + G2_CT_OFF);
+    const int jme = pb * 32 + l31;                                   // this lane's particle (MFMA column) within the item
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+    // this lane's share of its particle's bf16 feature row: the B operand, channels 16 ks + 8 half ... + 8 (rows past the item's
+    // particles hold the list's next rows -- a slack of GMAX rows lies behind the last frame's)
+#define G2_RFLP(T_, p_) reinterpret_cast<T_>((unsigned long long)(unsigned)G2_RFL((unsigned)(unsigned long long)reinterpret_cast<uintptr_t>(p_)) | \
+                                           ((unsigned long long)(unsigned)G2_RFL((unsigned)((unsigned long long)reinterpret_cast<uintptr_t>(p_) >> 32)) << 32))
+    const int N = G2_RFL(A.N);
+    const char* fbase = G2_RFLP(const char*, A.featb) + (size_t)jme * (C * 2) + half * 16;
+#undef G2_RFLP
+#define G2_LOAD_FEATS(dst, f_, first_)                                                                                          \
+    { const char* p_ = fbase + (size_t)((f_) * N + (first_)) * (C * 2);                                                        \
+      _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                                          \
+          const u32x4_gm t_ = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_gm*>((const __attribute__((address_space(1))) char*)(p_ + ks * 32)); \
+          dst[ks] = make_uint4(t_.x, t_.y, t_.z, t_.w); } }
+    G2_TDECL
+    for (;;) {
+        lds_barrier();                                                   // (batch head: the first aux wave looks the items up)
+        __syncthreads();
+        bool more = true;
+        int first0, count0, f0, nch0;
+        G2_ITEM(0, first0, count0, f0, nch0)
+        (void)count0; (void)nch0;
+        if (f0 < 0) break;
+        uint4 bfr[8];
+        G2_LOAD_FEATS(bfr, f0, first0)                                   // (exposed: the batch's first item)
+        lds_barrier();                                                   // (P)
+        int st = 0;                                                      // the stage this step consumes
+        for (int it = 0; it < GM_ENTS; ++it) {
+            int first, count, f, nch, firstn, countn, fn, nchn;
+            G2_ITEM(it, first, count, f, nch)
+            if (f < 0) { more = false; break; }
+            G2_ITEM(it + 1, firstn, countn, fn, nchn)
+            (void)first; (void)countn; (void)nchn;
+            const int4 cs = ent[4 * it + 1];
+            const int cs1 = G2_RFL(cs.x), cs2 = G2_RFL(cs.y), cs3 = G2_RFL(cs.z);
+            const int4 pv = ent[4 * it + 2];
+            const int P0 = G2_RFL(pv.x), P1 = G2_RFL(pv.y), P2 = G2_RFL(pv.z), P3 = G2_RFL(pv.w);
+            const int4* recp = rec + (it & 1) * (GMAX * PIPS_LEVELS);
+            const int an0 = recp[jme * PIPS_LEVELS + 0].x, an1 = recp[jme * PIPS_LEVELS + 1].x, an2 = recp[jme * PIPS_LEVELS + 2].x,
+                      an3 = recp[jme * PIPS_LEVELS + 3].x;
+            const bool active = pb * 32 < count;
+            // the steps go level by level (the level a compile-time constant: what depends on it alone -- this lane's anchor relative to the
+            // region, its window's address -- is worked out once per level, and the blend of the level before has a fixed place: the level's
+            // first step, AHEAD of that step's products; behind them it cost 7 % in gather_mfma_kernel)
+#define G2_PLEVEL(L_, an_, P_, s0_, s1_, UNUSED_)                                                                               \
+            {                                                                                                                   \
+                const int bxo = 4 * half - ((int)(short)((an_) & 0xffff) - ((P_) & 0xffff)), byo = (int)((unsigned)(P_) >> 16) - ((an_) >> 16); \
+                const unsigned wb = lds0 + (unsigned)(G2_WIN_OFF + ((L_) & 1) * GM_WIN_BYTES + jme * (GM_WIN_ROW * 4));          \
+                for (int s = (s0_); s < (s1_); ++s) {                                                                           \
+                    G2_T(0)                                                                                                     \
+                    const uint2 m_ = ctab[it * GM_CHUNKS_MAX + s];                                                              \
+                    const int nvalid = (G2_RFL(m_.x) >> 2) & 7, bxy = (G2_RFL(m_.y) >> (8 * bl)) & 0xff;                       \
+                    if (active && bl < nvalid && !(G2_ABLATE & 2)) {                                                            \
+                        const int dx0 = (bxy & 15) * 8 + bxo, dy0 = (bxy >> 4) * 4 + byo;                                       \
+                        G2_PRODUCT(wb, dx0, dy0)                                                                                \
+                    }                                                                                                           \
+                    /* behind the item's last products: the NEXT item's feature rows into the same registers (a second register set held   \
+                       across the item cost the fragment reads their double buffering: 128 registers per wave).  They have the barrier and \
+                       the next item's first blend to land */                                                                   \
+                    if ((L_) == 3 && s == (s1_) - 1 && fn >= 0) G2_LOAD_FEATS(bfr, fn, firstn)                                  \
+                    G2_T(4)                                                                                                     \
+                    lds_barrier();                                                                                              \
+                    G2_T(5)                                                                                                     \
+                    G2_TSTEP                                                                                                    \
+                    st = st == 2 ? 0 : st + 1;                                                                                  \
+                }                                                                                                               \
+            }
+            // one (pixel block, particle block) product and its window scatter.  A lane's 4 x 4 pixels touch its particle's window iff dx0, dy0
+            // in [-3, 7]; a pixel block no window of the wave's 32 particles reaches is skipped (slots past the item's particles hold the
+            // records behind it)
+#define G2_PRODUCT(wb_, dx0, dy0)                                                                                               \
+            {                                                                                                                   \
+                const bool hit = (unsigned)((dx0) + 3) < 11u && (unsigned)((dy0) + 3) < 11u && jme < count;                     \
+                G2_T(1)                                                                                                         \
+                if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {                                                                 \
+                    f32x16 acc;                                                                                                 \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                                \
+                    const char* ap = smem + st * GM_STAGE + bl * GM_BLK_BYTES + l31 * 256;                                      \
+                    /* all eight fragment reads in flight, THEN the MFMAs (left alone hipcc reads one fragment at a time into one register \
+                       set, each MFMA behind its own LDS round trip) */                                                         \
+                    uint4 afr[8];                                                                                               \
+                    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                                            \
+                        afr[ks] = (G2_ABLATE & 32) ? make_uint4((unsigned)ks, (unsigned)lane, 0u, 0u)                           \
+                                                   : *reinterpret_cast<const uint4*>(ap + (((ks * 2 + half) ^ (l31 & 15)) << 4)); \
+                    __builtin_amdgcn_sched_barrier(0);                                                                          \
+                    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                                            \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_gm*>(&afr[ks]),            \
+                                                                      *reinterpret_cast<const bf16x8_gm*>(&bfr[ks]), acc, 0, 0, 0); \
+                    G2_TRACE_SYNC(acc)                                                                                          \
+                    G2_T(2)                                                                                                     \
+                    if (G2_ABLATE & 16) { asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15])); } else {    \
+                    const unsigned wbo = (wb_) + (unsigned)((dy0) * 32 + (dx0) * 4);                                            \
+                    const unsigned long long mx0 = __builtin_amdgcn_ballot_w64((unsigned)((dx0) + 0) < 8u), mx1 = __builtin_amdgcn_ballot_w64((unsigned)((dx0) + 1) < 8u), \
+                                             mx2 = __builtin_amdgcn_ballot_w64((unsigned)((dx0) + 2) < 8u), mx3 = __builtin_amdgcn_ballot_w64((unsigned)((dx0) + 3) < 8u), \
+                                             my0 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 0) < 8u), my1 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 1) < 8u), \
+                                             my2 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 2) < 8u), my3 = __builtin_amdgcn_ballot_w64((unsigned)((dy0) + 3) < 8u); \
+                    unsigned long long sv;                                                                                      \
+                    /* the window scatter: the 16 values under execution masks = (x in the window) & (y in the window).  They come straight  \
+                       out of the last MFMA: 12 wait states in front of the first DS read of an accumulator (tools/asm_hazard_lint.py:        \
+                       s_nop 10 = 11, + s_mov + s_and) */                                                                       \
+                    asm volatile("s_nop 10\n\ts_mov_b64 %0, exec\n\t"                                                          \
+                    "s_and_b64 exec, %1, %5\n\tds_write_b32 %9, %10 offset:0\n\t"                                             \
+                    "s_and_b64 exec, %2, %5\n\tds_write_b32 %9, %11 offset:4\n\t"                                             \
+                    "s_and_b64 exec, %3, %5\n\tds_write_b32 %9, %12 offset:8\n\t"                                             \
+                    "s_and_b64 exec, %4, %5\n\tds_write_b32 %9, %13 offset:12\n\t"                                            \
+                    "s_and_b64 exec, %1, %6\n\tds_write_b32 %9, %14 offset:32\n\t"                                            \
+                    "s_and_b64 exec, %2, %6\n\tds_write_b32 %9, %15 offset:36\n\t"                                            \
+                    "s_and_b64 exec, %3, %6\n\tds_write_b32 %9, %16 offset:40\n\t"                                            \
+                    "s_and_b64 exec, %4, %6\n\tds_write_b32 %9, %17 offset:44\n\t"                                            \
+                    "s_and_b64 exec, %1, %7\n\tds_write_b32 %9, %18 offset:64\n\t"                                            \
+                    "s_and_b64 exec, %2, %7\n\tds_write_b32 %9, %19 offset:68\n\t"                                            \
+                    "s_and_b64 exec, %3, %7\n\tds_write_b32 %9, %20 offset:72\n\t"                                            \
+                    "s_and_b64 exec, %4, %7\n\tds_write_b32 %9, %21 offset:76\n\t"                                            \
+                    "s_and_b64 exec, %1, %8\n\tds_write_b32 %9, %22 offset:96\n\t"                                            \
+                    "s_and_b64 exec, %2, %8\n\tds_write_b32 %9, %23 offset:100\n\t"                                           \
+                    "s_and_b64 exec, %3, %8\n\tds_write_b32 %9, %24 offset:104\n\t"                                           \
+                    "s_and_b64 exec, %4, %8\n\tds_write_b32 %9, %25 offset:108\n\t"                                           \
+                    "s_mov_b64 exec, %0"                                                                                        \
+                    : "=&s"(sv)                                                                                                 \
+                    : "s"(mx0), "s"(mx1), "s"(mx2), "s"(mx3), "s"(my0), "s"(my1), "s"(my2), "s"(my3), "v"(wbo),                 \
+                    "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]), "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15]) \
+                    : "memory", "scc");                                                                                         \
+                    }                                                                                                           \
+                    G2_T(3)                                                                                                     \
+                }                                                                                                               \
+            }
+            G2_PLEVEL(0, an0, P0, 0, cs1, )
+            G2_PLEVEL(1, an1, P1, cs1, cs2, )
+            G2_PLEVEL(2, an2, P2, cs2, cs3, )
+            G2_PLEVEL(3, an3, P3, cs3, nch, )
+#undef G2_PLEVEL
+#undef G2_PRODUCT
+            if (fn < 0) { more = it + 1 >= GM_ENTS; break; }
+        }
+        if (!more) break;
+    }
+    G2_TDUMP(0)
+#undef G2_LOAD_FEATS
+}
+#undef G2_SEL4
+#undef G2_RFL
+#undef G2_ITEM
+
+__global__ __launch_bounds__(GM_THREADS) void gather_mfma2_kernel(const unsigned short* __restrict__ mirror, TiledLevels lv,
+                                                                 const uint4* __restrict__ featb, int N, int max_items, int F,
+                                                                 const int4* __restrict__ order, const int4* __restrict__ items,
+                                                                 const int* __restrict__ nitems, int tiles_x,
+                                                                 float* __restrict__ X) {
+    G2Args A;
+    A.mirror = mirror; A.featb = featb; A.order = order; A.items = items; A.nitems = nitems; A.X = X;
+    A.N = N; A.max_items = max_items; A.F = F; A.tiles_x = tiles_x;
+    A.W0 = lv.W[0]; A.W1 = lv.W[1]; A.W2 = lv.W[2]; A.W3 = lv.W[3]; A.H0 = lv.H[0]; A.H1 = lv.H[1]; A.H2 = lv.H[2]; A.H3 = lv.H[3];
+    A.ob0 = (unsigned)(lv.off[0] * 2); A.ob1 = (unsigned)(lv.off[1] * 2); A.ob2 = (unsigned)(lv.off[2] * 2); A.ob3 = (unsigned)(lv.off[3] * 2);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= GM_PWAVES + 2) { if (G2_ROLE != 2) g2_blend_role(A); }
+    else if (wave >= GM_PWAVES) { if (G2_ROLE != 2) g2_aux_role(A); }
+    else if (G2_ROLE != 1) g2_product_role(A);
+}
+
+#endif   // gather_mfma2_kernel
 
 // ---------------------------------------------------------------------------- host side
 static int tiled_max_items(int N, int H8, int W8) { return cdiv(W8, TS) * cdiv(H8, TS) + N / GMAX + 1; }
@@ -1108,7 +1681,19 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
     }
     const int grid = max(cus / 8, 1) * 8;
     if (ev) (void)hipEventRecord(ev[2], st);
-    if (mirror != nullptr) {                     // one persistent block of 12 product + 4 loader waves per compute unit
+    if (mirror != nullptr) {                     // one persistent block of 12 product + 4 loader / aux waves per compute unit
+#if PIPS_GM_V_DEFAULT == 2 || defined(PIPS_TUNING)
+        if (PIPS_TUNE("PIPS_GATHER_MFMA_V", PIPS_GM_V_DEFAULT) == 2) {                   // (variant builds: round 6's re-cut)
+            static std::atomic<unsigned long long> raised_g2{0};
+            const int rc2 = ensure_dynamic_lds(raised_g2, (const void*)gather_mfma2_kernel, G2_LDS);
+            if (rc2 != PIPS_OK) return rc2;
+            hipLaunchKernelGGL(gather_mfma2_kernel, dim3(grid), dim3(GM_THREADS), G2_LDS, st, mirror, lv, featb, N, max_items, F,
+                               order, items, nitems, tiles_x, X);
+            if (ev) (void)hipEventRecord(ev[3], st);
+            PIPS_CHECK_LAUNCH("gather_mfma2_kernel");
+            return PIPS_OK;
+        }
+#endif
         static std::atomic<unsigned long long> raised_gm{0};
         const int rc = ensure_dynamic_lds(raised_gm, (const void*)gather_mfma_kernel, GM_LDS);
         if (rc != PIPS_OK) return rc;
@@ -1127,6 +1712,11 @@ int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const 
 
 }  // namespace pips
 
+#if defined(G2_TRACE) && (PIPS_GM_V_DEFAULT == 2 || defined(PIPS_TUNING))
+extern "C" int pips_g2_trace(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(pips::g_g2_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
 #ifdef GM_TRACE
 extern "C" int pips_gm_trace(void* buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(pips::g_gm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
