@@ -420,24 +420,46 @@ def config4_leg(device):
     ops.pyramid_mirror(pyr, F, h, w, STRIDE)
     comp_bf = F * (lv * 256 + n * 256 + n * 8 + n * 196 * 4)
     c0 = (xys / STRIDE).unsqueeze(1).expand(b, S, n, 2).permute(0, 2, 1, 3).reshape(M, 2).contiguous()
-    tb = []
+    tb = {"bin": [], "embed": [], "gather": []}
     for i in range(12):
         _, t = ops.mixer_input_build_tiled_timed(pyr, b, H8, W8, ffeats, c0, bf16_maps=True)
         if i >= 2:
-            tb.append(t["gather"])
-    tgb = statistics.mean(tb)
+            for kk in tb:
+                tb[kk].append(t[kk])
+    tgb = statistics.mean(tb["gather"])
+    path_b = sum(statistics.mean(tb[kk]) for kk in tb)
     traffic_b, traffic_b_src = pmc_traffic("gather_mfma_kernel")
+    # what bounds THIS formulation on the chip (profiles/r6_probe_gather_mfma2.txt): the work items fetch 780 MB of pixel blocks through the
+    # compute units' vector L1s -- 17-18 B/clk/CU = 70 us whatever the staging (registers or LDS-DMA, two or three buffers) -- and the window
+    # scatter occupies the LDS store path for 192 ds_write_b32 x 4 clk per step
+    fetch_floor_ms = 0.070
     gather_bf16 = {"bound": "hbm", "kernel": "gather_mfma_kernel (bf16 mode: PIPS_FLAG_BF16_MAPS on a dense query set)", "launch_ms": tgb,
                    "achieved": comp_bf / tgb / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": comp_bf / tgb / 1e6 / PEAK_HBM_GBS,
                    "traffic": traffic_b, "traffic_source": traffic_b_src, "algorithmic_bytes_per_launch": comp_bf,
+                   # the whole tiled path of an iteration: binning + embedding rows + the gather itself, and the fraction on IT
+                   "gather_path_ms": path_b, "bin_particles_kernel_ms": statistics.mean(tb["bin"]),
+                   "embed_rows_kernel_ms": statistics.mean(tb["embed"]), "frac_of_path": comp_bf / path_b / 1e6 / PEAK_HBM_GBS,
+                   # the formulation's own floor as a fraction of 8 TB/s: what 0.80 would have to get past
+                   "l1_fetch_floor_ms": fetch_floor_ms, "ceiling_frac": comp_bf / fetch_floor_ms / 1e6 / PEAK_HBM_GBS,
+                   "ceiling_note": "the tile regions of the four levels are 780 MB per launch through the vector L1s at the 17-18 B/clk a "
+                                   "compute unit fetches from L2 / Infinity Cache (measured: the request stream alone, registers or LDS-DMA, "
+                                   "profiles/r6_probe_gather_mfma2.txt)",
                    "timing": "HIP event pair around the kernel launch, mean of 10 launches on the real maps (iteration-0 grid)"}
+    # the bf16 mode END TO END at this config: the whole forward under autocast (bf16 encoder + mixer, gather_mfma_kernel)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        fwd()
+        t_bf16 = ev_time_ms(fwd, 2)
     traffic, traffic_src = pmc_traffic("gather_tiled_kernel")
     valu_floor_ms = b * S * n * 4 * 64 * 128 / (105.0 * 256 * 2.4e9) * 1e3
     lds_floor_ms = 0.78 * b * S * n * 4 * 64 * 128 * 4 / (256.0 * 256 * 2.4e9) * 1e3
+    path_f = dom["gather_tiled_kernel_ms"] + dom["bin_particles_kernel_ms"] + dom["embed_rows_kernel_ms"]
     return {"workload": "BASELINE configs[3]: B=4 S=8 720x1280 N=4096 (64x64 grid) I=6 fp32 stride 8, encoder included",
             "value": b * S * n * ITERS / t_fwd * 1e3, "unit": "particle-updates/s", "ms_per_step": t_fwd, "dtype": "f32",
             "split_bf16": {"ms_per_step": t_split, "value": b * S * n * ITERS / t_split * 1e3,
                            "note": "Pips.matmul='split' at the same size; same 1e-3 px gate (tests/test_config45_gpu.py)"},
+            "bf16": {"ms_per_step": t_bf16, "value": b * S * n * ITERS / t_bf16 * 1e3, "dtype": "bf16 MFMA operands",
+                     "note": "the same forward under torch.autocast(bfloat16): bf16 encoder and mixer, the gather on the matrix cores; "
+                             "2e-2 px gate against the autocast oracle at this geometry (tests/test_config45_gpu.py)"},
             "gather_roofline": {"bound": "hbm", "kernel": "gather_tiled_kernel", "achieved": dom["achieved_GBs"],
                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": traffic,
                                 "traffic_source": traffic_src,
@@ -446,6 +468,8 @@ def config4_leg(device):
                                 # (76 us) lies below both
                                 "valu_floor_ms": valu_floor_ms, "lds_floor_ms": lds_floor_ms,
                                 # how close the launch is to what bounds THIS formulation: LDS -> VGPR fragment bandwidth
+                                "gather_path_ms": path_f, "frac_of_path": comp / path_f / 1e6 / PEAK_HBM_GBS,
+                                "ceiling_frac": comp / max(valu_floor_ms, lds_floor_ms) / 1e6 / PEAK_HBM_GBS,
                                 "frac_of_lds_floor": lds_floor_ms / dom["gather_tiled_kernel_ms"],
                                 "frac_of_valu_floor": valu_floor_ms / dom["gather_tiled_kernel_ms"],
                                 "floors_note": "valu: 4.29 G lane-FMAs at the measured 105 lane-FMA/clk/CU (tools/valu_peak.hip) x 256 CUs x "
@@ -556,6 +580,10 @@ def main(argv=None):
                     help="2 (default, the headline: B=1/GPU fp32), 3 (B=8/GPU, bf16 MFMA operands) or 4 (BASELINE configs[3]: "
                          "B=4 720x1280 N=4096 fp32 -- with --gpus N the PARTICLES are sharded over the ranks on replicated maps, "
                          "strong scaling, SURVEY 8(e) secondary axis)")
+    ap.add_argument("--encode", default="frames", choices=("frames", "replicate"),
+                    help="--config 4 with --gpus N: how the ranks get the clips' maps -- 'frames' (default): each rank encodes S/N frames of "
+                         "every clip and one all-gather per pyramid level rebuilds the cache (the encoder scales with the ranks too); "
+                         "'replicate': every rank encodes all frames (no exchange, Amdahl-capped by the encoder)")
     ap.add_argument("--leg", default=None, choices=("config3", "config4", "config5", "torch_rocm_baseline"),
                     help="run ONE of the extra legs alone and print its JSON (what the rocprofv3 passes under profiles/ wrap)")
     ap.add_argument("--matmul", default="exact", choices=("exact", "split"),
@@ -636,9 +664,12 @@ def main(argv=None):
         model.matmul = args.matmul
         xys, rgbs = make_inputs(rank, device, b_per_gpu)
 
+    # frame-sharded maps need S divisible by the ranks; a single rank has nothing to shard
+    enc4 = args.encode if (world > 1 and S % world == 0 and not fake) else "replicate"       # (the CPU stand-in has no pyramid to exchange)
+
     def step():
         if args.config == 4:          # particles sharded over the ranks on replicated maps + one gather on the particle axis
-            return pdist.track_sharded_particles(model, xys, rgbs, iters=ITERS, encode="replicate")
+            return pdist.track_sharded_particles(model, xys, rgbs, iters=ITERS, encode=enc4)
         preds, _, vis, _ = model(xys, rgbs, iters=ITERS)
         if world > 1:
             pdist.all_gather_result(preds[-1], vis)
@@ -706,7 +737,10 @@ def main(argv=None):
                                ("BASELINE configs[2]: B=8/GPU S=8 368x496 N=256 I=6 bf16 operands stride 8, encoder "
                                 "included, inputs resident in HBM") if args.config == 3 else
                                ("BASELINE configs[3]: B=4 S=8 720x1280 N=4096 (64x64 grid) I=6 fp32 stride 8, inputs resident in "
-                                "HBM; every rank encodes the 4 clips (replicated maps) and tracks N/G particles"),
+                                "HBM; " + ("every rank encodes S/G frames of the 4 clips, one all-gather per pyramid level rebuilds the maps"
+                                           if enc4 == "frames" else "every rank encodes the 4 clips (replicated maps)") +
+                                " and tracks N/G particles"),
+                   "encode": enc4 if args.config == 4 else None,
                    "clips_per_gpu": b_per_gpu,
                    "parallelism": f"particle-sharded x{world} (pips_amd.dist.track_sharded_particles)" if args.config == 4
                    else f"clip-sharded x{world}",

@@ -222,8 +222,9 @@ int    pips_mixer_input_build_ex(const float* pyramid, int B, int S, int H8, int
 /* Same result as pips_mixer_input_build through the LDS-tiled kernels meant for dense query sets
  * (BASELINE configs[3], test_on_davis.py:103-130): particles binned by 16x16 map tile, the tile's
  * halo region at each level staged in LDS once per tile (csrc/gather_tiled.hip).  pips_track /
- * pips_forward pick it by themselves when the query set is dense (>= 1024 particles and >= 16 per
- * tile on average, within the kernel's 32-bit offset limits -- otherwise the direct kernel).  scratch holds the per-frame sort,
+ * pips_forward pick it by themselves when the query set is dense (>= 16 particles per tile on average and >= 1024 per
+ * frame -- >= 256 with PIPS_FLAG_BF16_MAPS, whose matrix-core kernel pays earlier: BASELINE configs[2] takes it since
+ * round 6 -- within the kernel's 32-bit offset limits; otherwise the direct kernel).  scratch holds the per-frame sort,
  * the per-tile tables and (read by the bf16 mode's kernel) the features as bf16 in the sorted order; values agree
  * with the direct kernel to fp32 summation order.  The _timed form also returns the HIP-event
  * durations (ms) of its three launches {bin_particles, embed_rows, gather_tiled} in ms3_host and

@@ -14,7 +14,10 @@ SOURCES = ["gemm.hip", "gemm_f32_t4.hip", "conv_f32_t4.hip", "encoder.hip", "enc
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Werror=inline-asm"]
 # per-file additions.  conv_bf16_c64.hip: its VALU work runs beside MFMAs of a co-resident wave, where packed fp32 ops are an
 # anti-lever -- keep hipcc's SLP vectoriser from re-packing the scalar ops (MI355X_MICROARCH.md)
-FILE_FLAGS = {"conv_bf16_c64.hip": ["-fno-slp-vectorize"]}
+# track.hip: no IEEE-mode NaN quieting -- under the default (amdgpu-ieee) every fminf / fmaxf gets a `v_max x, x` in front of it to quiet a
+# signalling NaN: 512 of the 3 600 vector instructions of a token_mix_mfma_kernel wave, which is bound by exactly those (the GELU of its
+# 16 384 hidden units per particle; tools/token_trace_bf16.py).  Results on non-NaN data are bit-identical (the whole GPU suite runs on it)
+FILE_FLAGS = {"conv_bf16_c64.hip": ["-fno-slp-vectorize"], "track.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
 
 
 def _hipcc() -> str:

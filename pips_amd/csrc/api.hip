@@ -704,7 +704,7 @@ static int mixer_input(const float* pyramid, int B, int S, int H8, int W8, const
     PIPS_CHECK_ARG(lh[PIPS_LEVELS - 1] >= 1 && lw[PIPS_LEVELS - 1] >= 1, "mixer_input: map too small");
     const bool can_tile = scratch != nullptr && win_start == nullptr && S == PIPS_S && Sw == PIPS_S &&
                           scratch_bytes >= tiled_gather_scratch_bytes(B, N, H8, W8);
-    const bool tiled = force_tiled >= 0 ? (force_tiled != 0) : tiled_gather_wanted(B, N, H8, W8);
+    const bool tiled = force_tiled >= 0 ? (force_tiled != 0) : tiled_gather_wanted(B, N, H8, W8, bf16_maps);
     if (tiled && can_tile)      // (bf16 mode: the same work items on the matrix cores, reading the bf16 mirror behind the fp32 levels)
         return launch_mixer_input_tiled(pyramid, off, lh, lw, B, S, ffeats, coords, times, N, X, scratch, scratch_bytes, st, ev,
                                         bf16_maps ? reinterpret_cast<const unsigned short*>(pyramid + o) : nullptr);
@@ -762,7 +762,7 @@ int pips_mixer_input_build_tiled_timed(const float* pyramid, int B, int S, int H
 
 int pips_gather_route(int B, int N, int H8, int W8, int flags) {
     if (B <= 0 || N <= 0 || H8 <= 0 || W8 <= 0) return 0;
-    if (!tiled_gather_wanted(B, N, H8, W8)) return 0;
+    if (!tiled_gather_wanted(B, N, H8, W8, (flags & PIPS_FLAG_BF16_MAPS) != 0)) return 0;
     return (flags & PIPS_FLAG_BF16_MAPS) ? 2 : 1;
 }
 

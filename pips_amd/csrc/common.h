@@ -70,8 +70,14 @@ __device__ __forceinline__ f2 gelu_exact2(f2 x) {
 // GELU whose result is rounded to bf16 right away (hidden activations of the bf16 mixer): the same form with a degree-5 exponent
 // polynomial -- max |error| 5.1e-6, 3.3e-5 relative where |gelu| > 1e-3, two orders below the bf16 rounding (2^-9); three
 // packed FMAs per pair fewer.  The coefficients of tools/gen_gemm_bf16_t4up.py (the up-projection's epilogue).
+// min(|x|, c) and max(x, 0) as ONE instruction each: v_med3_f32 (the abs is a source modifier; med3(|x|, c, -1) = min(|x|, c) for c > 0,
+// med3(x, 0, +inf) = max(x, 0)).  Written with the min / max / abs builtins hipcc emits v_max |x|,|x| for the abs and a v_max x,x in
+// front of every IEEE min / max (it quiets a signalling NaN): 768 of the 3 600 vector instructions of a token_mix_mfma_kernel wave,
+// which is bound by exactly those (tools/token_trace_bf16.py: the 16 channel slots are 9.3 of its 12.4 us)
+__device__ __forceinline__ float min_abs(float x, float c) { return __builtin_amdgcn_fmed3f(__builtin_fabsf(x), c, -1.0f); }
+__device__ __forceinline__ float relu_med3(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()); }
 __device__ __forceinline__ f2 gelu_bf16out2(f2 x) {
-    const f2 t = __builtin_elementwise_min(__builtin_elementwise_abs(x), (f2){PIPS_GELU_TMAX, PIPS_GELU_TMAX});
+    const f2 t = {min_abs(x.x, PIPS_GELU_TMAX), min_abs(x.y, PIPS_GELU_TMAX)};
 #define PIPS_C2(v) ((f2){v, v})
     f2 q = PIPS_C2(2.554670494e-05f);
     q = q * t + PIPS_C2(-6.529359078e-04f);
@@ -82,7 +88,7 @@ __device__ __forceinline__ f2 gelu_bf16out2(f2 x) {
 #undef PIPS_C2
     const f2 a = q * t;
     const f2 w = t * (f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-    return w * -0.5f + __builtin_elementwise_max(x, (f2){0.0f, 0.0f});
+    return w * -0.5f + (f2){relu_med3(x.x), relu_med3(x.y)};
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -385,7 +391,7 @@ int launch_mixer_input_bf16maps(const void* mirror, const size_t* lvl_off, const
 int launch_pyramid_mirror(const float* pyramid, size_t floats, void* mirror, hipStream_t st);
 // LDS-tiled gather for dense query sets (gather_tiled.hip)
 size_t tiled_gather_scratch_bytes(int B, int N, int H8, int W8);
-bool tiled_gather_wanted(int B, int N, int H8, int W8);
+bool tiled_gather_wanted(int B, int N, int H8, int W8, bool bf16_maps = false);
 // ev != null: 4 events recorded around the three launches (bin, embed, gather)
 int launch_mixer_input_tiled(const float* pyramid, const size_t* lvl_off, const int* lvlH, const int* lvlW, int B,
                              int S, const float* ffeats, const float* coords, const float* times, int N,

@@ -1614,11 +1614,14 @@ bool tiled_gather_fits(int B, int N, int H8, int W8) {
            (size_t)B * S * N * PIPS_LEVELS * sizeof(int4) < (1ull << 32) && H8 < 16384 && W8 < 16384 &&
            ((size_t)33 * cdiv(W8, TS) * cdiv(H8, TS) + 1) * sizeof(int) <= 64 * 1024;
 }
-bool tiled_gather_wanted(int B, int N, int H8, int W8) {
+// bf16_maps: the bf16 mode's kernel (gather_mfma_kernel) pays from 256 particles per frame on -- BASELINE configs[2] (N = 256, 21 per tile):
+// bin 10 + embed 12 + gather 44 us against 77 us for the direct bf16-map kernel, config 3 12.55 -> 12.45 ms (same box, interleaved; round 6).
+// Both routes multiply bf16 features with bf16 maps since round 6, so the choice moves a result by fp32 summation order only.
+bool tiled_gather_wanted(int B, int N, int H8, int W8, bool bf16_maps) {
     if (!tiled_gather_fits(B, N, H8, W8)) return false;
     const int force = PIPS_TUNE("PIPS_GATHER_TILED", -1);
     if (force >= 0) return force > 0;
-    return (long)N >= 16L * cdiv(W8, TS) * cdiv(H8, TS) && N >= 1024;
+    return (long)N >= 16L * cdiv(W8, TS) * cdiv(H8, TS) && N >= (bf16_maps ? 256 : 1024);
 }
 
 // mirror != nullptr: the bf16 mode -- the work items run on gather_mfma_kernel, which reads the pyramid's bf16 mirror (element

@@ -640,6 +640,7 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
     const int l31 = lane & 31, half = lane >> 5;
     const int p = blockIdx.x * 4 + wave;                                      // (wave-uniform)
     if (p >= particles) return;
+    PIPS_TT(0)
     // ---- the particle's tile first: its 16 loads are the long ones (HBM / Infinity Cache), the weights below hit L2
     float* xp = x + ((size_t)p * S + 4 * half) * PIPS_DMIX + 4 * l31;         // + r * 512 + g * 128
     unsigned short* xh = reinterpret_cast<unsigned short*>(x) + ((size_t)p * S + 4 * half) * PIPS_DMIX + 4 * l31;   // the same elements of a bf16 stream
@@ -714,7 +715,9 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
         }
     };
     float mean[4], rstd[4];
+    PIPS_TT(1)
     ln_stats(xv, mean, rstd);
+    PIPS_TT(2)
 
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -761,7 +764,9 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
             }
         }
     }
+    PIPS_TT(3)
     ln_stats(xv, mean, rstd);
+    PIPS_TT(4)
     unsigned* xnp = xn + ((size_t)p * S + 4 * half) * (PIPS_DMIX / 2) + 2 * l31;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -776,6 +781,7 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
             *reinterpret_cast<uint2*>(xnp + r * (PIPS_DMIX / 2) + g * 64) = make_uint2(pack2_bf16(n[0], n[1]), pack2_bf16(n[2], n[3]));
         }
     }
+    PIPS_TT(5)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

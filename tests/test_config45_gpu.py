@@ -70,7 +70,8 @@ def test_config4_gather_bf16_matrix_cores_vs_oracle():
     lib = _lib.load()
     B, H8, W8, N = 1, 90, 160, 4096
     assert lib.pips_gather_route(B, N, H8, W8, 32) == 2 and lib.pips_gather_route(B, N, H8, W8, 0) == 1
-    assert lib.pips_gather_route(1, 256, 46, 62, 32) == 0                  # BASELINE configs[2]: sparse, the direct kernel
+    assert lib.pips_gather_route(1, 256, 46, 62, 32) == 2                  # BASELINE configs[2] (21 per tile): the bf16 mode's matrix-core kernel since round 6 ...
+    assert lib.pips_gather_route(1, 256, 46, 62, 0) == 0 and lib.pips_gather_route(1, 128, 46, 62, 32) == 0      # ... the fp32 mode and sparser sets: the direct kernels
     g = torch.Generator().manual_seed(22)
     fmaps = torch.randn(B, 8, 128, H8, W8, generator=g)
     ffeats = torch.randn(B, 8, N, 128, generator=g)
@@ -146,12 +147,12 @@ def test_bf16_mode_dense_query_set_agrees_with_its_particle_shards(weights_tamed
     reached (dense sets: bf16 x bf16 on the matrix cores; sparse sets: fp32 features x bf16 maps), so `dist.track_sharded_particles`
     -- which turns one dense set into G sparse ones -- changed a particle's result by 7e-3 per tap.  Round 6: both routes round the
     features to bf16 (nets/pips.py:394-397 casts both matmul operands).  One clip, a 2304-point grid on 46 x 62 maps under autocast:
-    the whole set (route 2 asserted) against its eight shards of 288 (route 0 asserted), same cached maps.  What is left is the
+    the whole set (route 2 asserted) against its sixteen shards of 144 (route 0 asserted), same cached maps.  What is left is the
     order of the fp32 sums in the gather (<= 1e-4 per tap, tests/test_kernels_gpu.py) and, from the second iteration on, what the
     bf16 mixer makes of a tap that rounds the other way: printed, gated at a quarter of the bf16 mode's own 2e-2 px budget."""
     from pips_amd import Pips, _lib
     lib = _lib.load()
-    B, H, W, N, G = 1, 368, 496, 2304, 8                      # a 48 x 48 grid, 288 queries per shard
+    B, H, W, N, G = 1, 368, 496, 2304, 16                     # a 48 x 48 grid, 144 queries per shard
     assert lib.pips_gather_route(B, N, H // 8, W // 8, 32) == 2 and lib.pips_gather_route(B, N // G, H // 8, W // 8, 32) == 0
     g = torch.Generator().manual_seed(9)
     rgbs = torch.randint(0, 256, (B, 8, 3, H, W), generator=g).float().to(DEV)
@@ -167,7 +168,7 @@ def test_bf16_mode_dense_query_set_agrees_with_its_particle_shards(weights_tamed
     e1 = float((whole[0][0] - torch.cat([p[0][0] for p in parts], dim=2)).abs().max())
     e6 = float((whole[0][-1] - torch.cat([p[0][-1] for p in parts], dim=2)).abs().max())
     ev = float((whole[2] - torch.cat([p[2] for p in parts], dim=2)).abs().max())
-    print(f"bf16 mode, dense set (matrix-core gather) vs its 8 particle shards (direct gather): first iterate {e1:.2e} px, after 6 "
+    print(f"bf16 mode, dense set (matrix-core gather) vs its 16 particle shards (direct gather): first iterate {e1:.2e} px, after 6 "
           f"iterations {e6:.2e} px, vis logits {ev:.2e}")
     assert e1 < 2e-3 and e6 < 5e-3 and ev < 5e-2
 
