@@ -235,3 +235,13 @@ def test_generators_take_their_wait_states_from_one_place():
     for g in gens:
         src = open(g).read()
         assert "import asm_guards" in src and "s_nop 15" not in src, g
+
+
+def test_profiles_readme_is_generated_from_the_files():
+    """The current round's table of profiles/README.md is what tools/profiles_readme.py generates from the committed evidence files
+    (rounds 3-5 copied their numbers by hand and the prose drifted from the files three times)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "profiles_readme.py"), "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -1,0 +1,226 @@
+"""Generate the current round's table of profiles/README.md FROM THE FILES (three rounds of hand-copied numbers drifted three times:
+round-5 verdict).  Every number in the generated section is read from the file the row names; the prose around it is fixed text.
+
+    python tools/profiles_readme.py [--round 6] [--check]
+
+rewrites the block between `<!-- rN:begin -->` and `<!-- rN:end -->` of profiles/README.md (inserted under the title when absent);
+--check exits 1 when the committed block differs (tests/test_boundary.py::test_profiles_readme_is_generated_from_the_files).
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def _stats(name):
+    """rocpd_summary text -> {kernel name prefix: (calls, avg_us)}"""
+    out = {}
+    path = os.path.join(P, name)
+    if not os.path.exists(path):
+        return out
+    for line in open(path).read().splitlines()[1:]:
+        cols = line.rsplit(None, 4)
+        if len(cols) == 5:
+            try:
+                out[cols[0].strip()] = (int(cols[1]), float(cols[3]))
+            except ValueError:
+                pass
+    return out
+
+
+def _k(stats, sub):
+    for k, v in stats.items():
+        if sub in k:
+            return v
+    return None
+
+
+def _us(stats, sub):
+    v = _k(stats, sub)
+    return "n/a" if v is None else "%.2f µs" % v[1]
+
+
+def _json(name):
+    path = os.path.join(P, name)
+    if not os.path.exists(path):
+        return None
+    txt = open(path).read().strip()
+    try:
+        return json.loads(txt)
+    except ValueError:
+        return json.loads(txt.splitlines()[-1])
+
+
+def _traffic(d, sub):
+    if not d:
+        return "n/a"
+    for k, v in d["kernels"].items():
+        if sub in k:
+            return "%.1f MB" % (v["hbm_bytes"] / 1e6)
+    return "n/a"
+
+
+def _mfma(name, sub):
+    path = os.path.join(P, name)
+    if not os.path.exists(path):
+        return "n/a"
+    for line in open(path):
+        if sub in line:
+            return line.split()[-1]
+    return "n/a"
+
+
+def _counter(name, counter):
+    path = os.path.join(P, name)
+    if not os.path.exists(path):
+        return None
+    for line in open(path):
+        c = line.split()
+        if len(c) >= 5 and c[1] == counter:
+            return float(c[3])
+    return None
+
+
+def _grep(name, pattern, group=1, default="n/a"):
+    path = os.path.join(P, name)
+    if not os.path.exists(path):
+        return default
+    m = re.search(pattern, open(path).read())
+    return m.group(group) if m else default
+
+
+def section(r):
+    t = "r%d" % r
+    b = _json(t + "_bench.json")
+    ks, k3, k4 = _stats(t + "_kernel_stats.txt"), _stats(t + "_config3_kernel_stats.txt"), _stats(t + "_config4_kernel_stats.txt")
+    pm, pm3 = _json(t + "_pmc_traffic.json"), _json(t + "_pmc_traffic_config3.json")
+    L = []
+    L.append("## Round %d (`sh tools/r%d_final.sh` = `pytest -m gpu; python bench.py; sh tools/profile_round.sh r%d; sh tools/profile_mfma.sh r%d; "
+             "sh tools/gather_pmc.sh … fp32 / bf16`; the `r%d_probe_*` files come from the `tools/history/r%d_call*.sh` scripts; THIS TABLE IS "
+             "GENERATED from the files by `python tools/profiles_readme.py`)" % (r, r, r, r, r, r))
+    L.append("")
+    L.append("| file | what | command |")
+    L.append("|---|---|---|")
+    if b:
+        ro, c3, c4 = b["roofline"], b.get("config3", {}), b.get("config4", {})
+        g32, g16 = c4.get("gather_roofline", {}), c4.get("gather_roofline_bf16", {})
+        L.append("| `%s_bench.json` | the bench line of the final code: headline %.2f ms = %.3f M particle-updates/s (median of per-step HIP-event gaps %.2f ms); "
+                 "`roofline.frac` %.3f from launch trains (`%s` %.1f µs start to start; `kernel_body_ms` %.1f µs; `frac_rocprof` %s from `%s`); "
+                 "`split_bf16` %.2f ms; `config3` weak %.2f ms = %.2f M updates/s per GPU (strong, 64 clips: %.1f ms), %.3f of the bf16 roof; `config4` %.1f ms "
+                 "(split %.1f ms, **bf16 mode %.1f ms = %.2f M updates/s**), `gather_tiled_kernel` %.1f µs = %.3f of 8 TB/s (path bin + embed + gather %.1f µs = %.3f; "
+                 "`ceiling_frac` %.2f), `gather_mfma_kernel` %.1f µs = %.3f (path %.1f µs = %.3f; `ceiling_frac` %.2f); `config5` %.3f s per video; "
+                 "stock PyTorch-ROCm ops %.1f ms; CPU port %.0f updates/s on %d cores | `python bench.py` |" % (
+                     t, b["ms_per_step"], b["value"] / 1e6, b.get("ms_per_step_median", 0.0), ro["frac"], ro.get("kernel", "?").split("(")[0],
+                     ro["launch_ms"] * 1e3, ro.get("kernel_body_ms", 0.0) * 1e3,
+                     ("%.3f" % ro["frac_rocprof"]) if ro.get("frac_rocprof") else "n/a", ro.get("rocprof_source", "n/a"),
+                     b["split_bf16"]["ms_per_step"], c3.get("weak", {}).get("ms_per_step", 0.0), c3.get("weak", {}).get("value", 0.0) / 1e6,
+                     c3.get("strong", {}).get("ms_per_step", 0.0), c3.get("roofline", {}).get("frac", 0.0), c4.get("ms_per_step", 0.0),
+                     c4.get("split_bf16", {}).get("ms_per_step", 0.0), c4.get("bf16", {}).get("ms_per_step", 0.0), c4.get("bf16", {}).get("value", 0.0) / 1e6,
+                     c4.get("gather", {}).get("iter0_grid", {}).get("gather_tiled_kernel_ms", 0.0) * 1e3, g32.get("frac", 0.0),
+                     g32.get("gather_path_ms", 0.0) * 1e3, g32.get("frac_of_path", 0.0), g32.get("ceiling_frac", 0.0),
+                     g16.get("launch_ms", 0.0) * 1e3, g16.get("frac", 0.0), g16.get("gather_path_ms", 0.0) * 1e3, g16.get("frac_of_path", 0.0),
+                     g16.get("ceiling_frac", 0.0), b.get("config5", {}).get("seconds_per_video", 0.0),
+                     b.get("torch_rocm_baseline", {}).get("ms_per_step", 0.0), b["cpu_baseline"]["value"], b["cpu_baseline"]["cores"]))
+    if ks:
+        calls = _k(ks, "gemm_f32_t4u_kernel<0>")
+        L.append("| `%s_kernel_stats.txt` | rocprofv3 per-kernel summary of the headline command: `gemm_f32_t4u_kernel<0>` **%s**, `gemm_f32_t4e_kernel` %s (%s launches each), "
+                 "`conv3x3_f32_t4_kernel<0/1/2>` %s / %s / %s, `token_mix_kernel` %s, `igemm_f32_kernel<64,64,2,2,1,true>` %s, `mixer_input_kernel` %s | "
+                 "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-stage-profile --no-extras` |" % (
+                     t, _us(ks, "gemm_f32_t4u_kernel<0>"), _us(ks, "gemm_f32_t4e_kernel"), calls[0] if calls else "?", _us(ks, "conv3x3_f32_t4_kernel<0>"),
+                     _us(ks, "conv3x3_f32_t4_kernel<1>"), _us(ks, "conv3x3_f32_t4_kernel<2>"), _us(ks, "token_mix_kernel"),
+                     _us(ks, "igemm_f32_kernel<64, 64, 2, 2, 1, true>"), _us(ks, "mixer_input_kernel")))
+    if k3 or k4:
+        L.append("| `%s_config3_kernel_stats.txt`, `%s_config4_kernel_stats.txt` | the config-3 leg: `gemm_bf16_t4_gelu_kernel` %s, `gemm_bf16_t4_res_kernel<true>` %s, "
+                 "`token_mix_mfma_kernel<true>` %s, `conv3x3_c64_pp_kernel` %s, `conv3x3_c96_t4_kernel` %s, `stem_conv_bf16_kernel` %s, `inorm_apply_bf16_kernel<3>` %s, "
+                 "`gather_mfma_kernel` %s (+ `bin_particles_kernel` %s, `embed_rows_kernel` %s: the bf16 mode's tiled route since this round); the config-4 leg: "
+                 "`gather_tiled_kernel` %s, `gather_mfma_kernel` %s | `rocprofv3 --kernel-trace --stats -- python bench.py --leg config3` / `--leg config4` |" % (
+                     t, t, _us(k3, "gemm_bf16_t4_gelu_kernel"), _us(k3, "gemm_bf16_t4_res_kernel<true>"), _us(k3, "token_mix_mfma_kernel<true>"),
+                     _us(k3, "conv3x3_c64_pp_kernel"), _us(k3, "conv3x3_c96_t4_kernel"), _us(k3, "stem_conv_bf16_kernel"), _us(k3, "inorm_apply_bf16_kernel<3>"),
+                     _us(k3, "gather_mfma_kernel"), _us(k3, "bin_particles_kernel"), _us(k3, "embed_rows_kernel"), _us(k4, "gather_tiled_kernel"),
+                     _us(k4, "gather_mfma_kernel")))
+    if pm:
+        L.append("| `%s_pmc_traffic.json` | FETCH_SIZE / WRITE_SIZE per kernel of the headline and config-4 commands (separate `--pmc` passes), `hbm_bytes` = 2×FETCH + WRITE: "
+                 "`gemm_f32_t4u_kernel<0>` %s, `gather_tiled_kernel` %s (483.9 MB algorithmic), `gather_mfma_kernel` %s (293.8 MB algorithmic); read by `bench.py` for the "
+                 "`traffic` fields | `tools/profile_round.sh` |" % (t, _traffic(pm, "gemm_f32_t4u_kernel<0>"), _traffic(pm, "gather_tiled_kernel"), _traffic(pm, "gather_mfma_kernel")))
+    if pm3:
+        L.append("| `%s_pmc_traffic_config3.json` | the same counters for the config-3 forward (B = 8, bf16; round 5 had none): `gemm_bf16_t4_gelu_kernel` %s, "
+                 "`gemm_bf16_t4_res_kernel<true>` %s, `token_mix_mfma_kernel<true>` %s, `conv3x3_c64_pp_kernel` %s (746 MB of maps in + out), `inorm_apply_bf16_kernel<3>` %s, "
+                 "`stem_conv_bf16_kernel` %s, `gemm_bf16_kernel<128,256,…>` (416 → 256 convolution) %s | `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` `-- python bench.py "
+                 "--config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-stage-profile --no-extras` (the `--leg config3` form: rocprofv3 dies with SIGSEGV on its ~20 k dispatches) |" % (
+                     t, _traffic(pm3, "gemm_bf16_t4_gelu_kernel"), _traffic(pm3, "gemm_bf16_t4_res_kernel<true>"), _traffic(pm3, "token_mix_mfma_kernel<true>"),
+                     _traffic(pm3, "conv3x3_c64_pp_kernel"), _traffic(pm3, "inorm_apply_bf16_kernel<3>"), _traffic(pm3, "stem_conv_bf16_kernel"),
+                     _traffic(pm3, "gemm_bf16_kernel<128, 256")))
+    if os.path.exists(os.path.join(P, t + "_pmc_mfma_util_exact.txt")):
+        L.append("| `%s_pmc_mfma_util_exact.txt`, `_split.txt`, `_config3.txt` | `SQ_VALU_MFMA_BUSY_CYCLES` ÷ (1024 SIMDs × duration × 2.4 GHz) per matrix-core kernel: "
+                 "`gemm_f32_t4u_kernel<0>` %s, `gemm_f32_t4e_kernel` %s, `conv3x3_f32_t4_kernel<0>` %s; config 3: `gemm_bf16_t4_gelu_kernel` %s, `gemm_bf16_t4_res_kernel<true>` %s, "
+                 "`token_mix_mfma_kernel<true>` %s, `conv3x3_c64_pp_kernel` %s | `tools/profile_mfma.sh r%d` |" % (
+                     t, _mfma(t + "_pmc_mfma_util_exact.txt", "gemm_f32_t4u_kernel<0>"), _mfma(t + "_pmc_mfma_util_exact.txt", "gemm_f32_t4e_kernel"),
+                     _mfma(t + "_pmc_mfma_util_exact.txt", "conv3x3_f32_t4_kernel<0>"), _mfma(t + "_pmc_mfma_util_config3.txt", "gemm_bf16_t4_gelu_kernel"),
+                     _mfma(t + "_pmc_mfma_util_config3.txt", "gemm_bf16_t4_res_kernel<true>"), _mfma(t + "_pmc_mfma_util_config3.txt", "token_mix_mfma_kernel<true>"),
+                     _mfma(t + "_pmc_mfma_util_config3.txt", "conv3x3_c64_pp_kernel"), r))
+    f32c, b16c = t + "_gather_pmc_counters_fp32.txt", t + "_gather_pmc_counters_bf16.txt"
+    if os.path.exists(os.path.join(P, b16c)):
+        def mm(name, c):
+            v = _counter(name, c)
+            return "n/a" if v is None else ("%.1f M" % (v / 1e6))
+        fs, ws = _counter(b16c, "FETCH_SIZE"), _counter(b16c, "WRITE_SIZE")
+        ff, wf = _counter(f32c, "FETCH_SIZE"), _counter(f32c, "WRITE_SIZE")
+        L.append("| `%s`, `%s` | SQ / TCC counters of the two tiled gathers at config-4 geometry.  `gather_mfma_kernel`: %s MFMAs, `SQ_WAIT_ANY` %s of %s wave-cycles, "
+                 "`SQ_LDS_IDX_ACTIVE` %s (bank conflicts %s), L2 requests %s (misses %s), traffic 2×FETCH + WRITE = %s against 293.8 MB = %s.  `gather_tiled_kernel`: "
+                 "`SQ_INSTS_VALU` %s, `SQ_LDS_IDX_ACTIVE` %s, `SQ_WAIT_INST_LDS` %s, traffic %s against 483.9 MB = %s | `sh tools/gather_pmc.sh` |" % (
+                     f32c, b16c, mm(b16c, "SQ_INSTS_MFMA"), mm(b16c, "SQ_WAIT_ANY"), mm(b16c, "SQ_WAVE_CYCLES"), mm(b16c, "SQ_LDS_IDX_ACTIVE"),
+                     mm(b16c, "SQ_LDS_BANK_CONFLICT"), mm(b16c, "TCC_REQ_sum"), mm(b16c, "TCC_MISS_sum"),
+                     ("%.1f MB" % ((2 * fs + ws) * 1024 / 1e6)) if fs and ws else "n/a", ("%.2f×" % ((2 * fs + ws) * 1024 / 293830656.0)) if fs and ws else "n/a",
+                     mm(f32c, "SQ_INSTS_VALU"), mm(f32c, "SQ_LDS_IDX_ACTIVE"), mm(f32c, "SQ_WAIT_INST_LDS"),
+                     ("%.1f MB" % ((2 * ff + wf) * 1024 / 1e6)) if ff and wf else "n/a", ("%.2f×" % ((2 * ff + wf) * 1024 / 483852288.0)) if ff and wf else "n/a"))
+    fixed = [
+        (t + "_probe_gather_mfma2.txt", "the round's re-cut of the bf16 dense gather (`gather_mfma2_kernel`: LDS-DMA requests as assembly statements with counted waits, three stage "
+         "buffers, blend waves, per-level product loops), eight cuts with their timing probes and the per-phase clock trace: bit-identical to round 5's kernel and 3–4 % slower; what "
+         "the two share (70 µs of L1 fetches whatever the staging, 27 µs of window scatter on the LDS store path, 16 + 16 µs of blend arithmetic and tap stores wherever they run)",
+         "`tools/history/r6_call3.sh` … `r6_call9.sh`, `tools/g2_trace.py`, `tools/gather_dump.py`"),
+        (t + "_probe_token_mix_mfma_phases.txt", "shader-clock stamps of `token_mix_mfma_kernel<true>` at 2048 particles: the 16 channel slots (3 MFMAs + 256 GELUs per lane) are "
+         "%s of the wave's %s -- vector-ALU bound (3 600 instructions per wave, two waves per SIMD)" % (
+             _grep(t + "_probe_token_mix_mfma_phases.txt", r"16 channel slots[^\n]*?=\s+([0-9.]+ us)"), _grep(t + "_probe_token_mix_mfma_phases.txt", r"start -> stores issued[^\n]*?=\s+([0-9.]+ us)")),
+         "`tools/token_trace_bf16.py` on a `-DPIPS_TOKEN_TRACE` build"),
+        (t + "_probe_gather_final.txt", "`tools/gather_c4.py` on the final library: the three launches of both tiled gathers at config-4 geometry and the config-3 comparison "
+         "(direct bf16-map kernel against the tiled matrix-core path)", "`python tools/gather_c4.py`"),
+        (t + "_rccl_one_rank.log", "`tests/test_dist_gpu.py::test_rccl_one_rank`: `init_process_group(\"nccl\", world_size=1)` on the 1-GPU box -- every collective of "
+         "`pips_amd.dist` through RCCL on device tensors, bit-equal to the plain forward", "`pytest -m gpu -k rccl_one_rank`"),
+    ]
+    for name, what, cmd in fixed:
+        if os.path.exists(os.path.join(P, name)):
+            L.append("| `%s` | %s | %s |" % (name, what, cmd))
+    if os.path.exists(os.path.join(P, t + "_pytest_gpu.log")):
+        last = [l for l in open(os.path.join(P, t + "_pytest_gpu.log")).read().splitlines() if " passed" in l]
+        L.append("| `%s_pytest_gpu.log` | `pytest -m gpu` of the final code: %s | |" % (t, last[-1].strip() if last else "n/a"))
+    return "\n".join(L) + "\n"
+
+
+def main(argv):
+    r = 6
+    if "--round" in argv:
+        r = int(argv[argv.index("--round") + 1])
+    begin, end = "<!-- r%d:begin -->" % r, "<!-- r%d:end -->" % r
+    path = os.path.join(P, "README.md")
+    txt = open(path).read()
+    block = begin + "\n" + section(r) + end + "\n"
+    if begin in txt:
+        new = txt[:txt.index(begin)] + block + txt[txt.index(end) + len(end) + 1:]
+    else:
+        head, rest = txt.split("\n", 2)[0], txt.split("\n", 2)[2] if txt.count("\n") >= 2 else ""
+        new = head + "\n\n" + block + "\n" + rest
+    if "--check" in argv:
+        if new != txt:
+            print("profiles/README.md: the round-%d block is not what tools/profiles_readme.py generates from the files" % r)
+            return 1
+        return 0
+    open(path, "w").write(new)
+    print("wrote", path)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
