@@ -149,7 +149,8 @@ def test_bf16_mode_dense_query_set_agrees_with_its_particle_shards(weights_tamed
     features to bf16 (nets/pips.py:394-397 casts both matmul operands).  One clip, a 2304-point grid on 46 x 62 maps under autocast:
     the whole set (route 2 asserted) against its sixteen shards of 144 (route 0 asserted), same cached maps.  What is left is the
     order of the fp32 sums in the gather (<= 1e-4 per tap, tests/test_kernels_gpu.py) and, from the second iteration on, what the
-    bf16 mixer makes of a tap that rounds the other way: printed, gated at a quarter of the bf16 mode's own 2e-2 px budget."""
+    bf16 mixer makes of a tap that rounds the other way (its in-projection rounds X to bf16: already in the first iterate): printed, gated at
+    half of the bf16 mode's own 2e-2 px budget."""
     from pips_amd import Pips, _lib
     lib = _lib.load()
     B, H, W, N, G = 1, 368, 496, 2304, 16                     # a 48 x 48 grid, 144 queries per shard
@@ -170,7 +171,7 @@ def test_bf16_mode_dense_query_set_agrees_with_its_particle_shards(weights_tamed
     ev = float((whole[2] - torch.cat([p[2] for p in parts], dim=2)).abs().max())
     print(f"bf16 mode, dense set (matrix-core gather) vs its 16 particle shards (direct gather): first iterate {e1:.2e} px, after 6 "
           f"iterations {e6:.2e} px, vis logits {ev:.2e}")
-    assert e1 < 2e-3 and e6 < 5e-3 and ev < 5e-2
+    assert e1 < 4e-3 and e6 < 1e-2 and ev < 5e-2          # measured 1.2e-3 / 4.5e-3 / 7.5e-3 (profiles/r6_bf16_parity_tests.log)
 
 
 def test_config4_teacher_forced_iteration(weights_raw):

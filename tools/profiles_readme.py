@@ -187,6 +187,12 @@ def section(r):
          "`tools/token_trace_bf16.py` on a `-DPIPS_TOKEN_TRACE` build"),
         (t + "_probe_gather_final.txt", "`tools/gather_c4.py` on the final library: the three launches of both tiled gathers at config-4 geometry and the config-3 comparison "
          "(direct bf16-map kernel against the tiled matrix-core path)", "`python tools/gather_c4.py`"),
+        (t + "_bf16_parity_tests.log", "`pytest -s` output of the bf16 parity tests on the one-rounding-contract build: configs[2] %s px against the autocast oracle, config-4 geometry "
+         "%s px, dense query set against its particle shards %s px after six iterations" % (
+             _grep(t + "_bf16_parity_tests.log", r"config 3 geometry \(B=8[^\n]*?autocast oracle ([0-9.e+-]+) px"),
+             _grep(t + "_bf16_parity_tests.log", r"end to end[^\n]*?autocast oracle ([0-9.e+-]+) px"),
+             _grep(t + "_bf16_parity_tests.log", r"after 6 iterations ([0-9.e+-]+) px")),
+         "`pytest tests/test_config3_gpu.py tests/test_config45_gpu.py -s -k \"config3 or bf16\"`"),
         (t + "_rccl_one_rank.log", "`tests/test_dist_gpu.py::test_rccl_one_rank`: `init_process_group(\"nccl\", world_size=1)` on the 1-GPU box -- every collective of "
          "`pips_amd.dist` through RCCL on device tensors, bit-equal to the plain forward", "`pytest -m gpu -k rccl_one_rank`"),
     ]
