@@ -245,3 +245,19 @@ def test_profiles_readme_is_generated_from_the_files():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "profiles_readme.py"), "--check"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_gather_mfma2_variant_builds_and_passes_the_lint(tmp_path):
+    """gather_mfma2_kernel (round 6's re-cut of the bf16 dense gather: LDS-DMA requests as assembly statements with counted waits) is not in
+    the product library -- it is 3-4 % slower than gather_mfma_kernel -- but stays buildable for A/B runs (-DPIPS_GM_V_DEFAULT=2): the variant
+    object compiles for gfx950 and its hand-written request statements hold their wait states (M0 -> LDS-DMA, fresh SGPR -> vector memory)."""
+    import subprocess
+    L, root = _lint()
+    from pips_amd import _build
+    obj = tmp_path / "gather_gm2.o"
+    cmd = [_build._hipcc(), *_build.FLAGS, "-DPIPS_GM_V_DEFAULT=2", "-c", os.path.join(_build.CSRC, "gather_tiled.hip"), "-o", str(obj)]
+    subprocess.check_call(cmd)
+    findings, st = L.lint_path(str(obj))
+    assert st["kernels"] >= 6 and findings == [], findings[:5]
+    dis = "\n".join(L.disassemble(str(obj)))
+    assert "gather_mfma2_kernel" in dis and dis.count("offen lds") >= 16        # the requests are there (two blocks of eight pieces + records)
