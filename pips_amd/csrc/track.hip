@@ -533,7 +533,10 @@ __device__ __forceinline__ void ln_stats2(const f2 (&x)[S], float (&mean)[S], fl
 #ifdef PIPS_TOKEN_TRACE
 // tools/token_trace.py (variant build): shader-clock stamps of block 0 .. 255 at the kernel's phases
 __device__ unsigned long long g_token_trace[256 * 8];
-#define PIPS_TT(k) if (threadIdx.x == 0 && blockIdx.x < 256) g_token_trace[blockIdx.x * 8 + (k)] = clock64();
+// (stamps 0..5: shader clock, s_memtime; 6 / 7: the constant 100 MHz clock, s_memrealtime, at stamps 0 / 5 -- their ratio is the clock the
+// kernel actually ran at, and the real-time stamps are comparable across compute units)
+#define PIPS_TT(k) if (threadIdx.x == 0 && blockIdx.x < 256) { g_token_trace[blockIdx.x * 8 + (k)] = clock64(); \
+    if ((k) == 0) g_token_trace[blockIdx.x * 8 + 6] = wall_clock64(); if ((k) == 5) g_token_trace[blockIdx.x * 8 + 7] = wall_clock64(); }
 extern "C" int pips_debug_token_trace(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_token_trace), sizeof(unsigned long long) * 256 * 8);
 }
@@ -622,6 +625,31 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
 // lane's own four tokens again: no cross-lane traffic between the three products.  LayerNorm statistics in one pass
 // (sum, sum of squares; the operands are rounded to bf16 anyway), fp32 residual stream.
 typedef __bf16 bf16x8_tm __attribute__((ext_vector_type(8)));
+
+// 8-byte store of the token-mix outputs, written through the compute die's L2 (sc1: agent scope).  The kernel leaves 33.5 MB at configs[2]
+// (residual stream + LayerNorm-2 output), all of it read next by OTHER dies' L2s -- as dirty lines they are written back when the kernel ends,
+// after its last wave; written through they leave while the waves still compute: 21.5 -> 20.6 us per launch, 1.262 -> 1.249 ms per mixer pass
+// [measured, profiles/r6_probe_store_policy.txt; the same bit on the two GEMMs' output stores: no change, nt / sc0 sc1 nt: +3 %].
+// PIPS_TM_STORE (variant builds, tools/tm_store_ab.sh): 0 plain, 1 the nontemporal builtin, 2 sc1 (product), 3 sc0 sc1, 4 nt, 5 sc0 sc1 nt.
+#ifndef PIPS_TM_STORE
+#define PIPS_TM_STORE 2
+#endif
+__device__ __forceinline__ void tm_store8(void* p, uint2 v) {
+    const unsigned long long q = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+#if PIPS_TM_STORE == 0
+    *reinterpret_cast<uint2*>(p) = v;
+#elif PIPS_TM_STORE == 1
+    __builtin_nontemporal_store(q, reinterpret_cast<unsigned long long*>(p));
+#elif PIPS_TM_STORE == 2
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+#elif PIPS_TM_STORE == 3
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(q) : "memory");
+#elif PIPS_TM_STORE == 4
+    asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(q) : "memory");
+#else
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(q) : "memory");
+#endif
+}
 
 // One WAVE per particle (round 3, second cut: a 256-thread block per particle spent its time in four block-wide
 // reductions and the memory round trips between them -- 30.5 us at 2048 particles against 35 for the VALU kernel): the
@@ -757,7 +785,7 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
             if (XB) {
                 // the stored stream is what every later reader sees: LayerNorm 2 below works on the ROUNDED values too
                 const uint2 o = make_uint2(pack2_bf16(xv[r][4 * g], xv[r][4 * g + 1]), pack2_bf16(xv[r][4 * g + 2], xv[r][4 * g + 3]));
-                *reinterpret_cast<uint2*>(xh + r * PIPS_DMIX + g * 128) = o;
+                tm_store8(xh + r * PIPS_DMIX + g * 128, o);
                 xv[r][4 * g] = bf16_lo(o.x); xv[r][4 * g + 1] = bf16_hi(o.x); xv[r][4 * g + 2] = bf16_lo(o.y); xv[r][4 * g + 3] = bf16_hi(o.y);
             } else {
                 *reinterpret_cast<float4*>(xp + r * PIPS_DMIX + g * 128) = make_float4(xv[r][4 * g], xv[r][4 * g + 1], xv[r][4 * g + 2], xv[r][4 * g + 3]);
@@ -778,7 +806,7 @@ __global__ __launch_bounds__(256, 2) void token_mix_mfma_kernel(const float* __r
             float n[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) n[q] = (xv[r][4 * g + q] - mean[r]) * (rstd[r] * g2a[q]) + be2a[q];
-            *reinterpret_cast<uint2*>(xnp + r * (PIPS_DMIX / 2) + g * 64) = make_uint2(pack2_bf16(n[0], n[1]), pack2_bf16(n[2], n[3]));
+            tm_store8(xnp + r * (PIPS_DMIX / 2) + g * 64, make_uint2(pack2_bf16(n[0], n[1]), pack2_bf16(n[2], n[3])));
         }
     }
     PIPS_TT(5)

@@ -1,5 +1,5 @@
 """Shader clock and power under a sustained kernel: loops one workload for a few seconds while rocm-smi is sampled.
-usage: python tools/clock_probe.py gemm16384 | gemm2048 | conv64 | idle"""
+usage: python tools/clock_probe.py gemm16384 | gemm2048 | conv64 | mixerbf16_16384 | idle"""
 import os, sys, subprocess, threading, time, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,6 +21,14 @@ elif what == "conv64":
     b = torch.randn(64, generator=g).to(dev)
     fn = lambda: ops.conv_nhwc(x, w, b, 3, 1, 1, want_stats=True)
     flops = 2.0 * 8 * 184 * 248 * 64 * 576
+elif what.startswith("mixerbf16_"):
+    # the bf16 mixer pass of BASELINE configs[2] (M rows; 12 x {token mix, up-projection + GELU, down-projection + residual})
+    from pips_amd.weights import init_state_dict
+    M = int(what.split("_")[1])
+    arena = ops.pack_weights(init_state_dict(0), torch.device(dev), sections=ops.PACK_FP32 | ops.PACK_BF16)
+    X = torch.randn(M, 544, generator=g).to(dev)
+    fn = lambda: ops.mixer_fwd(arena, X, bf16=True, stream_bf16=True)
+    flops = 2.0 * M * (544 * 512 + 12 * (2 * 512 * 2048 + 2 * 8 * 32 * 512 / 8) + 512 * 130)
 else:
     fn, flops = None, 0.0
 samples = []

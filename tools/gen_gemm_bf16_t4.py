@@ -24,6 +24,7 @@ import asm_guards as G  # noqa: E402  (wait-state guards: the numbers live in to
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "gemm_bf16_t4_asm.inc"))
+POLICY = os.environ.get("PIPS_GEN_STORE_POLICY", "")      # tuning builds: cache-policy bits of the output stores, e.g. " sc1"
 
 FA = [0, 48]          # A fragment base register of K step 0 / 1
 FW = [16, 64]
@@ -252,10 +253,10 @@ def body(stream_bf16=False):
             if stream_bf16:
                 e.raw("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (r, r, r + 1))
                 e.raw("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (r + 1, r + 2, r + 3))
-                e.vmem("buffer_store_dwordx2 v[%d:%d], %%[voC], s[%d:%d], s%d offen offset:%d" % (r, r + 1, RS_C, RS_C + 3, S_CR + i, 32 * j),
+                e.vmem("buffer_store_dwordx2 v[%d:%d], %%[voC], s[%d:%d], s%d offen offset:%d" % (r, r + 1, RS_C, RS_C + 3, S_CR + i, 32 * j) + POLICY,
                        ("out", i, j))
             else:
-                e.vmem("buffer_store_dwordx4 v[%d:%d], %%[voC], s[%d:%d], s%d offen offset:%d" % (r, r + 3, RS_C, RS_C + 3, S_CR + i, 64 * j),
+                e.vmem("buffer_store_dwordx4 v[%d:%d], %%[voC], s[%d:%d], s%d offen offset:%d" % (r, r + 3, RS_C, RS_C + 3, S_CR + i, 64 * j) + POLICY,
                        ("out", i, j))
         if j >= 1:
             e.need_vm({("out", i, j - 1) for i in range(4)})   # the other register set is free again
