@@ -544,6 +544,32 @@ extern "C" int pips_debug_token_trace(unsigned long long* out) {
 #define PIPS_TT(k)
 #endif
 
+// 8-byte store of the token-mix outputs, written through the compute die's L2 (sc1: agent scope).  The kernel leaves 33.5 MB at configs[2]
+// (residual stream + LayerNorm-2 output), all of it read next by OTHER dies' L2s -- as dirty lines they are written back when the kernel ends,
+// after its last wave; written through they leave while the waves still compute: 21.5 -> 20.6 us per launch, 1.262 -> 1.249 ms per mixer pass
+// [measured, profiles/r6_probe_store_policy.txt; the same bit on the two GEMMs' output stores: no change, nt / sc0 sc1 nt: +3 %; in the exact-fp32
+// mixer at M = 2048 (8.4 MB per launch) it changes nothing on token_mix_kernel and costs the up-projection 1.7 us: r6_probe_store_policy_fp32.txt].
+// PIPS_TM_STORE (variant builds, tools/tm_store_ab.sh): 0 plain, 1 the nontemporal builtin, 2 sc1 (product), 3 sc0 sc1, 4 nt, 5 sc0 sc1 nt.
+#ifndef PIPS_TM_STORE
+#define PIPS_TM_STORE 2
+#endif
+__device__ __forceinline__ void tm_store8(void* p, uint2 v) {
+    const unsigned long long q = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+#if PIPS_TM_STORE == 0
+    *reinterpret_cast<uint2*>(p) = v;
+#elif PIPS_TM_STORE == 1
+    __builtin_nontemporal_store(q, reinterpret_cast<unsigned long long*>(p));
+#elif PIPS_TM_STORE == 2
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+#elif PIPS_TM_STORE == 3
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(q) : "memory");
+#elif PIPS_TM_STORE == 4
+    asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(q) : "memory");
+#else
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(q) : "memory");
+#endif
+}
+
 template <bool XN_BF16>
 __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict__ arena, MixLayerW L,
                                                         float* __restrict__ x, float* __restrict__ xn) {
@@ -625,31 +651,6 @@ __global__ __launch_bounds__(256) void token_mix_kernel(const float* __restrict_
 // lane's own four tokens again: no cross-lane traffic between the three products.  LayerNorm statistics in one pass
 // (sum, sum of squares; the operands are rounded to bf16 anyway), fp32 residual stream.
 typedef __bf16 bf16x8_tm __attribute__((ext_vector_type(8)));
-
-// 8-byte store of the token-mix outputs, written through the compute die's L2 (sc1: agent scope).  The kernel leaves 33.5 MB at configs[2]
-// (residual stream + LayerNorm-2 output), all of it read next by OTHER dies' L2s -- as dirty lines they are written back when the kernel ends,
-// after its last wave; written through they leave while the waves still compute: 21.5 -> 20.6 us per launch, 1.262 -> 1.249 ms per mixer pass
-// [measured, profiles/r6_probe_store_policy.txt; the same bit on the two GEMMs' output stores: no change, nt / sc0 sc1 nt: +3 %].
-// PIPS_TM_STORE (variant builds, tools/tm_store_ab.sh): 0 plain, 1 the nontemporal builtin, 2 sc1 (product), 3 sc0 sc1, 4 nt, 5 sc0 sc1 nt.
-#ifndef PIPS_TM_STORE
-#define PIPS_TM_STORE 2
-#endif
-__device__ __forceinline__ void tm_store8(void* p, uint2 v) {
-    const unsigned long long q = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
-#if PIPS_TM_STORE == 0
-    *reinterpret_cast<uint2*>(p) = v;
-#elif PIPS_TM_STORE == 1
-    __builtin_nontemporal_store(q, reinterpret_cast<unsigned long long*>(p));
-#elif PIPS_TM_STORE == 2
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
-#elif PIPS_TM_STORE == 3
-    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(q) : "memory");
-#elif PIPS_TM_STORE == 4
-    asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(q) : "memory");
-#else
-    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(q) : "memory");
-#endif
-}
 
 // One WAVE per particle (round 3, second cut: a 256-thread block per particle spent its time in four block-wide
 // reductions and the memory round trips between them -- 30.5 us at 2048 particles against 35 for the VALU kernel): the

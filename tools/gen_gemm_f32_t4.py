@@ -42,6 +42,7 @@ import struct
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "gemm_f32_t4_asm.inc"))
+POLICY = os.environ.get("PIPS_GEN_STORE_POLICY", "")      # tuning builds: cache-policy bits of the output stores, e.g. " sc1"
 
 LDROW = 144                         # LDS row stride in bytes
 FA = [0, 16]
@@ -382,7 +383,7 @@ def epilogue_u(e, sh, epi):
                                   (X + 4 * h + 2 * p, X + 4 * h + 2 * p + 1, X + 4 * h + 2 * p, X + 4 * h + 2 * p + 1, r + 2 * p, r + 2 * p + 1))
                 for h in range(2):
                     e.vmem("buffer_store_dwordx4 v[%d:%d], %%[voC], s[%d:%d], s%d offen offset:%d" %
-                           (X + 4 * h, X + 4 * h + 3, RS_C, RS_C + 3, S_CR + i, (32 * j + 8 * (2 * qq + h)) * 4), ("out", k))
+                           (X + 4 * h, X + 4 * h + 3, RS_C, RS_C + 3, S_CR + i, (32 * j + 8 * (2 * qq + h)) * 4) + POLICY, ("out", k))
                 k += 1
     # the next tile's rows of C / R (scalar writes: the stores in flight have read their descriptor)
     e.raw("s_add_u32 s%d, s%d, %%[tstepC]" % (RS_C, RS_C))
@@ -425,7 +426,7 @@ def epilogue_d(e, sh):
                 e.raw("v_pk_add_f32 v[%d:%d], v[%d:%d], v[%d:%d]" % (X + 2 * p, X + 2 * p + 1, X + 2 * p, X + 2 * p + 1, b + 2 * p, b + 2 * p + 1))
             for p in range(2):
                 e.raw("v_pk_add_f32 v[%d:%d], v[%d:%d], v[%d:%d]" % (O + 2 * p, O + 2 * p + 1, X + 2 * p, X + 2 * p + 1, rr + 2 * p, rr + 2 * p + 1))
-            e.vmem("buffer_store_dwordx4 v[%d:%d], %%[voC], s[%d:%d], 0 offen offset:%d" % (O, O + 3, RS_C, RS_C + 3, 32 * q), ("out", q))
+            e.vmem("buffer_store_dwordx4 v[%d:%d], %%[voC], s[%d:%d], 0 offen offset:%d" % (O, O + 3, RS_C, RS_C + 3, 32 * q) + POLICY, ("out", q))
 
 
 def body(shape, epi):

@@ -11,6 +11,6 @@ for v in product "$@" product; do
     python tools/tm_store_ab.py 2>/dev/null | grep "ms per mixer pass" >> $OUT
     rm -rf /tmp/tmab && rocprofv3 --kernel-trace --stats -d /tmp/tmab -o r -- python tools/tm_store_ab.py > /tmp/tmab.log 2>&1
     for f in $(find /tmp/tmab -name "*.db"); do python tools/rocpd_summary.py $f /tmp/tmab_stats.txt > /dev/null; done
-    grep -E "token_mix|gemm_bf16_t4|ln_mean" /tmp/tmab_stats.txt | cut -c1-60,110-160 | sed 's/^/    /' >> $OUT
+    grep -E "token_mix|gemm_bf16_t4|gemm_f32_t4|ln_mean" /tmp/tmab_stats.txt | cut -c1-60,110-160 | sed 's/^/    /' >> $OUT
 done
 cat $OUT
