@@ -25,6 +25,7 @@ import struct
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "gemm_bf16_t4up_asm.inc"))
+ABL = os.environ.get("PIPS_GEN_ABLATE", "")                 # timing probes (wrong results): gelu = no GELU arithmetic in the epilogue
 POLICY = os.environ.get("PIPS_GEN_STORE_POLICY", "")      # tuning builds: cache-policy bits of the output stores, e.g. " sc1"
 
 NI, NJ = 8, 8                       # 16-row / 16-column blocks of the wave tile
@@ -244,7 +245,8 @@ def epilogue(e):
             for p in range(4):
                 e.raw("v_lshlrev_b32 v%d, 16, v%d" % (X + 2 * p, O + p))
                 e.raw("v_and_b32 v%d, 0xffff0000, v%d" % (X + 2 * p + 1, O + p))
-            gelu4(e, X, T, Q)
+            if "gelu" not in ABL:
+                gelu4(e, X, T, Q)
             for p in range(4):
                 e.raw("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (O + p, X + 2 * p, X + 2 * p + 1))
             e.vmem("buffer_store_dwordx4 v[%d:%d], %%[voC], s[%d:%d], s%d offen offset:%d" % (O, O + 3, RS_C, RS_C + 3, S_CR + i, jp * 64) + POLICY,

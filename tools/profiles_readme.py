@@ -185,6 +185,22 @@ def section(r):
          "%s of the wave's %s -- vector-ALU bound (3 600 instructions per wave, two waves per SIMD)" % (
              _grep(t + "_probe_token_mix_mfma_phases.txt", r"16 channel slots[^\n]*?=\s+([0-9.]+ us)"), _grep(t + "_probe_token_mix_mfma_phases.txt", r"start -> stores issued[^\n]*?=\s+([0-9.]+ us)")),
          "`tools/token_trace_bf16.py` on a `-DPIPS_TOKEN_TRACE` build"),
+        (t + "_probe_shader_clock.txt", "the same stamps beside `s_memrealtime` (100 MHz): the clock `token_mix_mfma_kernel` actually runs at in a sustained bf16 mixer pass -- %s GHz "
+         "(after 300 passes; 1.68 GHz for the first launches after idle), a wave %s of real time" % (
+             _grep(t + "_probe_shader_clock.txt", r"after 300 more passes: shader clock ([0-9.]+) GHz"), _grep(t + "_probe_shader_clock.txt", r"after 300 more passes:[^\n]*?wave ([0-9.]+ us)")),
+         "`tools/token_trace_bf16.py` (`tools/history/r6_call14.sh`)"),
+        (t + "_probe_clock_power_bf16.txt", "`rocm-smi` sampled under the bf16 mixer pass at configs[2]'s M = 16384: sclk %s MHz at %s W of the 1400 W package limit "
+         "(the exact-fp32 GEMM loop beside it: 2395 MHz; the same pass at M = 2048: 2400 MHz at 0.92 kW) -- configs[2] is power-limited" % (
+             _grep(t + "_probe_clock_power_bf16.txt", r"sclk clock level: 1: \((\d+)Mhz\)"), _grep(t + "_probe_clock_power_bf16.txt", r"Package Power \(W\): ([0-9.]+)")),
+         "`python tools/clock_probe.py mixerbf16_16384` (`tools/history/r6_call17.sh`)"),
+        (t + "_probe_store_policy.txt", "cache-policy bits on the output stores of the bf16 mixer's three kernels (variant builds), 200 mixer passes each under rocprofv3: `sc1` "
+         "(write through at agent scope) on `token_mix_mfma_kernel`'s stores 21.5 → 20.6 µs per launch and 1.262 → 1.249 ms per pass (the product since); on the two GEMMs' stores "
+         "no change; `nt` +3 %.  `_fp32.txt`: the same in the exact-fp32 mixer at M = 2048 -- no gain, stays plain", "`sh tools/tm_store_ab.sh tms2 gup gres gboth gall` (`r6_call16.sh`, `r6_call18.sh`)"),
+        (t + "_probe_t4up_without_gelu.txt", "timing probe: `gemm_bf16_t4_gelu_kernel` without the GELU arithmetic of its epilogue (wrong results) %s against %s µs -- what "
+         "overlapping the epilogue with the next tile's K loop could win at most" % (
+             _grep(t + "_probe_t4up_without_gelu.txt", r"libpips_nogelu[^\n]*\n[^\n]*gemm_bf16_t4_gelu_kernel[^\n]*?\s([0-9.]+)\s+[0-9.]+\n"),
+             _grep(t + "_probe_t4up_without_gelu.txt", r"product[^\n]*\n[^\n]*gemm_bf16_t4_gelu_kernel[^\n]*?\s([0-9.]+)\s+[0-9.]+\n")),
+         "`PIPS_GEN_ABLATE=gelu python tools/gen_gemm_bf16_t4up.py` (`tools/history/r6_call19.sh`)"),
         (t + "_probe_gather_final.txt", "`tools/gather_c4.py` on the final library: the three launches of both tiled gathers at config-4 geometry and the config-3 comparison "
          "(direct bf16-map kernel against the tiled matrix-core path)", "`python tools/gather_c4.py`"),
         (t + "_bf16_parity_tests.log", "`pytest -s` output of the bf16 parity tests on the one-rounding-contract build: configs[2] %s px against the autocast oracle, config-4 geometry "
