@@ -974,6 +974,51 @@ __global__ __launch_bounds__(256) void ln_mean_kernel(const float* __restrict__ 
     out[(size_t)blockIdx.x * PIPS_DMIX + c1] = a1 * (1.0f / S);
 }
 
+// The same on the bf16 residual stream with one WAVE per particle (BASELINE configs[2]: 2048 particles, where the block form above spent
+// 16 us on 2-byte loads and four block-wide reductions): a lane holds 8 tokens x 8 channels -- 16-byte loads, a token row is the wave's 64
+// lanes -- and both LayerNorm passes are wave_sum8 transposes: no LDS, no barrier.  [measured] profiles/r6_probe_ln_mean_wave.txt
+__global__ __launch_bounds__(256) void ln_mean_wave_kernel(const unsigned short* __restrict__ x, const float* __restrict__ g,
+                                                           const float* __restrict__ bta, float* __restrict__ out, int particles) {
+    const int lane = threadIdx.x & 63, p = blockIdx.x * 4 + (threadIdx.x >> 6);      // (wave-uniform)
+    if (p >= particles) return;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)p * S * PIPS_DMIX) + lane;
+    float v[S][8], a[S], mean[S], rstd[S];
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        const uint4 q = xr[t * (PIPS_DMIX / 8)];
+        v[t][0] = bf16_lo(q.x); v[t][1] = bf16_hi(q.x); v[t][2] = bf16_lo(q.y); v[t][3] = bf16_hi(q.y);
+        v[t][4] = bf16_lo(q.z); v[t][5] = bf16_hi(q.z); v[t][6] = bf16_lo(q.w); v[t][7] = bf16_hi(q.w);
+    }
+    const float4 g0 = *reinterpret_cast<const float4*>(g + 8 * lane), g1 = *reinterpret_cast<const float4*>(g + 8 * lane + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(bta + 8 * lane), b1 = *reinterpret_cast<const float4*>(bta + 8 * lane + 4);
+#pragma unroll
+    for (int t = 0; t < S; ++t) a[t] = ((v[t][0] + v[t][1]) + (v[t][2] + v[t][3])) + ((v[t][4] + v[t][5]) + (v[t][6] + v[t][7]));
+    const float m = wave_sum8(a) * (1.0f / PIPS_DMIX);                                // lane l: token l & 7
+#pragma unroll
+    for (int t = 0; t < S; ++t) mean[t] = lane_bcast(m, t);
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[t][k] - mean[t]; q = fmaf(d, d, q); }
+        a[t] = q;
+    }
+    const float r = rsqrt_nr(wave_sum8(a) * (1.0f / PIPS_DMIX) + 1e-5f);
+#pragma unroll
+    for (int t = 0; t < S; ++t) rstd[t] = lane_bcast(r, t);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < S; ++t) s = fmaf(v[t][k] - mean[t], rstd[t], s);
+        acc[k] = s * (1.0f / S);
+    }
+    float* op = out + (size_t)p * PIPS_DMIX + 8 * lane;
+    *reinterpret_cast<float4*>(op) = make_float4(fmaf(acc[0], g0.x, b0.x), fmaf(acc[1], g0.y, b0.y), fmaf(acc[2], g0.z, b0.z), fmaf(acc[3], g0.w, b0.w));
+    *reinterpret_cast<float4*>(op + 4) = make_float4(fmaf(acc[4], g1.x, b1.x), fmaf(acc[5], g1.y, b1.y), fmaf(acc[6], g1.z, b1.z), fmaf(acc[7], g1.w, b1.w));
+}
+
 // any window length: nn.LayerNorm(512) per token, mean over the Sw tokens
 template <int SMAX>
 __global__ __launch_bounds__(256) void ln_mean_any_kernel(const float* __restrict__ x, const float* __restrict__ g,
@@ -1001,7 +1046,9 @@ int launch_ln_mean(const float* x, const float* g, const float* b, float* out, i
         PIPS_CHECK_LAUNCH("ln_mean_any_kernel");
         return PIPS_OK;
     }
-    if (x_bf16) hipLaunchKernelGGL(ln_mean_kernel<true>, dim3(particles), dim3(256), 0, st, x, g, b, out);
+    if (x_bf16 && PIPS_TUNE("PIPS_LN_MEAN_WAVE", 1))
+        hipLaunchKernelGGL(ln_mean_wave_kernel, dim3(cdiv(particles, 4)), dim3(256), 0, st, reinterpret_cast<const unsigned short*>(x), g, b, out, particles);
+    else if (x_bf16) hipLaunchKernelGGL(ln_mean_kernel<true>, dim3(particles), dim3(256), 0, st, x, g, b, out);
     else hipLaunchKernelGGL(ln_mean_kernel<false>, dim3(particles), dim3(256), 0, st, x, g, b, out);
     PIPS_CHECK_LAUNCH("ln_mean_kernel");
     return PIPS_OK;
