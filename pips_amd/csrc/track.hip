@@ -1058,7 +1058,12 @@ int launch_ln_mean(const float* x, const float* g, const float* b, float* out, i
 // nets/pips.py:525-539: ffeats += GELU(Linear(GroupNorm(1,128)(dfeat))); coords += dcoord;
 // frame 0 locked to the query; trajectory written in pixels as (B,S,N,2).  Optionally the
 // visibility head Linear(128->1) on the NEW features (:559).  One block per particle.
-__global__ __launch_bounds__(256) void state_update_kernel(const float* __restrict__ arena,
+// Thread = output channel o x ALL 8 rows (128 threads): every weight is fetched once per block (the 256-thread form fetched it in two
+// waves, and its 128 four-byte loads per thread were as long as its FMAs: 1 MB through each compute unit's L1 per launch at BASELINE
+// configs[2]), two rows per v_pk_fma_f32, the old features requested before the product.  Same operations in the same order as before
+// (acc = fma(h, w, acc) over ascending k; LayerNorm by 32 lanes x 4 channels per row): results are bit-identical.
+// [measured] profiles/r6_probe_state_update.txt
+__global__ __launch_bounds__(128) void state_update_kernel(const float* __restrict__ arena,
                                                            size_t o_ng, size_t o_nb, size_t o_wt, size_t o_b,
                                                            size_t o_wv, size_t o_bv,
                                                            const float* __restrict__ delta,
@@ -1066,25 +1071,32 @@ __global__ __launch_bounds__(256) void state_update_kernel(const float* __restri
                                                            const float* __restrict__ coords0, int N, float stride,
                                                            float* __restrict__ out_traj, float* __restrict__ out_vis) {
     __shared__ __attribute__((aligned(16))) float hs[C][S];      // normalised dfeat, [k][row]
-    __shared__ float vred[4][4];
+    __shared__ float vred[2][S];
     const int pn = blockIdx.x, tid = threadIdx.x;
     const int b = pn / N, n = pn - b * N;
     const float* dp = delta + (size_t)pn * PIPS_NOUT;
+    const int o = tid;
 
-    // LayerNorm over the 128 delta-feature channels of each of the 8 rows
-    {
-        const int row = tid >> 5, l = tid & 31;
+    // the old features are requested first: their round trip runs under the LayerNorm and the product
+    float fold[S];
+#pragma unroll
+    for (int r = 0; r < S; ++r) fold[r] = ffeats[((size_t)pn * S + r) * C + o];
+
+    // LayerNorm over the 128 delta-feature channels of each of the 8 rows (four rows at a time: 32 lanes x 4 channels per row)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row = half * 4 + (tid >> 5), l = tid & 31;
         const float* d = dp + row * (C + 2) + 2 + l * 4;
         float v[4] = {d[0], d[1], d[2], d[3]};
         float sum = (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        for (int of = 16; of >= 1; of >>= 1) sum += __shfl_xor(sum, of);
         const float mean = sum * (1.0f / C);
         float sq = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const float t = v[k] - mean; sq += t * t; }
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+        for (int of = 16; of >= 1; of >>= 1) sq += __shfl_xor(sq, of);
         const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1095,26 +1107,30 @@ __global__ __launch_bounds__(256) void state_update_kernel(const float* __restri
     __syncthreads();
 
     // Linear 128->128 (weights transposed [k][o]) + GELU + residual
-    const int o = tid & 127, r0 = (tid >> 7) * 4;
-    float acc[4];
     const float bo = arena[o_b + o];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = bo;
+    f2 a[4] = {{bo, bo}, {bo, bo}, {bo, bo}, {bo, bo}};          // rows (0,1) (2,3) (4,5) (6,7)
     const float* wt = arena + o_wt + o;
 #pragma unroll 8
-    for (int k = 0; k < C; ++k) {
-        const float w = wt[(size_t)k * C];
-        const float4 h = *reinterpret_cast<const float4*>(&hs[k][r0]);
-        acc[0] = fmaf(h.x, w, acc[0]); acc[1] = fmaf(h.y, w, acc[1]);
-        acc[2] = fmaf(h.z, w, acc[2]); acc[3] = fmaf(h.w, w, acc[3]);
+    for (int k = 0; k < C; k += 2) {
+        // the two weights of a k pair sit in one register pair; op_sel picks the half that serves BOTH results of a packed FMA (written as
+        // (f2){w, w} hipcc copies every weight into a second register first)
+        const f2 w2 = {wt[(size_t)k * C], wt[(size_t)(k + 1) * C]};
+        const float4 p0 = *reinterpret_cast<const float4*>(&hs[k][0]), p1 = *reinterpret_cast<const float4*>(&hs[k][4]);
+        const float4 q0 = *reinterpret_cast<const float4*>(&hs[k + 1][0]), q1 = *reinterpret_cast<const float4*>(&hs[k + 1][4]);
+        const f2 hk[4] = {{p0.x, p0.y}, {p0.z, p0.w}, {p1.x, p1.y}, {p1.z, p1.w}};
+        const f2 hk1[4] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(hk[i]), "v"(w2));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a[i]) : "v"(hk1[i]), "v"(w2));
     }
-    float vis_part[4];
+    const float acc[S] = {a[0].x, a[0].y, a[1].x, a[1].y, a[2].x, a[2].y, a[3].x, a[3].y};
+    float vis_part[S];
     const float wv = out_vis != nullptr ? arena[o_wv + o] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float* fp = ffeats + ((size_t)pn * S + r0 + r) * C + o;
-        const float nf = gelu_exact(acc[r]) + *fp;
-        *fp = nf;
+    for (int r = 0; r < S; ++r) {
+        const float nf = gelu_exact(acc[r]) + fold[r];
+        ffeats[((size_t)pn * S + r) * C + o] = nf;
         vis_part[r] = nf * wv;
     }
 
@@ -1133,16 +1149,12 @@ __global__ __launch_bounds__(256) void state_update_kernel(const float* __restri
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vis_part[r] += __shfl_xor(vis_part[r], off);
+            for (int r = 0; r < S; ++r) vis_part[r] += __shfl_xor(vis_part[r], off);
         if ((tid & 63) == 0)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vred[tid >> 6][r] = vis_part[r];
+            for (int r = 0; r < S; ++r) vred[tid >> 6][r] = vis_part[r];
         __syncthreads();
-        if (tid < S) {
-            const int t = tid, grp = t >> 2, r = t & 3;             // rows 0-3: waves 0,1; rows 4-7: waves 2,3
-            const float v = vred[grp * 2][r] + vred[grp * 2 + 1][r] + arena[o_bv];
-            out_vis[((size_t)b * S + t) * N + n] = v;
-        }
+        if (tid < S) out_vis[((size_t)b * S + tid) * N + n] = vred[0][tid] + vred[1][tid] + arena[o_bv];
     }
 }
 
@@ -1272,7 +1284,7 @@ int launch_state_update(const float* arena, const float* delta, float* ffeats, f
         return PIPS_OK;
     }
     const ArenaLayout& A = arena_layout();
-    hipLaunchKernelGGL(state_update_kernel, dim3(B * N), dim3(256), 0, st, arena,
+    hipLaunchKernelGGL(state_update_kernel, dim3(B * N), dim3(128), 0, st, arena,
                        A.norm_g, A.norm_b, A.w_upd_t, A.b_upd, A.w_vis, A.b_vis, delta, ffeats, coords,
                        coords0, N, stride, out_traj, out_vis);
     PIPS_CHECK_LAUNCH("state_update_kernel");

@@ -201,6 +201,13 @@ def section(r):
              _grep(t + "_probe_t4up_without_gelu.txt", r"libpips_nogelu[^\n]*\n[^\n]*gemm_bf16_t4_gelu_kernel[^\n]*?\s([0-9.]+)\s+[0-9.]+\n"),
              _grep(t + "_probe_t4up_without_gelu.txt", r"product[^\n]*\n[^\n]*gemm_bf16_t4_gelu_kernel[^\n]*?\s([0-9.]+)\s+[0-9.]+\n")),
          "`PIPS_GEN_ABLATE=gelu python tools/gen_gemm_bf16_t4up.py` (`tools/history/r6_call19.sh`)"),
+        (t + "_probe_ln_mean_wave.txt", "`ln_mean` on the bf16 residual stream with one wave per particle (`ln_mean_wave_kernel`: 16-byte loads, both LayerNorm passes as wave "
+         "transposes, no LDS) against the block form: %s against %s µs per launch at 2048 particles" % (
+             _grep(t + "_probe_ln_mean_wave.txt", r"ln_mean_wave_kernel[^\n]*?\s([0-9.]+)\s+[0-9.]+\n"), _grep(t + "_probe_ln_mean_wave.txt", r"ln_mean_kernel<true>[^\n]*?\s([0-9.]+)\s+[0-9.]+\n")),
+         "`sh tools/tm_store_ab.sh prevln` (`tools/history/r6_call20.sh`)"),
+        (t + "_probe_state_update.txt", "`state_update_kernel` at 2048 particles, four re-cuts against round 5's 23.5 µs, all bit-identical: weights in registers + a particle loop "
+         "26.1 (fewer blocks in flight lose: the kernel is a latency chain per particle), packed FMAs alone no change, early feature loads 21.8, 128 threads = channel × all 8 rows "
+         "(every weight fetched once per block) 20.7 -- kept", "`tools/history/r6_call21.sh`, `r6_call22.sh`"),
         (t + "_probe_gather_final.txt", "`tools/gather_c4.py` on the final library: the three launches of both tiled gathers at config-4 geometry and the config-3 comparison "
          "(direct bf16-map kernel against the tiled matrix-core path)", "`python tools/gather_c4.py`"),
         (t + "_bf16_parity_tests.log", "`pytest -s` output of the bf16 parity tests on the one-rounding-contract build: configs[2] %s px against the autocast oracle, config-4 geometry "
