@@ -208,6 +208,11 @@ def section(r):
         (t + "_probe_state_update.txt", "`state_update_kernel` at 2048 particles, four re-cuts against round 5's 23.5 µs, all bit-identical: weights in registers + a particle loop "
          "26.1 (fewer blocks in flight lose: the kernel is a latency chain per particle), packed FMAs alone no change, early feature loads 21.8, 128 threads = channel × all 8 rows "
          "(every weight fetched once per block) 20.7 -- kept", "`tools/history/r6_call21.sh`, `r6_call22.sh`"),
+        (t + "_probe_two_streams.txt", "configs[2]'s 8 clips as ONE forward against two forwards of 4 clips in flight on two streams (and four of 2): %s / %s / %s ms -- "
+         "launch floors and tails of one stream do fill with the other's kernels, which only buys back what the smaller launches lose (one after the other: %s ms)" % (
+             _grep(t + "_probe_two_streams.txt", r"one forward of 8 clips: ([0-9.]+) ms"), _grep(t + "_probe_two_streams.txt", r"on two streams: ([0-9.]+) ms"),
+             _grep(t + "_probe_two_streams.txt", r"on four streams: ([0-9.]+) ms"), _grep(t + "_probe_two_streams.txt", r"one after the other: ([0-9.]+) ms")),
+         "`python tools/two_stream_probe.py` (`tools/history/r6_call23.sh`)"),
         (t + "_probe_gather_final.txt", "`tools/gather_c4.py` on the final library: the three launches of both tiled gathers at config-4 geometry and the config-3 comparison "
          "(direct bf16-map kernel against the tiled matrix-core path)", "`python tools/gather_c4.py`"),
         (t + "_bf16_parity_tests.log", "`pytest -s` output of the bf16 parity tests on the one-rounding-contract build: configs[2] %s px against the autocast oracle, config-4 geometry "

@@ -1,42 +1,50 @@
-"""BASELINE configs[2] share of one GPU (8 clips, bf16) as ONE forward of 8 clips against TWO concurrent forwards of 4 clips on two
-streams (one module, per-stream scratch): does the second stream fill the first one's idle tails?"""
-import os, sys, threading, time
+"""BASELINE configs[2] on one GPU (8 clips, bf16 mode): ONE forward of 8 clips against TWO forwards of 4 clips on two streams, in flight
+together -- do launch floors and kernel tails of one stream fill with the other's work?  (The module keeps its scratch per stream.)"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import _tunelib  # noqa: F401
+import bench
 from pips_amd import Pips
 dev = torch.device("cuda:0")
-m = Pips(stride=8).to(dev).eval()
-m.mixer_dtype = m.encoder_dtype = torch.bfloat16
-g = torch.Generator().manual_seed(1)
-rgbs = torch.randint(0, 256, (8, 8, 3, 368, 496), generator=g).float().to(dev)
-xys = (torch.rand(8, 256, 2, generator=g) * torch.tensor([495.0, 367.0])).to(dev)
+model = Pips(S=8, stride=8).to(dev).eval()
+model.mixer_dtype = model.encoder_dtype = torch.bfloat16
+xys, rgbs = bench.make_inputs(0, dev, 8)
+s = [torch.cuda.Stream() for _ in range(4)]
 
 
-def one(reps):
-    for _ in range(reps):
-        m(xys, rgbs, iters=6)
+def one():
+    return model(xys, rgbs, iters=6)
 
 
-def split(reps, k):
-    sts = [torch.cuda.Stream() for _ in range(k)]
-    per = 8 // k
-    for _ in range(reps):
-        for i, st in enumerate(sts):
-            with torch.cuda.stream(st):
-                m(xys[i * per:(i + 1) * per], rgbs[i * per:(i + 1) * per], iters=6)
-    for st in sts:
-        st.synchronize()
+def split(k):
+    n = 8 // k
+    outs = []
+    cur = torch.cuda.current_stream()
+    for i in range(k):
+        s[i].wait_stream(cur)
+        with torch.cuda.stream(s[i]):
+            outs.append(model(xys[i * n:(i + 1) * n], rgbs[i * n:(i + 1) * n], iters=6))
+    for i in range(k):
+        cur.wait_stream(s[i])
+    return outs
 
 
-def timed(fn, *a):
-    fn(2, *a) if a else fn(2)
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    fn(10, *a) if a else fn(10)
+    for _ in range(reps):
+        fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / 10 * 1e3
+    return (time.perf_counter() - t0) / reps * 1e3
 
 
+ref = one()
+sp = split(2)
+torch.cuda.synchronize()
+err = float((torch.cat([o[0][-1] for o in sp], 0) - ref[0][-1]).abs().max())
 for rnd in range(2):
-    print(f"round {rnd}: one forward of 8 clips {timed(one):.2f} ms | 2 streams x 4 clips {timed(split, 2):.2f} ms | 4 streams x 2 clips {timed(split, 4):.2f} ms", flush=True)
+    print("one forward of 8 clips: %.3f ms;  2 x 4 clips on two streams: %.3f ms;  4 x 2 clips on four streams: %.3f ms;  2 x 4 clips one after the other: %.3f ms   (max |d traj| split vs whole %.2e px)"
+          % (timed(one), timed(lambda: split(2)), timed(lambda: split(4)), timed(lambda: [model(xys[:4], rgbs[:4], iters=6), model(xys[4:], rgbs[4:], iters=6)]), err))
