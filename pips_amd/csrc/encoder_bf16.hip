@@ -18,14 +18,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // K = (ci, kh) pair x kw padded 7 -> 8: a lane's 8 K values are 8 NEIGHBOURING input pixels of one row, so an A fragment
 // is 16 contiguous bytes of the bf16 input tile; an MFMA takes two (ci, kh) pairs (one per lane half): 21 pairs -> 11
 // steps (the 22nd pair and the 8th tap carry zero weights).  Block (4 waves) = 4 output rows x 64 output columns x 64
-// channels, wave w = row w; LDS: input tile [3][13][136] bf16 + weights [11][2][64][8] bf16 = 33 KB, four blocks per CU.
+// channels, wave w = row w; LDS: input tile [3][13][136] bf16 + weights [11][2][64][8] bf16 = 33 KB; 168 registers: three blocks per CU.
 constexpr int SB_ROWS = 4, SB_COLS = 64;
 constexpr int SB_TH = 2 * SB_ROWS + 5, SB_TW = 136;
 constexpr int SB_STEPS = 11;
 constexpr int SB_TILE_BYTES = 3 * SB_TH * SB_TW * 2;
 constexpr int SB_W_BYTES = SB_STEPS * 2 * 64 * 16;
 
-template <typename RGB>
+// V4 (round 6; image width a multiple of 4, frames 16-byte aligned): the zero tap of the padded 8 sits in FRONT (kw' = kw + 1), which moves
+// the tile's first column from 2 col0 - 3 to 2 col0 - 4 -- a multiple of four pixels: the tile is staged with aligned 16-byte loads (4-byte
+// for 8-bit frames), whole quads in or out of the image, 6 loads and one 8-byte LDS store per thread and tile instead of 22 four-byte loads
+// and 11 stores: 232-240 -> 198-205 us at BASELINE configs[2].  [measured] profiles/r6_probe_stem_v4.txt
+template <typename RGB, bool V4>
 __global__ __launch_bounds__(256, 3) void stem_conv_bf16_kernel(const RGB* __restrict__ rgbs, const float* __restrict__ w,
                                                                 const float* __restrict__ bias,
                                                                 unsigned short* __restrict__ out, float* __restrict__ stats,
@@ -37,8 +41,8 @@ __global__ __launch_bounds__(256, 3) void stem_conv_bf16_kernel(const RGB* __res
     // ---- weights once per (persistent) block: arena layout [(ci*7+kh)*7 + kw][64] fp32 -> [step][half][n][8 kw] bf16
     for (int i = tid; i < SB_STEPS * 2 * 64 * 4; i += 256) {                 // one dword (two taps) per item
         const int kp = i & 3, n = (i >> 2) & 63, sh = i >> 8;                // sh = step*2 + half = (ci, kh) pair index
-        const int k0 = 2 * kp;
-        const float a = (sh < 21) ? w[(sh * 7 + k0) * 64 + n] : 0.f;
+        const int k0 = V4 ? 2 * kp - 1 : 2 * kp;                            // filter tap of the pair's first K value (V4: K value 0 is the zero tap)
+        const float a = (sh < 21 && k0 >= 0) ? w[(sh * 7 + k0) * 64 + n] : 0.f;
         const float b = (sh < 21 && k0 + 1 < 7) ? w[(sh * 7 + k0 + 1) * 64 + n] : 0.f;
         reinterpret_cast<unsigned*>(sb_w)[i] = pack2_bf16(a, b);
     }
@@ -48,13 +52,45 @@ __global__ __launch_bounds__(256, 3) void stem_conv_bf16_kernel(const RGB* __res
         const int row0 = ty * SB_ROWS, col0 = tx * SB_COLS;
         // ---- stage the scaled input tile: pixel pairs, every load issued before the first use
         const RGB* src = rgbs + (size_t)frame * 3 * H * W;
-        const int hi0 = 2 * row0 - 3, wi0 = 2 * col0 - 3;
-        constexpr int NPAIR = 3 * SB_TH * (SB_TW / 2), NIT = (NPAIR + 255) / 256;
-        float v0[NIT], v1[NIT];                               // raw pixel values; scaled when they are written to LDS
-        unsigned in_mask = 0;
+        const int hi0 = 2 * row0 - 3, wi0 = 2 * col0 - (V4 ? 4 : 3);
         int tq = tid;
         asm volatile("" : "+v"(tq));                          // opaque per tile: the 11 steps' index arithmetic is recomputed here
                                                               // instead of living in ~60 registers across the persistent loop
+        if constexpr (V4) {
+            constexpr int NQ = 3 * SB_TH * (SB_TW / 4), NIT4 = (NQ + 255) / 256;
+            float v[NIT4][4];                                 // raw pixel values of a quad; scaled when they are written to LDS
+            unsigned in_mask = 0;
+#pragma unroll
+            for (int it = 0; it < NIT4; ++it) {
+                const int q = tq + it * 256, qc = q < NQ ? q : 0;              // (the last step is partial)
+                const int r = qc / (SB_TW / 4), j = qc - r * (SB_TW / 4);
+                const int c = r / SB_TH, y = r - c * SB_TH;
+                const int hi = hi0 + y, wi = wi0 + 4 * j;
+                const bool in = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;     // W % 4 == 0: the quad is inside or outside as a whole
+                const RGB* q4 = src + (c * H + (in ? hi : 0)) * W + (in ? wi : 0);               // < 2^31: one frame
+                if constexpr (sizeof(RGB) == 1) {
+                    const uchar4 u = *reinterpret_cast<const uchar4*>(q4);
+                    v[it][0] = (float)u.x; v[it][1] = (float)u.y; v[it][2] = (float)u.z; v[it][3] = (float)u.w;
+                } else {
+                    const float4 f = *reinterpret_cast<const float4*>(q4);
+                    v[it][0] = f.x; v[it][1] = f.y; v[it][2] = f.z; v[it][3] = f.w;
+                }
+                in_mask |= (in ? 1u : 0u) << it;
+            }
+            __syncthreads();                                  // the previous tile's fragment reads are done (and sb_w is written)
+#pragma unroll
+            for (int it = 0; it < NIT4; ++it) {
+                const int q = tid + it * 256;
+                const bool in = in_mask >> it & 1;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = in ? 2.0f * (v[it][e] / 255.0f) - 1.0f : 0.f;   // 2*(x/255)-1 (nets/pips.py:436); zero padding in the scaled domain
+                if (q < NQ) reinterpret_cast<uint2*>(sb_tile)[q] = make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
+            }
+        } else {
+        constexpr int NPAIR = 3 * SB_TH * (SB_TW / 2), NIT = (NPAIR + 255) / 256;
+        float v0[NIT], v1[NIT];                               // raw pixel values; scaled when they are written to LDS
+        unsigned in_mask = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int q = tq + it * 256, qc = q < NPAIR ? q : 0;           // (the last step is partial)
@@ -76,6 +112,7 @@ __global__ __launch_bounds__(256, 3) void stem_conv_bf16_kernel(const RGB* __res
             const float a = (in_mask >> (2 * it) & 1) ? 2.0f * (v0[it] / 255.0f) - 1.0f : 0.f;
             const float b = (in_mask >> (2 * it + 1) & 1) ? 2.0f * (v1[it] / 255.0f) - 1.0f : 0.f;
             if (q < NPAIR) reinterpret_cast<unsigned*>(sb_tile)[q] = pack2_bf16(a, b);
+        }
         }
         __syncthreads();
         // ---- 11 steps x (2 x 2) MFMAs per wave
@@ -160,13 +197,16 @@ int launch_stem_bf16(const void* rgbs, int rgb_u8, const float* w, const float* 
     const int cus = device_cus();
     if (cus <= 0) { set_error("stem_bf16: cannot query the device"); return PIPS_E_LAUNCH; }
     const long total = (long)tiles * F;
-    const int grid = total < 4L * cus ? (int)total : 4 * cus;          // persistent: the weights are converted once per block
-    if (rgb_u8)
-        hipLaunchKernelGGL(stem_conv_bf16_kernel<unsigned char>, dim3(grid), dim3(256), 0, st, (const unsigned char*)rgbs, w,
-                           bias, (unsigned short*)out, stats, H, W, Ho, Wo, tiles_x, tiles, F);
-    else
-        hipLaunchKernelGGL(stem_conv_bf16_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)rgbs, w, bias,
-                           (unsigned short*)out, stats, H, W, Ho, Wo, tiles_x, tiles, F);
+    // persistent (the weights are converted once per block), ONE round of resident blocks: 168 registers = three blocks per compute unit (a grid of
+    // 4 x CUs ran a quarter of the blocks in a second round at one block per unit: 204.6 -> 191.8 us at BASELINE configs[2])
+    const int grid = total < 3L * cus ? (int)total : 3 * cus;
+    // quads of four pixels: rows and frames start on a quad boundary when W % 4 == 0 and the first frame does
+    const bool v4 = W % 4 == 0 && reinterpret_cast<uintptr_t>(rgbs) % (rgb_u8 ? 4 : 16) == 0 && PIPS_TUNE("PIPS_STEM_V4", 1);
+#define PIPS_STEM(T_, V_) hipLaunchKernelGGL((stem_conv_bf16_kernel<T_, V_>), dim3(grid), dim3(256), 0, st, (const T_*)rgbs, w, bias, \
+                                             (unsigned short*)out, stats, H, W, Ho, Wo, tiles_x, tiles, F)
+    if (rgb_u8) { if (v4) PIPS_STEM(unsigned char, true); else PIPS_STEM(unsigned char, false); }
+    else { if (v4) PIPS_STEM(float, true); else PIPS_STEM(float, false); }
+#undef PIPS_STEM
     PIPS_CHECK_LAUNCH("stem_conv_bf16_kernel");
     return PIPS_OK;
 }

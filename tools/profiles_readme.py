@@ -213,6 +213,9 @@ def section(r):
              _grep(t + "_probe_two_streams.txt", r"one forward of 8 clips: ([0-9.]+) ms"), _grep(t + "_probe_two_streams.txt", r"on two streams: ([0-9.]+) ms"),
              _grep(t + "_probe_two_streams.txt", r"on four streams: ([0-9.]+) ms"), _grep(t + "_probe_two_streams.txt", r"one after the other: ([0-9.]+) ms")),
          "`python tools/two_stream_probe.py` (`tools/history/r6_call23.sh`)"),
+        (t + "_probe_stem_v4.txt", "`stem_conv_bf16_kernel` at configs[2]: aligned 16-byte quad loads (the padded filter's zero tap moved to the front puts the tile's first "
+         "column on a multiple of four pixels) 232–240 → 198–205 µs, and a grid of 3 × CUs -- what 168 registers keep resident -- instead of 4 × (a quarter of the blocks ran in a "
+         "second round) → 191.8 µs", "`tools/history/r6_call25.sh`"),
         (t + "_probe_gather_final.txt", "`tools/gather_c4.py` on the final library: the three launches of both tiled gathers at config-4 geometry and the config-3 comparison "
          "(direct bf16-map kernel against the tiled matrix-core path)", "`python tools/gather_c4.py`"),
         (t + "_bf16_parity_tests.log", "`pytest -s` output of the bf16 parity tests on the one-rounding-contract build: configs[2] %s px against the autocast oracle, config-4 geometry "
