@@ -25,7 +25,12 @@ constexpr int STEM_LDS = (3 * STEM_TH * STEM_TW + STEM_STEPS * 64 * 2) * 4;
 
 // RGB = float (0..255 values, what the reference's callers pass after .float()) or unsigned char
 // (the decoded frames themselves: a quarter of the bytes, bit-identical results).
-template <typename RGB>
+// V4 (round 6; image width a multiple of 4, frames 16-byte aligned): the padded filter's zero tap sits in FRONT (kw' = kw + 1), which moves the
+// tile's first column from 2 col0 - 3 to 2 col0 - 4 -- a multiple of four pixels -- and the tile is staged with SIX aligned 16-byte loads per
+// thread, all in flight before the first is used: one memory round trip per tile.  The row-by-row form below issues a (channel, row) per wave
+// and step, ten dependent round trips per tile that only the compute unit's other block hides (128 us per launch at the headline's 8 frames
+// where the MFMAs need 50).  [measured] profiles/r6_probe_stem_f32_v4.txt
+template <typename RGB, bool V4>
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const RGB* __restrict__ rgbs,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bias,
@@ -40,8 +45,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const RGB* __restrict
     // ---- the weights once per (persistent) block
     for (int i = tid; i < STEM_STEPS * 64 * 2; i += 256) {
         const int h = i & 1, n = (i >> 1) & 63, s = i >> 7;          // step s = (ci*7 + kh)*4 + j
-        const int j = s & 3, ck = s >> 2, kw = 2 * j + h;
-        wl[i] = kw < 7 ? w[(ck * 7 + kw) * 64 + n] : 0.f;
+        const int j = s & 3, ck = s >> 2, kw = 2 * j + h - (V4 ? 1 : 0);   // (V4: K value 0 of the eight is the zero tap)
+        wl[i] = (kw >= 0 && kw < 7) ? w[(ck * 7 + kw) * 64 + n] : 0.f;
     }
   for (int work = blockIdx.x; work < tiles * F; work += gridDim.x) {
     const int frame = work / tiles, tile_id = work - frame * tiles;
@@ -49,7 +54,37 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const RGB* __restrict
     const int row0 = ty * STEM_ROWS, col0 = tx * STEM_COLS;
     // ---- stage the scaled input tile
     const RGB* src = rgbs + (size_t)frame * 3 * H * W;
-    const int hi0 = 2 * row0 - 3, wi0 = 2 * col0 - 3;
+    const int hi0 = 2 * row0 - 3, wi0 = 2 * col0 - (V4 ? 4 : 3);
+    if constexpr (V4) {
+        constexpr int NQ = 3 * STEM_TH * (STEM_TW / 4), NIT4 = (NQ + 255) / 256;
+        float4 v[NIT4];
+        unsigned in_mask = 0;
+#pragma unroll
+        for (int it = 0; it < NIT4; ++it) {
+            const int q = tid + it * 256, qc = q < NQ ? q : 0;               // (the last step is partial)
+            const int r = qc / (STEM_TW / 4), j = qc - r * (STEM_TW / 4);
+            const int c = r / STEM_TH, y = r - c * STEM_TH;
+            const int hi = hi0 + y, wi = wi0 + 4 * j;
+            const bool in = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;     // W % 4 == 0: a quad is inside or outside as a whole
+            const RGB* q4 = src + ((size_t)c * H + (in ? hi : 0)) * W + (in ? wi : 0);
+            if constexpr (sizeof(RGB) == 1) {
+                const uchar4 u = *reinterpret_cast<const uchar4*>(q4);
+                v[it] = make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
+            } else {
+                v[it] = *reinterpret_cast<const float4*>(q4);
+            }
+            in_mask |= (in ? 1u : 0u) << it;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT4; ++it) {
+            const int q = tid + it * 256;
+            const bool in = in_mask >> it & 1;
+            const float4 o = in ? make_float4(2.0f * (v[it].x / 255.0f) - 1.0f, 2.0f * (v[it].y / 255.0f) - 1.0f, 2.0f * (v[it].z / 255.0f) - 1.0f,
+                                              2.0f * (v[it].w / 255.0f) - 1.0f)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < NQ) reinterpret_cast<float4*>(tile)[q] = o;
+        }
+    } else
     for (int r = wave; r < 3 * STEM_TH; r += 4) {                     // one (channel, row) of the tile per wave and step
         const int c = r / STEM_TH, y = r - c * STEM_TH;
         const int hi = hi0 + y;
@@ -136,17 +171,19 @@ int launch_stem(const void* rgbs, int rgb_u8, const float* w, const float* bias,
     // persistent blocks (two per CU: 64 KiB of LDS each), each stages the weights once and walks tiles
     const int grid = tiles * F < 512 ? tiles * F : 512;
     static std::atomic<unsigned long long> raised_f{0}, raised_u{0};
-    if (rgb_u8) {
-        const int rc = ensure_dynamic_lds(raised_u, (const void*)stem_conv_kernel<unsigned char>, STEM_LDS);
-        if (rc != PIPS_OK) return rc;
-        hipLaunchKernelGGL(stem_conv_kernel<unsigned char>, dim3(grid), dim3(256), STEM_LDS, st,
-                           (const unsigned char*)rgbs, w, bias, out, stats, H, W, Ho, Wo, tiles_x, tiles, F);
-    } else {
-        const int rc = ensure_dynamic_lds(raised_f, (const void*)stem_conv_kernel<float>, STEM_LDS);
-        if (rc != PIPS_OK) return rc;
-        hipLaunchKernelGGL(stem_conv_kernel<float>, dim3(grid), dim3(256), STEM_LDS, st, (const float*)rgbs, w, bias,
-                           out, stats, H, W, Ho, Wo, tiles_x, tiles, F);
+    static std::atomic<unsigned long long> raised_f4{0}, raised_u4{0};
+    // quads of four pixels: rows and frames start on a quad boundary when W % 4 == 0 and the first frame does
+    const bool v4 = W % 4 == 0 && reinterpret_cast<uintptr_t>(rgbs) % (rgb_u8 ? 4 : 16) == 0 && PIPS_TUNE("PIPS_STEM_V4", 1);
+#define PIPS_STEM32(T_, V_, RAISED_)                                                                                             \
+    {                                                                                                                            \
+        const int rc = ensure_dynamic_lds(RAISED_, (const void*)stem_conv_kernel<T_, V_>, STEM_LDS);                            \
+        if (rc != PIPS_OK) return rc;                                                                                            \
+        hipLaunchKernelGGL((stem_conv_kernel<T_, V_>), dim3(grid), dim3(256), STEM_LDS, st, (const T_*)rgbs, w, bias, out, stats, \
+                           H, W, Ho, Wo, tiles_x, tiles, F);                                                                     \
     }
+    if (rgb_u8) { if (v4) PIPS_STEM32(unsigned char, true, raised_u4) else PIPS_STEM32(unsigned char, false, raised_u) }
+    else { if (v4) PIPS_STEM32(float, true, raised_f4) else PIPS_STEM32(float, false, raised_f) }
+#undef PIPS_STEM32
     PIPS_CHECK_LAUNCH("stem_conv_kernel");
     return PIPS_OK;
 }

@@ -218,22 +218,44 @@ int launch_stem_bf16(const void* rgbs, int rgb_u8, const float* w, const float* 
 // MODE 2: y = relu(n2(res) + relu(n(x)))              :169-170,179,181 (1x1 stride-2 shortcut + norm3)
 // MODE 3: y = relu(relu(n2(res)) + relu(n(x)))        the first block's identity shortcut is the stem's relu(norm1(.)),
 //                                                     which is never materialised: it is recomputed from the stem's raw map
+// Block = a run of APPLY_ITERS x (threads / C8) pixels of ONE frame; thread = one 8-channel group c8 (the block has a multiple of C8 threads):
+// the 8 x {mean, rstd} of the thread's channels (and the shortcut's) are loaded ONCE into registers.  The grid-stride form of round 4 fetched
+// them per element -- 64 (128 with a normalised shortcut) bytes through the L1 for every 48 bytes of map traffic.
+// [measured] profiles/r6_probe_inorm_apply.txt
+constexpr int APPLY_ITERS = 8;
 template <int MODE>
 __global__ __launch_bounds__(256) void inorm_apply_bf16_kernel(const uint4* __restrict__ x, const float4* __restrict__ stats,
                                                                const uint4* __restrict__ res,
                                                                const float4* __restrict__ res_stats, uint4* __restrict__ y,
-                                                               int HW, int C8, size_t total8) {
-    const size_t per_frame = (size_t)HW * C8;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i / per_frame);
-        const int c8 = (int)(i % C8);
-        const float4* st = stats + ((size_t)f * C8 + c8) * 4;            // 8 x {mean, rstd}
+                                                               int HW, int C8, int chunks) {
+    const int f = blockIdx.x / chunks, chunk = blockIdx.x - f * chunks;
+    const int ppb = blockDim.x / C8;                                         // pixels per step of the block
+    const int c8 = threadIdx.x % C8, pl = threadIdx.x / C8;
+    float4 sx[4], sr[4];
+    {
+        const float4* st = stats + ((size_t)f * C8 + c8) * 4;                // 8 x {mean, rstd}
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sx[k] = st[k];
+        if (MODE >= 2) {
+            const float4* rs = res_stats + ((size_t)f * C8 + c8) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sr[k] = rs[k];
+        }
+    }
+    const int p0 = chunk * (APPLY_ITERS * ppb) + pl;
+    const size_t base = (size_t)f * HW * C8 + c8;
+#pragma unroll
+    for (int it = 0; it < APPLY_ITERS; ++it) {
+        const int pp = p0 + it * ppb;
+        const bool live = pp < HW;
+        const int p = live ? pp : HW - 1;                                    // (loads stay unconditional: every step's are in flight together)
+        const size_t i = base + (size_t)p * C8;
         const uint4 xv = x[i];
         const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
         float o[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float4 s = st[k];
+            const float4 s = sx[k];
             o[2 * k] = fmaxf((bf16_lo(xw[k]) - s.x) * s.y, 0.f);
             o[2 * k + 1] = fmaxf((bf16_hi(xw[k]) - s.z) * s.w, 0.f);
         }
@@ -244,10 +266,9 @@ __global__ __launch_bounds__(256) void inorm_apply_bf16_kernel(const uint4* __re
 #pragma unroll
             for (int k = 0; k < 4; ++k) { r[2 * k] = bf16_lo(rw[k]); r[2 * k + 1] = bf16_hi(rw[k]); }
             if (MODE >= 2) {
-                const float4* rs = res_stats + ((size_t)f * C8 + c8) * 4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float4 s = rs[k];
+                    const float4 s = sr[k];
                     r[2 * k] = (r[2 * k] - s.x) * s.y;
                     r[2 * k + 1] = (r[2 * k + 1] - s.z) * s.w;
                     if (MODE == 3) { r[2 * k] = fmaxf(r[2 * k], 0.f); r[2 * k + 1] = fmaxf(r[2 * k + 1], 0.f); }
@@ -256,23 +277,25 @@ __global__ __launch_bounds__(256) void inorm_apply_bf16_kernel(const uint4* __re
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = fmaxf(r[k] + o[k], 0.f);
         }
-        y[i] = make_uint4(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7]));
+        if (live) y[i] = make_uint4(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7]));
     }
 }
 
 int launch_inorm_apply_bf16(const void* x, const float* stats, const void* res, const float* res_stats, int mode, void* y,
                             int F, int HW, int C, hipStream_t st) {
-    PIPS_CHECK_ARG(C % 8 == 0 && mode >= 0 && mode <= 3, "inorm_apply_bf16: C %% 8, mode 0..3");
+    PIPS_CHECK_ARG(C % 8 == 0 && C <= 2048 && mode >= 0 && mode <= 3, "inorm_apply_bf16: C %% 8, C <= 2048, mode 0..3");
     PIPS_CHECK_ARG(mode == 0 || res != nullptr, "inorm_apply_bf16: mode %d needs a shortcut map", mode);
     PIPS_CHECK_ARG(mode < 2 || res_stats != nullptr, "inorm_apply_bf16: mode %d needs the shortcut's statistics", mode);
-    const size_t total8 = (size_t)F * HW * (C / 8);
-    const int blocks = (int)((total8 + 255) / 256 < 8192 ? (total8 + 255) / 256 : 8192);
+    const int C8 = C / 8;
+    const int threads = (256 / C8) * C8;                                     // a multiple of the channel groups: 256, 252 (C = 96), ...
+    const int chunks = cdiv(HW, APPLY_ITERS * (threads / C8));
+    PIPS_CHECK_ARG((long)F * chunks < (1L << 31), "inorm_apply_bf16: %d frames x %d chunks", F, chunks);
     const uint4* x4 = reinterpret_cast<const uint4*>(x);
     const float4* s4 = reinterpret_cast<const float4*>(stats);
     const uint4* r4 = reinterpret_cast<const uint4*>(res);
     const float4* rs4 = reinterpret_cast<const float4*>(res_stats);
     uint4* y4 = reinterpret_cast<uint4*>(y);
-#define PIPS_APPLY(M_) hipLaunchKernelGGL(inorm_apply_bf16_kernel<M_>, dim3(blocks), dim3(256), 0, st, x4, s4, r4, rs4, y4, HW, C / 8, total8)
+#define PIPS_APPLY(M_) hipLaunchKernelGGL(inorm_apply_bf16_kernel<M_>, dim3(F * chunks), dim3(threads), 0, st, x4, s4, r4, rs4, y4, HW, C8, chunks)
     if (mode == 0) PIPS_APPLY(0); else if (mode == 1) PIPS_APPLY(1); else if (mode == 2) PIPS_APPLY(2); else PIPS_APPLY(3);
 #undef PIPS_APPLY
     PIPS_CHECK_LAUNCH("inorm_apply_bf16_kernel");

@@ -216,6 +216,12 @@ def section(r):
         (t + "_probe_stem_v4.txt", "`stem_conv_bf16_kernel` at configs[2]: aligned 16-byte quad loads (the padded filter's zero tap moved to the front puts the tile's first "
          "column on a multiple of four pixels) 232–240 → 198–205 µs, and a grid of 3 × CUs -- what 168 registers keep resident -- instead of 4 × (a quarter of the blocks ran in a "
          "second round) → 191.8 µs", "`tools/history/r6_call25.sh`"),
+        (t + "_probe_stem_f32_v4.txt", "the exact-fp32 `stem_conv_kernel` at the headline's 8 frames with the same aligned quad loads, all six in flight before the first is used "
+         "(the row-by-row staging made ten dependent memory round trips per tile): 128.4 → 102.3 µs per launch, the headline step −0.02…−0.03 ms (200 steps without the profiler, alternating)",
+         "`tools/history/r6_call27.sh`, `r6_call28.sh`"),
+        (t + "_probe_inorm_apply.txt", "`inorm_apply_bf16_kernel` at configs[2] with a block per run of pixels of one frame and the thread's statistics in registers (the grid-stride "
+         "form fetched 64–128 bytes of statistics through the L1 per 48 bytes of map traffic): `<3>` 247.6 → 213 µs, `<2>` 43.7 → 37.4, `<0>` 26.75 → 25.0, `<1>` 75.5 → 76.7 = "
+         "−61 µs per forward; the same re-cut of the fp32 kernel at the headline's sizes: no gain, not kept", "`tools/history/r6_call26.sh`, `r6_call29.sh`"),
         (t + "_probe_gather_final.txt", "`tools/gather_c4.py` on the final library: the three launches of both tiled gathers at config-4 geometry and the config-3 comparison "
          "(direct bf16-map kernel against the tiled matrix-core path)", "`python tools/gather_c4.py`"),
         (t + "_bf16_parity_tests.log", "`pytest -s` output of the bf16 parity tests on the one-rounding-contract build: configs[2] %s px against the autocast oracle, config-4 geometry "
