@@ -321,7 +321,8 @@ def test_conv_nhwc_bf16_maps_without_bias():
 
 # ----------------------------------------------------------------------------- encoder
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("H,W,stride", [(128, 160, 8), (96, 128, 4), (136, 200, 8), (368, 496, 8)])
+# (106 x 150: a width that is no multiple of 4 -- the stem's row-by-row staging; every other size takes its aligned quad loads)
+@pytest.mark.parametrize("H,W,stride", [(128, 160, 8), (96, 128, 4), (136, 200, 8), (368, 496, 8), (106, 150, 8)])
 def test_encoder_pyramid(H, W, stride, split, weights_raw, arenas):
     from pips_amd import ops
     O = _oracle()
@@ -370,7 +371,8 @@ def test_encoder_low_variance_frames(kind, weights_raw, arenas):
     assert err < 4 * floor + 1e-5
 
 
-@pytest.mark.parametrize("F_,H,W", [(8, 128, 160), (16, 184, 248)])   # the second size takes the fused LDS-resident layer-1 path
+# the second size takes the fused LDS-resident layer-1 path; the third has a width that is no multiple of 4 (the stem's pair-wise staging)
+@pytest.mark.parametrize("F_,H,W", [(8, 128, 160), (16, 184, 248), (8, 106, 150)])
 def test_encoder_bf16_operands(F_, H, W, weights_raw, arenas):
     """bf16 encoder mode (config 3: bf16 conv operands AND bf16 activation maps, the rounding points of the reference under
     torch.autocast(bfloat16)): maps within bf16-level error of the fp32 oracle, and no further from the oracle run under
@@ -396,6 +398,10 @@ def test_encoder_bf16_operands(F_, H, W, weights_raw, arenas):
     lv = ops.pyramid_levels(pyr, F_, H, W, 8)
     pooled = torch.nn.functional.avg_pool2d(lv[0].permute(0, 3, 1, 2), 2, stride=2).permute(0, 2, 3, 1)
     assert float((lv[1] - pooled).abs().max()) < 1e-5
+    # decoded uint8 frames (PIPS_FLAG_RGB_U8) through the same stem: the same values, bit for bit
+    pyr8 = ops.encoder_fwd(arenas["raw"], rgbs.to(torch.uint8).to(DEV), 8, bf16=True)
+    for a8, af in zip(ops.pyramid_levels(pyr8, F_, H, W, 8), lv):
+        assert torch.equal(a8, af)
 
 
 # ----------------------------------------------------------------------------- tracker stages
