@@ -222,6 +222,13 @@ def section(r):
         (t + "_probe_inorm_apply.txt", "`inorm_apply_bf16_kernel` at configs[2] with a block per run of pixels of one frame and the thread's statistics in registers (the grid-stride "
          "form fetched 64–128 bytes of statistics through the L1 per 48 bytes of map traffic): `<3>` 247.6 → 213 µs, `<2>` 43.7 → 37.4, `<0>` 26.75 → 25.0, `<1>` 75.5 → 76.7 = "
          "−61 µs per forward; the same re-cut of the fp32 kernel at the headline's sizes: no gain, not kept", "`tools/history/r6_call26.sh`, `r6_call29.sh`"),
+        (t + "_probe_mfma_clock_power.txt", "every SIMD issuing MFMAs back to back on constant operands, clock from in-kernel stamps and `rocm-smi` beside it: both bf16 shapes and "
+         "the fp32 MFMA hold 2.39–2.40 GHz at 0.8–1.1 kW (`v_mfma_f32_16x16x32_bf16` 2096 / 2316 TFLOP/s at one / two waves per SIMD with eight accumulators, "
+         "`v_mfma_f32_32x32x16_bf16` 2326 / 2417, fp32 155.5) -- the matrix cores alone do not reach the power limit the bf16 mixer pass runs at",
+         "`tools/mfma_power.hip` (`tools/history/r6_call33.sh`)"),
+        (t + "_probe_mfma_lds_mix.txt", "one wave per SIMD, 64 independent accumulators, the up-projection's LDS reads (24 `ds_read_b128` per 32 K values) issued between the MFMAs: "
+         "16x16x32 2428 → 2375 TFLOP/s, 32x32x16 2461 → 2341 -- neither shape loses issue to the reads of its own wave when nothing depends on them; the real K loop's 55 % is "
+         "dependences and barriers, not instruction issue (round 4's additive model does not carry over)", "`tools/mfma_lds_mix.hip` (`tools/history/r6_call34.sh`)"),
         (t + "_probe_gather_final.txt", "`tools/gather_c4.py` on the final library: the three launches of both tiled gathers at config-4 geometry and the config-3 comparison "
          "(direct bf16-map kernel against the tiled matrix-core path)", "`python tools/gather_c4.py`"),
         (t + "_bf16_parity_tests.log", "`pytest -s` output of the bf16 parity tests on the one-rounding-contract build: configs[2] %s px against the autocast oracle, config-4 geometry "
