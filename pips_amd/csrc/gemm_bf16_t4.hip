@@ -39,6 +39,25 @@ __device__ __forceinline__ unsigned t4_sgpr(unsigned v) { return (unsigned)__bui
 #define T4_LO(ptr) t4_sgpr((unsigned)(unsigned long long)reinterpret_cast<uintptr_t>(ptr))
 #define T4_HI(ptr) t4_sgpr((unsigned)((unsigned long long)reinterpret_cast<uintptr_t>(ptr) >> 32))
 
+#ifdef PIPS_T4_CLOCK
+// tools/t4_clock.py (variant build): per wave of the LAST launch of either kernel, shader clocks (s_memtime) and 100 MHz ticks (s_memrealtime)
+// around the generated statement -- the clock the kernel actually ran at, and a wave's share of the launch
+__device__ unsigned long long g_t4_clock[2][1024][2];
+extern "C" int pips_debug_t4_clock(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_t4_clock), sizeof(unsigned long long) * 2 * 1024 * 2);
+}
+#define PIPS_T4_CLOCK_BEGIN const unsigned long long clk0__ = clock64(), rt0__ = wall_clock64();
+#define PIPS_T4_CLOCK_END(which)                                                                                       \
+    {                                                                                                                  \
+        const unsigned long long clk1__ = clock64(), rt1__ = wall_clock64();                                           \
+        const int w__ = blockIdx.x * 4 + (threadIdx.x >> 6);                                                           \
+        if ((threadIdx.x & 63) == 0 && w__ < 1024) { g_t4_clock[which][w__][0] = clk1__ - clk0__; g_t4_clock[which][w__][1] = rt1__ - rt0__; } \
+    }
+#else
+#define PIPS_T4_CLOCK_BEGIN
+#define PIPS_T4_CLOCK_END(which)
+#endif
+
 // SB: the residual stream is bf16 -- R and C are bf16 (the reference's PreNormResidual under autocast adds two bf16 tensors,
 // nets/pips.py:93-100): the residual tile is widened into the accumulators, the result rounded once (RNE) on the way out.
 template <bool SB>
@@ -87,8 +106,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_res_kernel(GemmArgs p, int t
                    [wlo] "s"(T4_LO(Wb)), [whi] "s"(T4_HI(Wb)), [rlo] "s"(T4_LO(Rb)), [rhi] "s"(T4_HI(Rb)), [clo] "s"(T4_LO(Cb)), \
                    [chi] "s"(T4_HI(Cb)), [blo] "s"(T4_LO(Bb)), [bhi] "s"(T4_HI(Bb)), [passA] "s"(t4_sgpr(passA)), \
                    [passW] "s"(t4_sgpr(passW)), [rstep] "s"(t4_sgpr(rstep)), [cstep] "s"(t4_sgpr(cstep)), [kt] "s"(t4_sgpr(kt))
+    PIPS_T4_CLOCK_BEGIN
     if (SB) asm volatile(PIPS_T4B_TEXT : T4_OPERANDS : PIPS_T4_CLOBBER);
     else asm volatile(PIPS_T4_TEXT : T4_OPERANDS : PIPS_T4_CLOBBER);
+    PIPS_T4_CLOCK_END(1)
 #undef T4_OPERANDS
 }
 
@@ -130,6 +151,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_gelu_kernel(GemmArgs p, int 
     const unsigned voC = (unsigned)((r16 * p.ldc + 8 * g) * 2), voB = (unsigned)(32 * g);
     const unsigned cstep = (unsigned)(16 * p.ldc * 2), tstepC = (unsigned)(T4U_B * p.ldc * 2);
     const unsigned tstepA = (unsigned)(T4U_B * p.lda * 2 - 128 * (T4U_K / T4_BK));
+    PIPS_T4_CLOCK_BEGIN
     asm volatile(PIPS_T4UP_TEXT
                  :
                  : [rA0] "v"(rA0), [rW0] "v"(rW0), [rA1] "v"(rA1), [rW1] "v"(rW1), [wA] "v"(wA), [wW] "v"(wW), [voA] "v"(voA),
@@ -138,6 +160,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_gelu_kernel(GemmArgs p, int 
                    [passA] "s"(t4_sgpr(passA)), [passW] "s"(t4_sgpr(passW)), [cstep] "s"(t4_sgpr(cstep)), [tstepC] "s"(t4_sgpr(tstepC)),
                    [tstepA] "s"(t4_sgpr(tstepA)), [ntile] "s"(t4_sgpr((unsigned)tpb))
                  : PIPS_T4UP_CLOBBER);
+    PIPS_T4_CLOCK_END(0)
 }
 
 // Whether the up-projection form (bf16 A and C, GELU, K = 512) goes to gemm_bf16_t4_gelu_kernel; *tpb = row tiles per block.

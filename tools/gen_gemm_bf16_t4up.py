@@ -25,7 +25,8 @@ import struct
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("PIPS_GEN_OUT", os.path.join(HERE, "..", "pips_amd", "csrc", "gemm_bf16_t4up_asm.inc"))
-ABL = os.environ.get("PIPS_GEN_ABLATE", "")                 # timing probes (wrong results): gelu = no GELU arithmetic in the epilogue
+ABL = os.environ.get("PIPS_GEN_ABLATE", "")                 # timing probes (wrong results): gelu = no GELU arithmetic in the epilogue; vmwait / barrier / fragwait =
+                                                            # the K loop without its waits on staged loads / its barriers / its waits on fragments
 POLICY = os.environ.get("PIPS_GEN_STORE_POLICY", "")      # tuning builds: cache-policy bits of the output stores, e.g. " sc1"
 
 NI, NJ = 8, 8                       # 16-row / 16-column blocks of the wave tile
@@ -70,27 +71,30 @@ class Emit:
         self.lines.append(s)
         self.vm.append(tag)
 
-    def need_lds(self, tags):
+    def need_lds(self, tags, emit=True):
         idx = [k for k, t in enumerate(self.lgkm) if t in tags]
         if not idx:
             return
         left = min(len(self.lgkm) - 1 - max(idx), 15)
-        self.lines.append("s_waitcnt lgkmcnt(%d)" % left)
+        if emit:
+            self.lines.append("s_waitcnt lgkmcnt(%d)" % left)
         self.lgkm = self.lgkm[len(self.lgkm) - left:] if left else []
 
-    def need_vm(self, tags):
+    def need_vm(self, tags, emit=True):
         idx = [k for k, t in enumerate(self.vm) if t in tags]
         if not idx:
             return
         left = min(len(self.vm) - 1 - max(idx), 63)
-        self.lines.append("s_waitcnt vmcnt(%d)" % left)
+        if emit:
+            self.lines.append("s_waitcnt vmcnt(%d)" % left)
         self.vm = self.vm[len(self.vm) - left:] if left else []
 
     def barrier(self):
         if self.lgkm:
             self.lines.append("s_waitcnt lgkmcnt(0)")
             self.lgkm = []
-        self.lines.append("s_barrier")
+        if "barrier" not in ABL:                             # (timing probe: the waves of a block run unsynchronised)
+            self.lines.append("s_barrier")
 
     def drain(self):
         self.lines.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
@@ -102,6 +106,8 @@ def acc(i, j):
 
 
 def frag_read(e, ks, which, idx):
+    if "frags" in ABL:                                       # (timing probe: the K loop without its fragment reads)
+        return
     if which == "a":
         reg = FA[ks] + 4 * idx
         e.lds("ds_read_b128 v[%d:%d], %%[rA%d] offset:%d" % (reg, reg + 3, ks, idx * 2048), ("fa", ks, idx))
@@ -116,7 +122,7 @@ FRAG_ORDER = [("w", 0)] + [("a", i) for i in range(NI)] + [("w", j) for j in ran
 
 def mfma(e, ks, n, first):
     i, j = n % NI, n // NI
-    e.need_lds({("fw", ks, j), ("fa", ks, i)})
+    e.need_lds({("fw", ks, j), ("fa", ks, i)}, emit="fragwait" not in ABL)     # (timing probe "fragwait": MFMAs on fragments that may not have landed)
     c = acc(i, j)
     src_c = "0" if first and ks == 0 else "a[%d:%d]" % (c, c + 3)         # a tile's first K step starts from zero
     e.raw("v_mfma_f32_16x16x32_bf16 a[%d:%d], v[%d:%d], v[%d:%d], %s" %
@@ -124,7 +130,9 @@ def mfma(e, ks, n, first):
 
 
 def store_piece(e, s):
-    e.need_vm({("st", s)})
+    if "stage" in ABL:                                       # (timing probe: the K loop without its staging instructions)
+        return
+    e.need_vm({("st", s)}, emit="vmwait" not in ABL)         # (timing probe "vmwait": stores of registers whose load may not have landed)
     reg = ST + 4 * s
     if s < 8:
         e.lds("ds_write_b128 %%[wA], v[%d:%d] offset:%d" % (reg, reg + 3, s * 4096), ("wr", s))
@@ -133,6 +141,8 @@ def store_piece(e, s):
 
 
 def load_piece(e, s):
+    if "stage" in ABL:
+        return
     reg = ST + 4 * s
     if s < 8:
         e.vmem("buffer_load_dwordx4 v[%d:%d], v%d, s[%d:%d], s%d offen" % (reg, reg + 3, VO + s, RS_A, RS_A + 3, S_SOA), ("st", s))

@@ -229,6 +229,16 @@ def section(r):
         (t + "_probe_mfma_lds_mix.txt", "one wave per SIMD, 64 independent accumulators, the up-projection's LDS reads (24 `ds_read_b128` per 32 K values) issued between the MFMAs: "
          "16x16x32 2428 → 2375 TFLOP/s, 32x32x16 2461 → 2341 -- neither shape loses issue to the reads of its own wave when nothing depends on them; the real K loop's 55 % is "
          "dependences and barriers, not instruction issue (round 4's additive model does not carry over)", "`tools/mfma_lds_mix.hip` (`tools/history/r6_call34.sh`)"),
+        (t + "_probe_mfma_operands.txt", "64 back-to-back `v_mfma_f32_16x16x32_bf16` per iteration, one wave per SIMD, on constant against RANDOM bf16 operands: 16.4 clocks per MFMA "
+         "either way, but 2.38 GHz = 2 430 TFLOP/s on constants and **1.92–2.08 GHz = 1 940–2 050 TFLOP/s on random data** -- with real operands the matrix cores alone sit at the "
+         "package power limit; the dense bf16 rate this part can sustain is ≈ 2.0 PFLOP/s, not the 2.5 of its peak clock", "`tools/mfma_operands.hip` (`tools/history/r6_call36.sh`)"),
+        (t + "_probe_t4_clock.txt", "per-wave shader-clock and real-time stamps around the generated statement of the two bf16 GEMMs: `gemm_bf16_t4_gelu_kernel` runs at 2.11 GHz, "
+         "a wave 77.7 k clocks = 36.7 µs of the 42.3 µs launch (its 2 048 MFMAs: 33.6 k); `gemm_bf16_t4_res_kernel<true>` 1.98 GHz, 64.7 k clocks = 32.6 µs of 40; the up-projection "
+         "with staging + fragment reads left out: 67.8 k clocks at 2.42 GHz (the memory instructions are 9.9 k clocks, the rest of that probe's gain is clock), also without the GELU: 59.4 k",
+         "`tools/t4_clock.py` on `-DPIPS_T4_CLOCK` builds (`tools/history/r6_call38.sh`, `r6_call39.sh`)"),
+        (t + "_probe_t4up_kloop_ablations.txt", "the up-projection's launch time with parts of its K loop left out (generator probes): without its waits on staged loads / its barriers / "
+         "its fragment waits: 41.6 / 42.5 / 42.2 against 42.3 µs -- no dependence stalls it; without staging 37.4, without fragment reads 37.7, without both 33.95 (most of that is the "
+         "higher clock of MFMAs on stale data, see `_t4_clock`)", "`PIPS_GEN_ABLATE=… python tools/gen_gemm_bf16_t4up.py` (`tools/history/r6_call35.sh`, `r6_call37.sh`)"),
         (t + "_probe_gather_final.txt", "`tools/gather_c4.py` on the final library: the three launches of both tiled gathers at config-4 geometry and the config-3 comparison "
          "(direct bf16-map kernel against the tiled matrix-core path)", "`python tools/gather_c4.py`"),
         (t + "_bf16_parity_tests.log", "`pytest -s` output of the bf16 parity tests on the one-rounding-contract build: configs[2] %s px against the autocast oracle, config-4 geometry "
