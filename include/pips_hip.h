@@ -121,8 +121,9 @@ int    pips_repack_weights_ex(const void* const* params_host, int nparams, void*
  * variants take 1 <= S <= PIPS_S_MAX (the arena must have been packed for the same S) and run the token mixing, the final
  * LayerNorm + mean and the state update on generic kernels (same arithmetic, not tuned), the GEMMs and the gather on
  * the same kernels as S = 8.  pips_forward / pips_workspace_bytes take S from their own argument.  Rows of the mixer output
- * (delta) are pips_delta_stride(S) = S*(C+2) rounded up to a multiple of 4 floats apart. */
-#define PIPS_S_MAX 16
+ * (delta) are pips_delta_stride(S) = S*(C+2) rounded up to a multiple of 4 floats apart.  (Round 6: 32, was 16 -- the generic
+ * kernels are instantiated for 16 and for 32 token registers and picked by S.) */
+#define PIPS_S_MAX 32
 size_t pips_weight_arena_bytes_s(int S);
 int    pips_repack_weights_s(const void* const* params_host, int nparams, void* arena, int S, int sections, void* stream);
 int    pips_delta_stride(int S);

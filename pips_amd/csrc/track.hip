@@ -928,8 +928,9 @@ static int launch_token_mix_any(const float* arena, const MixLayerW& L, float* x
 int launch_token_mix(const float* arena, const MixLayerW& L, float* x, float* xn, int particles,
                      hipStream_t st, int xn_bf16, int Sw, int x_bf16) {
     PIPS_CHECK_ARG(!x_bf16 || (xn_bf16 && Sw == PIPS_S), "token_mix: a bf16 residual stream needs the bf16 mixer and S = %d", PIPS_S);
-    if (Sw != PIPS_S)
-        return launch_token_mix_any<PIPS_S_MAX>(arena, L, x, xn, particles, st, xn_bf16, Sw);
+    if (Sw != PIPS_S)                                   // (two instantiations: S <= 16 keeps the register budget it had before PIPS_S_MAX = 32)
+        return Sw <= 16 ? launch_token_mix_any<16>(arena, L, x, xn, particles, st, xn_bf16, Sw)
+                        : launch_token_mix_any<PIPS_S_MAX>(arena, L, x, xn, particles, st, xn_bf16, Sw);
     if (xn_bf16 && (x_bf16 || PIPS_TUNE("PIPS_TOKEN_MFMA", 1))) {
         // bf16-operand mixer: token MLP on the matrix cores, one wave per particle
         if (x_bf16)
@@ -1042,7 +1043,8 @@ int launch_ln_mean(const float* x, const float* g, const float* b, float* out, i
                    hipStream_t st, int Sw, int x_bf16) {
     PIPS_CHECK_ARG(!x_bf16 || Sw == PIPS_S, "ln_mean: a bf16 residual stream needs S = %d", PIPS_S);
     if (Sw != PIPS_S) {
-        hipLaunchKernelGGL(ln_mean_any_kernel<PIPS_S_MAX>, dim3(particles), dim3(256), 0, st, x, g, b, out, Sw);
+        if (Sw <= 16) hipLaunchKernelGGL(ln_mean_any_kernel<16>, dim3(particles), dim3(256), 0, st, x, g, b, out, Sw);
+        else hipLaunchKernelGGL(ln_mean_any_kernel<PIPS_S_MAX>, dim3(particles), dim3(256), 0, st, x, g, b, out, Sw);
         PIPS_CHECK_LAUNCH("ln_mean_any_kernel");
         return PIPS_OK;
     }

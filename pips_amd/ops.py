@@ -58,7 +58,7 @@ def pack_weights(state_dict, device, sections=PACK_FP32 | PACK_BF16 | PACK_SPLIT
             raise ValueError(f"{k}: shape {tuple(state_dict[k].shape)}, a Pips(S={S}) holds {tuple(table[k][0])}")
     nbytes = lib.pips_weight_arena_bytes_s(int(S))
     if nbytes == 0:
-        raise ValueError(f"window length S={S} is outside 1..16")
+        raise ValueError(f"window length S={S} is outside 1..32")
     with torch.cuda.device(device):
         srcs = [_f32(state_dict[k].detach().to(device)) for k in names]
         arena = torch.empty(nbytes // 4, dtype=torch.float32, device=device)

@@ -13,7 +13,7 @@ only to DRAW (nets/pips.py:447,477-497,541-557,564-598 -- none of those branches
 where the callers' writer has ``save_this`` set (every ``log_freq``-th, test_on_flt.py:197,267-272) the forward warns once
 and returns exactly what it returns for ``sw=None``; ``losses`` carries the reference's ``(seq_loss, vis_loss, ce_loss)`` when ``trajs_g`` is given
 (nets/pips.py:600-606; the score-map loss is reduced on the fly by ``pips_forward_ce``).  ``S`` = 8 (the window of every
-shipped checkpoint and caller) runs kernels specialised for it; any other ``1 <= S <= 16`` runs the token mixing, the
+shipped checkpoint and caller) runs kernels specialised for it; any other ``1 <= S <= 32`` runs the token mixing, the
 final LayerNorm and the state update on generic HIP kernels (``pips_*_s`` entry points).  There is no
 PyTorch fallback: without the HIP library or a GPU the forward raises.
 
@@ -55,10 +55,10 @@ class _Node(nn.Module):
 class Pips(nn.Module):
     def __init__(self, S: int = 8, stride: int = 8):
         super().__init__()
-        if not 1 <= int(S) <= 16:
+        if not 1 <= int(S) <= 32:
             # the reference builds S-dependent mixer weights for any S (nets/pips.py:295-301); here S = 8 (every shipped
-            # checkpoint / caller) runs specialised kernels and 1..16 (PIPS_S_MAX) generic ones
-            raise ValueError("pips_amd.Pips supports window lengths S = 1..16")
+            # checkpoint / caller) runs specialised kernels and 1..32 (PIPS_S_MAX) generic ones
+            raise ValueError("pips_amd.Pips supports window lengths S = 1..32")
         self.S = S = int(S)
         self.stride = stride
         self.hidden_dim = 256

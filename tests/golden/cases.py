@@ -31,6 +31,7 @@ WINDOW_CASES = {
     "w5_tamed_i3": dict(S=5, B=1, N=6, H=128, W=160, stride=8, iters=3, tamed=True, border=False),
     "w12_tamed_i2": dict(S=12, B=1, N=5, H=128, W=160, stride=8, iters=2, tamed=True, border=False),
     "w4_raw_s4_i2": dict(S=4, B=2, N=7, H=96, W=128, stride=4, iters=2, tamed=False, border=True),
+    "w24_tamed_i2": dict(S=24, B=1, N=4, H=128, W=160, stride=8, iters=2, tamed=True, border=False),     # beyond 16: the SMAX = 32 kernels
 }
 
 

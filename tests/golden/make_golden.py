@@ -102,6 +102,11 @@ if __name__ == "__main__":
         make_demo_frames()
         run_case("demo_full_s4_i2", G.CASES["demo_full_s4_i2"])
         sys.exit(0)
+    if "--window" in sys.argv:               # ONE Pips(S != 8) fixture by name (the others stay byte for byte what they are)
+        assert R.available(), "reference not mounted at /root/reference"
+        nm = sys.argv[sys.argv.index("--window") + 1]
+        run_case(nm, G.WINDOW_CASES[nm])
+        sys.exit(0)
     if "--windows" in sys.argv:              # only the Pips(S != 8) fixtures
         main_windows()
         main_losses("w5_tamed_i3")

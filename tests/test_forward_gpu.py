@@ -69,7 +69,8 @@ def test_golden_reference_outputs(name, matmul, weights_raw, weights_tamed):
 @pytest.mark.parametrize("name", list(G.WINDOW_CASES))
 def test_golden_reference_outputs_window_lengths(name, matmul):
     """Pips(S != 8) (nets/pips.py:295-301, 401-402) against vectors of the unmodified reference built with the same S: odd S
-    (padded head rows), S > 8 (two row groups in the state update), S = 4 at stride 4 with border queries."""
+    (padded head rows), S > 8 (two row groups in the state update), S = 4 at stride 4 with border queries, S = 24 (beyond 16: the
+    generic kernels' 32-register instantiation)."""
     from pips_amd.weights import init_state_dict
     case = G.WINDOW_CASES[name]
     S = case["S"]
@@ -311,7 +312,7 @@ def test_errors_and_signature(weights_tamed):
     with pytest.raises(NotImplementedError):
         m(xys.to(DEV), rgbs.to(DEV), iters=1, is_train=True)
     with pytest.raises(ValueError):
-        Pips(S=17)                                               # window lengths 1..16 (PIPS_S_MAX)
+        Pips(S=33)                                               # window lengths 1..32 (PIPS_S_MAX)
     # trajs_g given (test_on_flt.py:87): losses tuple is produced, outputs unchanged
     tg = torch.zeros(1, 8, 4, 2, device=DEV)
     ones = torch.ones(1, 8, 4, device=DEV)
