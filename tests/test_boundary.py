@@ -50,7 +50,7 @@ def test_library_exports_every_declared_symbol():
     # sizing queries are pure host functions
     assert lib.pips_workspace_bytes(1, 8, 368, 496, 256, 8) > 0
     assert lib.pips_workspace_bytes(1, 7, 368, 496, 256, 8) > 0           # any window length 1..PIPS_S_MAX
-    assert lib.pips_workspace_bytes(1, 17, 368, 496, 256, 8) == 0 and lib.pips_weight_arena_bytes_s(17) == 0
+    assert lib.pips_workspace_bytes(1, 33, 368, 496, 256, 8) == 0 and lib.pips_weight_arena_bytes_s(33) == 0
     assert lib.pips_weight_arena_bytes_s(8) == lib.pips_weight_arena_bytes()
     assert lib.pips_weight_arena_bytes_s(5) < lib.pips_weight_arena_bytes() < lib.pips_weight_arena_bytes_s(12)
     assert lib.pips_delta_stride(8) == 1040 and lib.pips_delta_stride(5) == 652 and lib.pips_delta_stride(0) == 0
